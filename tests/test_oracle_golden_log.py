@@ -1,0 +1,138 @@
+"""Pin the oracle on the reference's only seeded whole-game vector.
+
+Fixture: tests/golden/example_game.jsonl = the mjai log embedded in the reference's
+log-viewer/index.example.html:10-264 (metadata stripped), seed (10637, 12210010324280706444).
+It pins: SHA3 input layout, ChaCha12 parameters, UNSHUFFLED order, the rand-0.8 shuffle, wall slice layout and
+pop direction (arena/board.rs:99-123), the whole event stream of three kyoku through BoardState::step
+(board.rs:511-678) incl. riichi acceptance, pon/chi, hora deltas and ura markers, and the action-id -> event
+decode of agent/mortal.rs:338-573.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "example_game.jsonl")
+
+
+def load_golden():
+    evs = [json.loads(l) for l in open(GOLDEN)]
+    assert evs[0]["type"] == "start_game" and evs[-1]["type"] == "end_game"
+    return evs[0]["seed"], evs[1:-1]
+
+
+def test_sha3_matches_hashlib(oracle):
+    rng = np.random.default_rng(0)
+    for n in [0, 1, 18, 135, 136, 137, 300]:
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        out = np.zeros(32, dtype=np.uint8)
+        oracle.lib().mjo_sha3_256(oracle.ptr(data), n, oracle.ptr(out))
+        assert out.tobytes() == hashlib.sha3_256(data.tobytes()).digest()
+
+
+def test_chacha12_rfc_style_vector(oracle):
+    # ChaCha with an all-zero key/nonce: first block of the 20-round variant is the RFC 7539 test vector; for the
+    # 12-round variant the widely published first words are 0x6a9af49b ... (rand_chacha's `test_chacha_true_values_c`
+    # style).  We only assert self-consistency here (determinism + counter advance); the golden deal pins the rest.
+    seed = np.zeros(32, dtype=np.uint8)
+    a = np.zeros(40, dtype=np.uint32)
+    b = np.zeros(40, dtype=np.uint32)
+    oracle.lib().mjo_chacha12(oracle.ptr(seed), 40, oracle.ptr(a))
+    oracle.lib().mjo_chacha12(oracle.ptr(seed), 40, oracle.ptr(b))
+    assert (a == b).all() and len(set(a.tolist())) > 30
+
+
+def test_deal_matches_golden_log(oracle):
+    (nonce, key), evs = load_golden()
+    kyokus = []
+    for e in evs:
+        if e["type"] == "start_kyoku":
+            kyokus.append([e])
+        else:
+            kyokus[-1].append(e)
+    assert len(kyokus) == 3
+    for kev in kyokus:
+        sk = kev[0]
+        kyoku = (oracle.TILE_ID[sk["bakaze"]] - 27) * 4 + sk["kyoku"] - 1
+        seq = oracle.deal(nonce, key, kyoku, sk["honba"], algo=0)
+        names = [oracle.TILE_NAMES[t] for t in seq]
+        assert [names[i * 13:(i + 1) * 13] for i in range(4)] == sk["tehais"]
+        assert names[60] == sk["dora_marker"]  # dora_indicators = seq[56:61], popped from the back
+        yama = names[66:136]
+        draws = [e["pai"] for e in kev if e["type"] == "tsumo"]
+        assert draws == yama[::-1][:len(draws)]  # no kans in this log: every tsumo comes from the wall
+        for e in kev:
+            if e["type"] == "hora":
+                n = len(e["ura_markers"])
+                assert e["ura_markers"] == names[61:61 + n]
+
+
+def _action_of(ev, oracle):
+    t = ev["type"]
+    if t == "dahai":
+        return oracle.TILE_ID[ev["pai"]], -1
+    if t == "reach":
+        return 37, -1
+    if t == "chi":
+        c = sorted(oracle.TILE_ID[x] if oracle.TILE_ID[x] < 34 else {34: 4, 35: 13, 36: 22}[oracle.TILE_ID[x]]
+                   for x in ev["consumed"])
+        p = oracle.TILE_ID[ev["pai"]]
+        p = p if p < 34 else {34: 4, 35: 13, 36: 22}[p]
+        return (38 if p < c[0] else 39 if p < c[1] else 40), -1
+    if t == "pon":
+        return 41, -1
+    if t in ("daiminkan", "ankan", "kakan"):
+        return 42, -1
+    if t == "hora":
+        return 43, -1
+    if t == "ryukyoku":
+        return 44, -1
+    raise AssertionError(t)
+
+
+def test_replay_golden_log_through_board(oracle):
+    (nonce, key), golden = load_golden()
+    arena = oracle.Arena([(nonce, key)], deal_algo=0, enable_quick_eval=False, version=4)
+    board_generated = {"tsumo", "reach_accepted", "dora", "start_kyoku", "end_kyoku"}
+    done = False
+    for _cycle in range(400):
+        rows = arena.poll()
+        log = arena.log(0)
+        n = len(log)
+        assert log == golden[:n], (log[-1], golden[n - 1])
+        if n >= len(golden):
+            done = True
+            break
+        assert len(rows) > 0
+        # the next logged events decide who acts
+        nxt = golden[n]
+        actors = {}
+        if nxt["type"] not in board_generated:
+            k = n
+            while k < len(golden) and golden[k]["type"] == nxt["type"] == "hora":
+                actors[golden[k]["actor"]] = golden[k]
+                k += 1
+            if not actors:
+                actors[nxt.get("actor")] = nxt
+        _, masks = arena.encode(0, len(rows), want_obs=False)
+        actions = []
+        for (g, seat, is_kan), mask in zip(rows, masks):
+            assert not is_kan
+            if seat in actors:
+                a, _ = _action_of(actors[seat], oracle)
+            else:
+                a = 45
+            assert mask[a], (seat, a, nxt)
+            actions.append(a)
+        arena.commit(actions)
+    assert done
+    # scores after the three kyoku = 25000 + sum of hora deltas
+    view = arena.game_view(0)
+    expect = np.array([25000] * 4)
+    for e in golden:
+        if e["type"] == "hora":
+            expect += np.array(e["deltas"])
+        if e["type"] == "reach_accepted":
+            expect[e["actor"]] -= 1000
+    assert view[4:8].tolist() == expect.tolist()
