@@ -1,0 +1,92 @@
+/* mortal_amd — C-ABI of the MI355X-native batched riichi arena (drop-in for the hot path of Mortal's `libriichi`).
+ *
+ * Plain C: pointers and sizes only, no torch / C++ types.  Device pointers are raw HIP device addresses
+ * (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void* (0 = default stream).
+ * Every function returns 0 on success or a negative code; mj_last_error() describes the failure.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to libriichi/src):
+ *
+ *   mj_tables_upload      algo/shanten.rs:11-44 + algo/agari.rs:24-51   (lazy-static table loading)
+ *   mj_pool_create/reset  arena/game.rs:230-266  BatchGame::run set-up: one Game per (seed, seat plan)
+ *                         arena/one_vs_three.rs:140-191  seed list / agent index planning (done by the caller)
+ *   mj_pool_configure     agent/mortal.rs:53-74  engine attributes read once per agent
+ *   mj_step               arena/game.rs:286-304  one poll/commit cycle over every live game:
+ *                           Game::commit (game.rs:180-218) + agent/mortal.rs:292-573 get_reaction (action decode)
+ *                           Game::poll   (game.rs:59-178)  + BoardState::poll/step (board.rs:141-161,511-678)
+ *                           agent/mortal.rs:200-250 set_scene (quick-eval, kan-select classification)
+ *   mj_rows_count         agent/mortal.rs:118-123  batch size of the coming react_batch call
+ *   mj_encode             agent/mortal.rs:252-287 -> state/obs_repr.rs:126-630  obs + mask for every row of the batch
+ *   mj_random_policy      (no reference counterpart: BASELINE config 2's uniform-random legal policy)
+ *   mj_results            arena/result.rs:19-30 GameResult.scores; arena/one_vs_three.rs:55-60 ranking input
+ *   mj_counters           arena/game.rs:298-311 cycles/actions progress counters
+ */
+#ifndef MORTAL_AMD_H
+#define MORTAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct MjPool MjPool;
+
+enum { MJ_DEAL_RAND08 = 0, MJ_DEAL_RAND09 = 1 };
+
+const char* mj_last_error(void);
+int mj_abi_version(void);
+
+/* Upload the lookup tables (payload format: mortal_amd/tables.py, 'MJT1').  Once per process and device. */
+int mj_tables_upload(const void* payload, size_t size);
+
+/* n_tables concurrent tables; obs `version` 1..4 (consts.rs:20-28); max_rows = capacity of the row lists per agent
+ * (0 -> 8 * n_tables, the theoretical maximum). */
+MjPool* mj_pool_create(int n_tables, int version, int deal_algo, int max_rows);
+void mj_pool_destroy(MjPool* pool);
+
+/* Start n_tables games.  Host arrays of length n_tables: seed nonce/key (board.rs:99-107), global game id, and
+ * agent_of_seat (bit s = agent index 0/1 of seat s).  n_games_total sizes the result arrays (>= max game id + 1). */
+int mj_pool_reset(MjPool* pool, const uint64_t* nonces, const uint64_t* keys, const uint32_t* game_ids,
+                  const uint8_t* agent_of_seat, int n_games_total);
+
+/* Per-agent engine attributes (agent/mortal.rs:53-74). */
+int mj_pool_configure(MjPool* pool, int agent, int enable_quick_eval, int enable_rule_based_agari_guard);
+/* Steady-state mode for throughput runs: finished tables restart with nonce += stride. 0 disables. */
+int mj_pool_set_refill(MjPool* pool, uint64_t nonce_stride);
+
+/* One arena cycle.  actions_dev[a] = int32 device array with one action id (0..45) per row of agent a's previous
+ * batch (NULL on the first cycle or when that agent had no rows). */
+int mj_step(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_dev1, void* stream);
+
+/* Number of policy rows per agent produced by the last mj_step (synchronises `stream`). */
+int mj_rows_count(MjPool* pool, int32_t n_rows_out[2], void* stream);
+/* Device array of row descriptors of agent a: table | seat << 28 | is_kan_select << 31. */
+const uint32_t* mj_rows_dev(MjPool* pool, int agent);
+
+/* Encode agent a's rows: obs_dev [n_rows][C][34] f32, masks_dev [n_rows][46] u8 (bool). */
+int mj_encode(MjPool* pool, int agent, float* obs_dev, uint8_t* masks_dev, void* stream);
+/* Average duration (ms) of the encode kernel launches timed with HIP events since the last call, and their count. */
+int mj_encode_timing(MjPool* pool, int enable, double* total_ms_out, int64_t* launches_out);
+
+/* Uniform-random legal action per row, counter-based (seed, game id, seat, kan flag, cycle). */
+int mj_random_policy(MjPool* pool, int agent, const uint8_t* masks_dev, uint64_t seed, uint64_t cycle,
+                     int32_t* actions_dev, void* stream);
+
+/* counters: [0] env steps (live tables summed over cycles), [1] games finished, [2] tables in error,
+ *           [3] decisions, [4] quick-eval decisions, [5] cycles */
+int mj_counters(MjPool* pool, uint64_t out[8], void* stream);
+/* Final scores [n_games_total][4] and done flags (0 running, 1 finished, 2 aborted on error) to host memory. */
+int mj_results(MjPool* pool, int32_t* scores_out, uint8_t* done_out, void* stream);
+/* First table in error: returns its error code (>0) and index, or 0. */
+int mj_pool_first_error(MjPool* pool, int* table_out, void* stream);
+
+/* Debug/test: copy one table's state (struct TableOne, mortal_amd/csrc/mj_state.h) to host memory. */
+int mj_debug_table(MjPool* pool, int table, void* out, size_t out_size, void* stream);
+size_t mj_debug_table_size(void);
+int mj_obs_rows(int version);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

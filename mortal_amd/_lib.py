@@ -1,0 +1,62 @@
+"""ctypes binding of the C-ABI in include/mortal_amd.h (libmortal_amd.so, built by __graft_entry__.build()).
+
+There is no fallback: if the shared library is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libmortal_amd.so")
+
+# Every symbol include/mortal_amd.h declares (tests/test_abi.py checks the library exports all of them).
+SYMBOLS = [
+    "mj_last_error", "mj_abi_version", "mj_tables_upload", "mj_pool_create", "mj_pool_destroy", "mj_pool_reset",
+    "mj_pool_configure", "mj_pool_set_refill", "mj_step", "mj_rows_count", "mj_rows_dev", "mj_encode",
+    "mj_encode_timing", "mj_random_policy", "mj_counters", "mj_results", "mj_pool_first_error", "mj_debug_table",
+    "mj_debug_table_size", "mj_obs_rows",
+]
+
+
+class MortalAmdError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise MortalAmdError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The HIP extension is mandatory; there is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+    L.mj_last_error.restype = C.c_char_p
+    L.mj_tables_upload.argtypes = [vp, C.c_size_t]
+    L.mj_pool_create.restype = vp
+    L.mj_pool_create.argtypes = [i32, i32, i32, i32]
+    L.mj_pool_destroy.argtypes = [vp]
+    L.mj_pool_reset.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.mj_pool_configure.argtypes = [vp, i32, i32, i32]
+    L.mj_pool_set_refill.argtypes = [vp, u64]
+    L.mj_step.argtypes = [vp, vp, vp, vp]
+    L.mj_rows_count.argtypes = [vp, vp, vp]
+    L.mj_rows_dev.restype = vp
+    L.mj_rows_dev.argtypes = [vp, i32]
+    L.mj_encode.argtypes = [vp, i32, vp, vp, vp]
+    L.mj_encode_timing.argtypes = [vp, i32, vp, vp]
+    L.mj_random_policy.argtypes = [vp, i32, vp, u64, u64, vp, vp]
+    L.mj_counters.argtypes = [vp, vp, vp]
+    L.mj_results.argtypes = [vp, vp, vp, vp]
+    L.mj_pool_first_error.argtypes = [vp, vp, vp]
+    L.mj_debug_table.argtypes = [vp, i32, vp, C.c_size_t, vp]
+    L.mj_debug_table_size.restype = C.c_size_t
+    L.mj_obs_rows.argtypes = [i32]
+    return L
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise MortalAmdError(lib.mj_last_error().decode())
+    return rc

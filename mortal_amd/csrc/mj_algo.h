@@ -1,0 +1,595 @@
+// Device-side riichi primitives for gfx950: tile helpers, register-packed hands, shanten, agari, points.
+//
+// Hands are NOT arrays here: the 34 tile counts (0..4) are packed 3 bits per tile into two 64-bit
+// registers (`mp` = man+pin, `sz` = sou+honours).  A modified copy of a hand is a register move, the
+// base-5 shanten keys come from static shifts, and nothing is dynamically indexed in scratch or LDS.
+//
+// Functional specs (reference, /root/reference/libriichi/src): algo/shanten.rs:51-150,
+// algo/agari.rs:126-157,203-912, algo/point.rs:13-112, tile.rs:68-150.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mj_state.h"
+
+#define MJD __device__ __forceinline__
+#define MJDN __device__ __noinline__
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+enum : int { T_5M = 4, T_5P = 13, T_5S = 22, T_E = 27, T_S = 28, T_W = 29, T_N = 30, T_P = 31, T_F = 32, T_C = 33,
+             T_5MR = 34, T_5PR = 35, T_5SR = 36, T_UNK = 37 };
+
+MJD int deaka(int t) { return t >= 34 ? (t == 34 ? 4 : t == 35 ? 13 : t == 36 ? 22 : t) : t; }
+MJD bool is_aka(int t) { return t >= 34 && t <= 36; }
+MJD int akaize(int t) { return t == 4 ? 34 : t == 13 ? 35 : t == 22 ? 36 : t; }
+MJD bool is_jihai(int t) { return t >= 27 && t <= 33; }
+MJD bool is_yaokyuu(int t) { return t < 34 && (t >= 27 || t % 9 == 0 || t % 9 == 8); }
+MJD int tile_next(int t) {  // tile.rs:117-132 (dora wrap)
+    if (t >= 37) return t;
+    t = deaka(t);
+    int kind = t / 9, num = t % 9;
+    if (kind < 3) return kind * 9 + (num + 1) % 9;
+    if (num < 4) return 27 + (num + 1) % 4;
+    return 31 + (num - 4 + 1) % 3;
+}
+MJD int tile_prev(int t) {  // tile.rs:134-150
+    if (t >= 37) return t;
+    t = deaka(t);
+    int kind = t / 9, num = t % 9;
+    if (kind < 3) return kind * 9 + (num + 8) % 9;
+    if (num < 4) return 27 + (num + 3) % 4;
+    return 31 + (num - 4 + 2) % 3;
+}
+constexpr u64 YAOKYUU_MASK = (1ull << 0) | (1ull << 8) | (1ull << 9) | (1ull << 17) | (1ull << 18) | (1ull << 26) |
+                             (0x7Full << 27);
+
+// ---------------------------------------------------------------- packed hand
+struct Hand {
+    u64 mp;  // tiles 0..17  at bit 3*t
+    u64 sz;  // tiles 18..33 at bit 3*(t-18)
+    MJD int get(int t) const { return t < 18 ? (int)((mp >> (3 * t)) & 7) : (int)((sz >> (3 * (t - 18))) & 7); }
+    MJD void inc(int t) {
+        if (t < 18) mp += 1ull << (3 * t);
+        else sz += 1ull << (3 * (t - 18));
+    }
+    MJD void dec(int t) {
+        if (t < 18) mp -= 1ull << (3 * t);
+        else sz -= 1ull << (3 * (t - 18));
+    }
+    MJD void clear(int t) {
+        if (t < 18) mp &= ~(7ull << (3 * t));
+        else sz &= ~(7ull << (3 * (t - 18)));
+    }
+    MJD bool empty() const { return (mp | sz) == 0; }
+    MJD u64 nonzero_mask() const {  // bit t set iff count(t) > 0
+        u64 m = 0;
+#pragma unroll
+        for (int t = 0; t < 34; t++) m |= (u64)(get(t) != 0) << t;
+        return m;
+    }
+};
+
+// ---------------------------------------------------------------- shanten (shanten.rs:51-150)
+MJD u32 suit_key9(u64 bits) {  // 9 packed counts, first tile most significant (shanten.rs:82-84)
+    u32 k = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k = k * 5 + (u32)((bits >> (3 * i)) & 7);
+    return k;
+}
+MJD u32 suit_key7(u64 bits) {
+    u32 k = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) k = k * 5 + (u32)((bits >> (3 * i)) & 7);
+    return k;
+}
+// Row = 10 nibbles in a u64 (nibble j at bits 4j).  Index past the table -> zeros (`unwrap_or_default`).
+MJD u64 sh_row(const u64* __restrict__ tab, u32 n, u32 idx) { return idx < n ? tab[idx] : 0ull; }
+#define NIB(r, j) ((int)(((r) >> (4 * (j))) & 15))
+
+MJD void sh_unpack(u64 r, int v[10]) {
+#pragma unroll
+    for (int j = 0; j < 10; j++) v[j] = NIB(r, j);
+}
+MJD void sh_add_suhai(int lhs[10], u64 tab, int m) {  // shanten.rs:51-69
+#pragma unroll
+    for (int j = 9; j >= 5; j--) {
+        if (j > 5 + m) continue;
+        int sht = min(lhs[j] + NIB(tab, 0), lhs[0] + NIB(tab, j));
+#pragma unroll
+        for (int k = 5; k < 9; k++) {
+            if (k >= j) continue;
+            sht = min(sht, min(lhs[k] + NIB(tab, j - k), lhs[j - k] + NIB(tab, k)));
+        }
+        lhs[j] = sht;
+    }
+#pragma unroll
+    for (int j = 4; j >= 0; j--) {
+        if (j > m) continue;
+        int sht = lhs[j] + NIB(tab, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= j) continue;
+            sht = min(sht, lhs[k] + NIB(tab, j - k));
+        }
+        lhs[j] = sht;
+    }
+}
+MJD int sh_add_jihai_final(const int lhs[10], u64 tab, int m) {  // shanten.rs:71-80, returns lhs[5+m]
+    int j = m + 5;
+    int sht = min(lhs[j] + NIB(tab, 0), lhs[0] + NIB(tab, j));
+#pragma unroll
+    for (int k = 5; k < 9; k++) {
+        if (k >= j) continue;
+        sht = min(sht, min(lhs[k] + NIB(tab, j - k), lhs[j - k] + NIB(tab, k)));
+    }
+    return sht;
+}
+MJD int calc_normal(const MjTablesDev& T, Hand h, int len_div3) {  // shanten.rs:88-102
+    u32 km = suit_key9(h.mp), kp = suit_key9(h.mp >> 27), ks = suit_key9(h.sz), kz = suit_key7(h.sz >> 27);
+    u64 rm = sh_row(T.suhai, T.n_suhai, km);
+    u64 rp = sh_row(T.suhai, T.n_suhai, kp);
+    u64 rs = sh_row(T.suhai, T.n_suhai, ks);
+    u64 rz = sh_row(T.jihai, T.n_jihai, kz);
+    int v[10];
+    sh_unpack(rm, v);
+    sh_add_suhai(v, rp, len_div3);
+    sh_add_suhai(v, rs, len_div3);
+    return sh_add_jihai_final(v, rz, len_div3) - 1;
+}
+MJD int calc_chitoi(Hand h) {  // shanten.rs:104-118
+    int pairs = 0, kinds = 0;
+#pragma unroll
+    for (int t = 0; t < 34; t++) {
+        int c = h.get(t);
+        kinds += c > 0;
+        pairs += c >= 2;
+    }
+    int redunct = kinds >= 7 ? 0 : 7 - kinds;
+    return 7 - pairs + redunct - 1;
+}
+MJD int calc_kokushi(Hand h) {  // shanten.rs:120-137
+    int pairs = 0, kinds = 0;
+#pragma unroll
+    for (int t = 0; t < 34; t++) {
+        if (!((YAOKYUU_MASK >> t) & 1)) continue;
+        int c = h.get(t);
+        kinds += c > 0;
+        pairs += c >= 2;
+    }
+    return 14 - kinds - (pairs > 0) - 1;
+}
+MJD int calc_all(const MjTablesDev& T, Hand h, int len_div3) {  // shanten.rs:139-150
+    int s = calc_normal(T, h, len_div3);
+    if (s <= 0 || len_div3 < 4) return s;
+    s = min(s, calc_chitoi(h));
+    if (s > 0) s = min(s, calc_kokushi(h));
+    return s;
+}
+
+// ---------------------------------------------------------------- points (point.rs:13-112)
+// The reference's match table equals the textbook formula on its whole domain (its own test,
+// point.rs:121-153, asserts exactly that), so the device uses the closed form.
+struct Point {
+    int ron, tsumo_ko, tsumo_oya;
+};
+MJD int ceil100(int x) { return (x + 99) / 100 * 100; }
+MJD Point point_calc(bool is_oya, int fu, int han) {
+    int base;
+    if (han >= 13) base = 8000;
+    else if (han >= 11) base = 6000;
+    else if (han >= 8) base = 4000;
+    else if (han >= 6) base = 3000;
+    else {
+        base = fu << (han + 2);
+        if (han >= 5 || base >= 2000) base = 2000;
+    }
+    Point p;
+    if (is_oya) {
+        p.ron = ceil100(base * 6);
+        p.tsumo_ko = ceil100(base * 2);
+        p.tsumo_oya = 0;
+    } else {
+        p.ron = ceil100(base * 4);
+        p.tsumo_ko = ceil100(base);
+        p.tsumo_oya = ceil100(base * 2);
+    }
+    return p;
+}
+MJD Point point_yakuman(bool is_oya, int n) {
+    Point p;
+    if (is_oya) { p.ron = 48000 * n; p.tsumo_ko = 16000 * n; p.tsumo_oya = 0; }
+    else { p.ron = 32000 * n; p.tsumo_ko = 8000 * n; p.tsumo_oya = 16000 * n; }
+    return p;
+}
+MJD int tsumo_total(Point p, bool is_oya) { return is_oya ? p.tsumo_ko * 3 : p.tsumo_ko * 2 + p.tsumo_oya; }
+
+// ---------------------------------------------------------------- agari (agari.rs)
+struct Melds {  // own open/closed sets, deaka'd tile ids (lowest tile for chi)
+    u8 chis[4], pons[4], minkans[4], ankans[4];
+    u8 n_chis, n_pons, n_minkans, n_ankans;
+};
+struct AgariIn {
+    Hand tehai;  // 3n+2 incl. the winning tile
+    Melds m;
+    bool is_menzen;
+    int bakaze, jikaze, winning_tile;
+    bool is_ron;
+};
+struct Agari {
+    int kind;  // 0 none, 1 normal, 2 yakuman
+    int fu, han;  // yakuman: han = count
+};
+MJD bool agari_better(Agari a, Agari b) {  // a > b per agari.rs:180-195
+    if (a.kind == 2 && b.kind == 2) return a.han > b.han;
+    if (a.kind == 2) return true;
+    if (b.kind == 2) return false;
+    if (a.han != b.han) return a.han > b.han;
+    return a.fu > b.fu;
+}
+
+// agari.rs:767-838: distinct tiles in ascending id + run-length key
+MJDN u32 tile14_and_key(Hand h, u8 tile14[14]) {
+    int n14 = 0;
+    u32 key = 0;
+    int bit = -1;
+    bool prev = false;
+    for (int t = 0; t < 27; t++) {
+        int c = h.get(t);
+        if (c > 0) {
+            prev = true;
+            tile14[n14++] = (u8)t;
+            bit += 1;
+            if (c == 2) { key |= 0b11u << bit; bit += 2; }
+            else if (c == 3) { key |= 0b1111u << bit; bit += 4; }
+            else if (c == 4) { key |= 0b111111u << bit; bit += 6; }
+        } else if (prev) {
+            prev = false;
+            key |= 1u << bit;
+            bit += 1;
+        }
+        if (t % 9 == 8 && prev) {
+            prev = false;
+            key |= 1u << bit;
+            bit += 1;
+        }
+    }
+    for (int t = 27; t < 34; t++) {
+        int c = h.get(t);
+        if (c == 0) continue;
+        tile14[n14++] = (u8)t;
+        bit += 1;
+        if (c == 2) { key |= 0b11u << bit; bit += 2; }
+        else if (c == 3) { key |= 0b1111u << bit; bit += 4; }
+        else if (c == 4) { key |= 0b111111u << bit; bit += 6; }
+        key |= 1u << bit;
+        bit += 1;
+    }
+    for (int i = n14; i < 14; i++) tile14[i] = 0;
+    return key;
+}
+MJD int agari_find(const MjTablesDev& T, u32 key) {  // index or -1 (binary search over sorted keys)
+    int lo = 0, hi = (int)T.n_agari;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        u32 k = T.agari_keys[mid];
+        if (k < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < (int)T.n_agari && T.agari_keys[lo] == key) ? lo : -1;
+}
+
+// One decomposition of the concealed part + the caller's melds (agari.rs:100-124, 287-761).
+struct DivWork {
+    const AgariIn* in;
+    int pair_tile;
+    u8 kotsu[8];    // menzen kotsu, then pons, minkans, ankans
+    int n_mk, n_kotsu;
+    u8 shuntsu[8];  // menzen shuntsu, then chis
+    int n_ms, n_shuntsu;
+    u8 seven[7];    // chitoi pairs
+    bool has_chitoi, has_chuuren, has_ittsuu, has_ryanpeikou, has_ipeikou;
+    bool wt_minkou;  // winning_tile_makes_minkou
+};
+MJDN void div_init(DivWork& w, const AgariIn& in, const u8 tile14[14], u32 v) {  // agari.rs:126-157, 288-338
+    w.in = &in;
+    w.pair_tile = tile14[(v >> 6) & 15];
+    int nk = v & 7, ns = (v >> 3) & 7;
+    w.n_mk = nk;
+    w.n_ms = ns;
+    for (int i = 0; i < nk; i++) w.kotsu[i] = tile14[(v >> (10 + i * 4)) & 15];
+    for (int i = 0; i < ns; i++) w.shuntsu[i] = tile14[(v >> (10 + (nk + i) * 4)) & 15];
+    int k = nk;
+    for (int i = 0; i < in.m.n_pons; i++) w.kotsu[k++] = in.m.pons[i];
+    for (int i = 0; i < in.m.n_minkans; i++) w.kotsu[k++] = in.m.minkans[i];
+    for (int i = 0; i < in.m.n_ankans; i++) w.kotsu[k++] = in.m.ankans[i];
+    w.n_kotsu = k;
+    k = ns;
+    for (int i = 0; i < in.m.n_chis; i++) w.shuntsu[k++] = in.m.chis[i];
+    w.n_shuntsu = k;
+    for (int i = 0; i < 7; i++) w.seven[i] = tile14[i];
+    w.has_chitoi = (v >> 26) & 1;
+    w.has_chuuren = (v >> 27) & 1;
+    w.has_ittsuu = (v >> 28) & 1;
+    w.has_ryanpeikou = (v >> 29) & 1;
+    w.has_ipeikou = (v >> 30) & 1;
+    // winning_tile_makes_minkou (agari.rs:314-338)
+    bool r = false;
+    if (in.is_ron) {
+        bool in_kotsu = false;
+        for (int i = 0; i < nk; i++) in_kotsu |= w.kotsu[i] == in.winning_tile;
+        if (in_kotsu) {
+            if (in.winning_tile >= 27) r = true;
+            else {
+                int kind = in.winning_tile / 9, num = in.winning_tile % 9;
+                int low = kind * 9 + (num >= 2 ? num - 2 : 0), high = kind * 9 + min(num, 6);
+                bool covered = false;
+                for (int i = 0; i < ns; i++) covered |= w.shuntsu[i] >= low && w.shuntsu[i] <= high;
+                r = !covered;
+            }
+        }
+    }
+    w.wt_minkou = r;
+}
+MJDN int div_calc_fu(const DivWork& w, bool has_pinfu) {  // agari.rs:367-452
+    const AgariIn& in = *w.in;
+    if (w.has_chitoi) return 25;
+    int fu = 20;
+    for (int i = 0; i < w.n_mk; i++) {
+        int t = w.kotsu[i];
+        bool mink = w.wt_minkou && t == in.winning_tile, yao = is_yaokyuu(t);
+        fu += (!mink && yao) ? 8 : (mink && !yao) ? 2 : 4;
+    }
+    for (int i = 0; i < in.m.n_pons; i++) fu += is_yaokyuu(in.m.pons[i]) ? 4 : 2;
+    for (int i = 0; i < in.m.n_ankans; i++) fu += is_yaokyuu(in.m.ankans[i]) ? 32 : 16;
+    for (int i = 0; i < in.m.n_minkans; i++) fu += is_yaokyuu(in.m.minkans[i]) ? 16 : 8;
+    int pt = w.pair_tile;
+    if (pt >= T_P && pt <= T_C) fu += 2;
+    else {
+        if (pt == in.bakaze) fu += 2;
+        if (pt == in.jikaze) fu += 2;
+    }
+    if (fu == 20) {
+        if (!in.is_menzen) return 30;
+        if (has_pinfu) return in.is_ron ? 30 : 20;
+        return in.is_ron ? 40 : 30;
+    }
+    if (!in.is_ron) fu += 2;
+    else if (in.is_menzen) fu += 10;
+    if (!w.wt_minkou) {
+        if (pt == in.winning_tile) fu += 2;
+        else {
+            bool kp = false;
+            for (int i = 0; i < w.n_ms; i++) {
+                int s = w.shuntsu[i];
+                kp |= s + 1 == in.winning_tile || (s % 9 == 0 && s + 2 == in.winning_tile) ||
+                      (s % 9 == 6 && s == in.winning_tile);
+            }
+            if (kp) fu += 2;
+        }
+    }
+    return ((fu - 1) / 10 + 1) * 10;
+}
+
+// Yaku search of one decomposition.  `any_only`: stop at the first yaku found (has_yaku path).
+// Unlike the reference's early-return macro we simply test han|yakuman after each group — the
+// boolean answer is identical because every check only ever adds.
+MJDN Agari div_search_yakus(const DivWork& w, bool any_only) {  // agari.rs:454-761
+    const AgariIn& in = *w.in;
+    int han = 0, yakuman = 0;
+    const int pt = w.pair_tile;
+    const bool pair_is_dragon = pt >= T_P && pt <= T_C;
+    bool has_pinfu = false;
+    if (w.n_ms == 4 && !pair_is_dragon && pt != in.bakaze && pt != in.jikaze) {
+        for (int i = 0; i < 4; i++) {
+            int s = w.shuntsu[i], num = s % 9 + 1;
+            has_pinfu |= (num <= 6 && s == in.winning_tile) || (num >= 2 && s + 2 == in.winning_tile);
+        }
+    }
+#define DONE_IF_ANY() if (any_only && (han | yakuman)) goto done
+    if (has_pinfu) han += 1;
+    if (w.has_chitoi) han += 2;
+    if (w.has_ryanpeikou) han += 3;
+    if (w.has_chuuren) yakuman += 1;
+    DONE_IF_ANY();
+    {
+        bool has_tanyao = true, has_toitoi, all_yao = true, yao_jihai = false;
+        u32 kinds_seen = 0;  // bit kind (0..2) for suited, bit 3 for honours, over every set + pair
+        if (w.has_chitoi) {
+            for (int i = 0; i < 7; i++) {
+                int t = w.seven[i], kind = t / 9, num = t % 9;
+                has_tanyao &= kind < 3 && num > 0 && num < 8;
+                bool y = kind >= 3 || num == 0 || num == 8;
+                all_yao &= y;
+                yao_jihai |= kind >= 3;
+                kinds_seen |= 1u << min(kind, 3);
+            }
+        } else {
+            for (int i = 0; i < w.n_shuntsu; i++) {
+                int s = w.shuntsu[i], num = s % 9;
+                has_tanyao &= num > 0 && num < 6;
+                kinds_seen |= 1u << (s / 9);
+            }
+            for (int i = 0; i <= w.n_kotsu; i++) {
+                int t = i < w.n_kotsu ? w.kotsu[i] : pt, kind = t / 9, num = t % 9;
+                has_tanyao &= kind < 3 && num > 0 && num < 8;
+                bool y = kind >= 3 || num == 0 || num == 8;
+                all_yao &= y;
+                yao_jihai |= kind >= 3;
+                kinds_seen |= 1u << min(kind, 3);
+            }
+        }
+        if (has_tanyao) han += 1;
+        has_toitoi = !w.has_chitoi && w.n_ms == 0 && in.m.n_chis == 0;
+        if (has_toitoi) han += 2;
+        // 字一色 / 混一色 / 清一色 (agari.rs:533-571)
+        {
+            u32 suits = kinds_seen & 7;
+            bool has_jihai = (kinds_seen >> 3) & 1;
+            if (suits == 0) yakuman += 1;
+            else if ((suits & (suits - 1)) == 0) han += (has_jihai ? 2 : 5) + (in.is_menzen ? 1 : 0);
+        }
+        DONE_IF_ANY();
+
+        if (!w.has_chitoi) {
+            // 一盃口 (agari.rs:573-596)
+            if (w.has_ipeikou) han += 1;
+            else if (in.m.n_ankans > 0 && in.is_menzen && w.n_ms >= 2) {
+                u32 marks = 0;
+                bool dup = false;
+                for (int i = 0; i < w.n_ms; i++) {
+                    u32 b = 1u << w.shuntsu[i];  // tile ids < 27
+                    dup |= (marks & b) != 0;
+                    marks |= b;
+                }
+                if (dup) han += 1;
+            }
+            // 一気通貫 (agari.rs:598-619)
+            if (in.is_menzen && w.has_ittsuu) han += 2;
+            else if (in.m.n_chis == 0 && w.has_ittsuu) han += 1;
+            else if (w.n_shuntsu >= 3) {
+                u32 starts = 0;
+                for (int i = 0; i < w.n_shuntsu; i++) starts |= 1u << w.shuntsu[i];
+                bool itt = false;
+                for (int k = 0; k < 3; k++) itt |= ((starts >> (9 * k)) & 0b1001001u) == 0b1001001u;
+                if (itt) han += 1;
+            }
+            // 三色同順 / 三色同刻 (agari.rs:621-647)
+            {
+                u32 s_bits = 0, k_bits = 0;
+                for (int i = 0; i < w.n_shuntsu; i++) s_bits |= 1u << w.shuntsu[i];
+                for (int i = 0; i < w.n_kotsu; i++)
+                    if (w.kotsu[i] < 27) k_bits |= 1u << w.kotsu[i];
+                u32 s3 = s_bits & (s_bits >> 9) & (s_bits >> 18) & 0x1FF;
+                u32 k3 = k_bits & (k_bits >> 9) & (k_bits >> 18) & 0x1FF;
+                if (s3) han += in.is_menzen ? 2 : 1;
+                else if (k3) han += 2;
+            }
+            // 暗刻 / 槓子 (agari.rs:649-666)
+            int ankous = in.m.n_ankans + w.n_mk - (w.wt_minkou ? 1 : 0);
+            if (ankous == 4) yakuman += 1;
+            else if (ankous == 3) han += 2;
+            int kans = in.m.n_ankans + in.m.n_minkans;
+            if (kans == 4) yakuman += 1;
+            else if (kans == 3) han += 2;
+            // 緑一色 (agari.rs:668-676)
+            {
+                const u64 GREEN = (1ull << 19) | (1ull << 20) | (1ull << 21) | (1ull << 23) | (1ull << 25) | (1ull << T_F);
+                bool g = (GREEN >> pt) & 1;
+                for (int i = 0; i < w.n_kotsu; i++) g &= (GREEN >> w.kotsu[i]) & 1;
+                for (int i = 0; i < w.n_shuntsu; i++) g &= w.shuntsu[i] == 19;
+                if (g) yakuman += 1;
+            }
+            DONE_IF_ANY();
+            if (!has_tanyao) {  // 役牌, 三元, 四喜 (agari.rs:678-721)
+                u32 jz = 0;
+                for (int i = 0; i < w.n_kotsu; i++)
+                    if (w.kotsu[i] >= 27) jz |= 1u << (w.kotsu[i] - 27);
+                if ((jz >> (in.bakaze - 27)) & 1) han += 1;
+                if ((jz >> (in.jikaze - 27)) & 1) han += 1;
+                int saneins = __popc(jz & 0b1110000);
+                if (saneins > 0) {
+                    han += saneins;
+                    if (saneins == 3) yakuman += 1;
+                    else if (saneins == 2 && pair_is_dragon) han += 2;
+                }
+                int winds = __popc(jz & 0b0001111);
+                if (winds == 4) yakuman += 1;
+                else if (winds == 3 && pt >= T_E && pt <= T_N) yakuman += 1;
+            }
+        }
+        if (!has_tanyao && all_yao) {  // 老頭 / 全帯 (agari.rs:724-757)
+            if (w.has_chitoi || has_toitoi) {
+                if (yao_jihai) han += 2;
+                else yakuman += 1;
+            } else {
+                bool jc = true;
+                for (int i = 0; i < w.n_shuntsu; i++) {
+                    int num = w.shuntsu[i] % 9;
+                    jc &= num == 0 || num == 6;
+                }
+                if (jc) han += (yao_jihai ? 1 : 2) + (in.is_menzen ? 1 : 0);
+            }
+        }
+    }
+done:
+#undef DONE_IF_ANY
+    Agari a;
+    if (yakuman > 0) { a.kind = 2; a.fu = 0; a.han = yakuman; }
+    else if (han > 0) { a.kind = 1; a.han = han; a.fu = (any_only || han >= 5) ? 0 : div_calc_fu(w, has_pinfu); }
+    else { a.kind = 0; a.fu = a.han = 0; }
+    return a;
+}
+
+// agari.rs:260-288.  any_only => has_yaku()
+MJDN Agari agari_search(const MjTablesDev& T, const AgariIn& in, bool any_only) {
+    Agari best = {0, 0, 0};
+    if (in.is_menzen && calc_kokushi(in.tehai) == -1) {
+        best.kind = 2;
+        best.han = 1;
+        return best;
+    }
+    u8 t14[14];
+    u32 key = tile14_and_key(in.tehai, t14);
+    int idx = agari_find(T, key);
+    if (idx < 0) return best;
+    const u32* rec = T.agari_divs + (size_t)idx * 5;
+    int n = (int)rec[0];
+    for (int i = 0; i < n; i++) {
+        DivWork w;
+        div_init(w, in, t14, rec[1 + i]);
+        Agari a = div_search_yakus(w, any_only);
+        if (a.kind == 0) continue;
+        if (any_only) return a;
+        if (best.kind == 0 || !agari_better(best, a)) best = a;
+    }
+    return best;
+}
+// agari.rs:228-258
+MJDN Agari agari_full(const MjTablesDev& T, const AgariIn& in, int additional_hans, int doras) {
+    Agari a = agari_search(T, in, false);
+    if (a.kind == 1) { a.han += additional_hans + doras; return a; }
+    if (a.kind == 2) return a;
+    Agari none = {0, 0, 0};
+    if (additional_hans == 0) return none;
+    if (additional_hans + doras >= 5) { Agari r = {1, 0, additional_hans + doras}; return r; }
+    u8 t14[14];
+    u32 key = tile14_and_key(in.tehai, t14);
+    int idx = agari_find(T, key);
+    if (idx < 0) return none;
+    const u32* rec = T.agari_divs + (size_t)idx * 5;
+    int fu = -1;
+    for (int i = 0; i < (int)rec[0]; i++) {
+        DivWork w;
+        div_init(w, in, t14, rec[1 + i]);
+        fu = max(fu, div_calc_fu(w, false));
+    }
+    if (fu < 0) return none;
+    Agari r = {1, fu, additional_hans + doras};
+    return r;
+}
+MJD Point agari_point(Agari a, bool is_oya) { return a.kind == 2 ? point_yakuman(is_oya, a.han) : point_calc(is_oya, a.fu, a.han); }
+
+// agari.rs:854-912 with strict = false (the only mode the state machine uses, update.rs:277-278)
+MJDN bool check_ankan_after_riichi(const MjTablesDev& T, Hand tehai, int len_div3, int tile) {
+    int tid = deaka(tile);
+    if (tehai.get(tid) != 4) return false;
+    if (tid >= 27) return true;
+    Hand before = tehai;
+    before.dec(tid);
+    for (int t = 0; t < 34; t++) {
+        if (before.get(t) == 4) continue;
+        Hand tmp = before;
+        tmp.inc(t);
+        if (calc_all(T, tmp, len_div3) != -1) continue;
+        if (t == tid) return false;
+        Hand after = tehai;
+        after.clear(tid);
+        after.inc(t);
+        u8 t14[14];
+        if (agari_find(T, tile14_and_key(after, t14)) < 0) return false;
+    }
+    return true;
+}

@@ -1,0 +1,409 @@
+// C-ABI host side (include/mortal_amd.h): pool life-cycle and kernel launches.  One translation unit for the whole
+// library; the kernels live in mj_step.hip / mj_encode.hip.
+// Host float math below builds bit-exact LUTs: compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mortal_amd.h"
+#include "mj_step.hip"
+#include "mj_encode.hip"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+#define HIP_OK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevTables {
+    bool ready = false;
+    MjTablesDev dev{};
+    MjGatherEnt* gather = nullptr;
+    int n_gather = 0;
+    float *decay = nullptr, *rbf_score = nullptr, *rbf_6 = nullptr, *rbf_12 = nullptr, *rbf_23 = nullptr;
+} g_tables;
+
+template <class T> int upload(const std::vector<T>& v, T** out) {
+    HIP_OK(hipMalloc(out, v.size() * sizeof(T)));
+    HIP_OK(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// obs_repr.rs:79-90 with f32 arithmetic in the reference's order
+std::vector<float> build_rbf(int n_max, int cap, int intervals) {
+    std::vector<float> out((size_t)n_max * (intervals - 1));
+    float interval_size = (float)cap / (float)intervals;
+    for (int n = 0; n < n_max; n++)
+        for (int i = 1; i < intervals; i++) {
+            float x = (float)n;
+            float mu = (float)i * interval_size;
+            float sigma = interval_size;
+            float d = x - mu;
+            out[(size_t)n * (intervals - 1) + i - 1] = expf(-(d * d) / (2.f * (sigma * sigma)));
+        }
+    return out;
+}
+
+std::vector<MjGatherEnt> build_gather() {
+    std::vector<MjGatherEnt> v;
+#define MJ_X_GATHER(type, name, dims, count)                                                         \
+    for (int k = 0; k < (count); k++)                                                                \
+        v.push_back({(uint32_t)(offsetof(TableBlock, name) + (size_t)k * MJ_LANES * sizeof(type)),   \
+                     (uint16_t)(offsetof(TableOne, name) + (size_t)k * sizeof(type)), (uint16_t)sizeof(type)});
+    MJ_FIELDS(MJ_X_GATHER)
+#undef MJ_X_GATHER
+    return v;
+}
+
+}  // namespace
+
+struct MjPool {
+    int n_tables = 0, n_blocks = 0, version = 4, C = 1012, deal_algo = 0, max_rows = 0;
+    TableBlock* blocks = nullptr;
+    uint32_t* rows[2] = {nullptr, nullptr};
+    int* n_rows_dev = nullptr;
+    int* n_rows_host = nullptr;  // pinned
+    unsigned long long* counters = nullptr;
+    int* final_scores = nullptr;
+    uint8_t* final_done = nullptr;
+    int n_games_total = 0;
+    int enable_quick_eval[2] = {1, 1};
+    int enable_agari_guard[2] = {0, 0};
+    uint64_t refill_stride = 0;
+    uint64_t cycles = 0;
+    int last_rows[2] = {0, 0};
+    bool rows_valid = false;
+    // encode timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double timed_ms = 0;
+    int64_t timed_launches = 0;
+};
+
+extern "C" {
+
+const char* mj_last_error(void) { return g_err.c_str(); }
+int mj_abi_version(void) { return 1; }
+int mj_obs_rows(int version) { return version == 1 ? 938 : version == 2 ? 942 : version == 3 ? 934 : version == 4 ? 1012 : -1; }
+size_t mj_debug_table_size(void) { return sizeof(TableOne); }
+
+int mj_tables_upload(const void* payload, size_t size) {
+    if (g_tables.ready) return 0;
+    const uint8_t* p = (const uint8_t*)payload;
+    if (size < 16 || memcmp(p, "MJT1", 4) != 0) return fail("bad table payload");
+    uint32_t ns, nj, na;
+    memcpy(&ns, p + 4, 4);
+    memcpy(&nj, p + 8, 4);
+    memcpy(&na, p + 12, 4);
+    if (size != 16 + (size_t)ns * 5 + (size_t)nj * 5 + (size_t)na * 24) return fail("bad table payload size");
+    auto rows = [](const uint8_t* b, uint32_t n) {
+        std::vector<uint64_t> v(n);
+        for (uint32_t i = 0; i < n; i++) {
+            uint64_t r = 0;
+            for (int k = 0; k < 5; k++) r |= (uint64_t)b[(size_t)i * 5 + k] << (8 * k);
+            v[i] = r;
+        }
+        return v;
+    };
+    std::vector<uint64_t> suhai = rows(p + 16, ns), jihai = rows(p + 16 + (size_t)ns * 5, nj);
+    const uint8_t* ag = p + 16 + (size_t)ns * 5 + (size_t)nj * 5;
+    std::vector<uint32_t> keys(na), divs((size_t)na * 5);
+    for (uint32_t i = 0; i < na; i++) {
+        uint32_t rec[6];
+        memcpy(rec, ag + (size_t)i * 24, 24);
+        keys[i] = rec[0];
+        for (int k = 0; k < 5; k++) divs[(size_t)i * 5 + k] = rec[1 + k];
+    }
+    uint64_t *d_s, *d_j;
+    uint32_t *d_k, *d_d;
+    if (upload(suhai, &d_s) || upload(jihai, &d_j) || upload(keys, &d_k) || upload(divs, &d_d)) return -1;
+    g_tables.dev = {d_s, ns, d_j, nj, d_k, d_d, na};
+    auto g = build_gather();
+    g_tables.n_gather = (int)g.size();
+    if (upload(g, &g_tables.gather)) return -1;
+    std::vector<float> decay(64);
+    for (int k = 0; k < 64; k++) decay[k] = expf(-0.2f * (float)k);  // obs_repr.rs:228,266
+    if (upload(decay, &g_tables.decay) || upload(build_rbf(4096, 500, 10), &g_tables.rbf_score) ||
+        upload(build_rbf(256, 6, 3), &g_tables.rbf_6) || upload(build_rbf(256, 12, 3), &g_tables.rbf_12) ||
+        upload(build_rbf(256, 23, 4), &g_tables.rbf_23))
+        return -1;
+    g_tables.ready = true;
+    return 0;
+}
+
+MjPool* mj_pool_create(int n_tables, int version, int deal_algo, int max_rows) {
+    if (!g_tables.ready) {
+        fail("mj_tables_upload has not been called");
+        return nullptr;
+    }
+    if (n_tables <= 0 || mj_obs_rows(version) < 0) {
+        fail("bad n_tables / version");
+        return nullptr;
+    }
+    MjPool* P = new MjPool;
+    P->n_tables = n_tables;
+    P->n_blocks = (n_tables + MJ_LANES - 1) / MJ_LANES;
+    P->version = version;
+    P->C = mj_obs_rows(version);
+    P->deal_algo = deal_algo;
+    P->max_rows = max_rows > 0 ? max_rows : 8 * n_tables;
+    bool ok = hipMalloc(&P->blocks, (size_t)P->n_blocks * sizeof(TableBlock)) == hipSuccess &&
+              hipMalloc(&P->rows[0], (size_t)P->max_rows * 4) == hipSuccess &&
+              hipMalloc(&P->rows[1], (size_t)P->max_rows * 4) == hipSuccess &&
+              hipMalloc(&P->n_rows_dev, 2 * sizeof(int)) == hipSuccess &&
+              hipHostMalloc(&P->n_rows_host, 2 * sizeof(int)) == hipSuccess &&
+              hipMalloc(&P->counters, 8 * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) {
+        fail("device allocation failed");
+        mj_pool_destroy(P);
+        return nullptr;
+    }
+    hipMemset(P->blocks, 0, (size_t)P->n_blocks * sizeof(TableBlock));
+    size_t lds = (size_t)P->C * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + 69 * 8;
+    hipFuncSetAttribute((const void*)mj_k_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return P;
+}
+
+void mj_pool_destroy(MjPool* P) {
+    if (!P) return;
+    hipFree(P->blocks);
+    hipFree(P->rows[0]);
+    hipFree(P->rows[1]);
+    hipFree(P->n_rows_dev);
+    if (P->n_rows_host) hipHostFree(P->n_rows_host);
+    hipFree(P->counters);
+    hipFree(P->final_scores);
+    hipFree(P->final_done);
+    for (auto& e : P->events) {
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    delete P;
+}
+
+int mj_pool_reset(MjPool* P, const uint64_t* nonces, const uint64_t* keys, const uint32_t* game_ids,
+                  const uint8_t* agent_of_seat, int n_games_total) {
+    if (!P) return fail("null pool");
+    std::vector<TableBlock> host(P->n_blocks);
+    memset(host.data(), 0, host.size() * sizeof(TableBlock));
+    for (int t = 0; t < P->n_blocks * MJ_LANES; t++) {
+        TableBlock& B = host[t >> 6];
+        int l = t & 63;
+        if (t >= P->n_tables) {
+            B.flags[l] = TF_INACTIVE | TF_DONE | TF_ENDED;
+            continue;
+        }
+        B.seed_nonce[l] = nonces[t];
+        B.seed_key[l] = keys[t];
+        B.game_id[l] = game_ids ? game_ids[t] : (uint32_t)t;
+        B.agent_of_seat[l] = agent_of_seat ? agent_of_seat[t] : 0;
+        for (int i = 0; i < 4; i++) B.scores[i][l] = 25000;  // BatchGame::tenhou_hanchan (game.rs:222-228)
+    }
+    HIP_OK(hipMemcpy(P->blocks, host.data(), host.size() * sizeof(TableBlock), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(P->counters, 0, 8 * sizeof(unsigned long long)));
+    hipFree(P->final_scores);
+    hipFree(P->final_done);
+    P->n_games_total = n_games_total > 0 ? n_games_total : P->n_tables;
+    HIP_OK(hipMalloc(&P->final_scores, (size_t)P->n_games_total * 4 * sizeof(int)));
+    HIP_OK(hipMalloc(&P->final_done, (size_t)P->n_games_total));
+    HIP_OK(hipMemset(P->final_scores, 0, (size_t)P->n_games_total * 4 * sizeof(int)));
+    HIP_OK(hipMemset(P->final_done, 0, (size_t)P->n_games_total));
+    P->cycles = 0;
+    P->rows_valid = false;
+    return 0;
+}
+
+int mj_pool_configure(MjPool* P, int agent, int enable_quick_eval, int enable_guard) {
+    if (!P || agent < 0 || agent > 1) return fail("bad agent");
+    P->enable_quick_eval[agent] = enable_quick_eval;
+    P->enable_agari_guard[agent] = enable_guard;
+    if (enable_guard) return fail("enable_rule_based_agari_guard is not supported on the device path yet");
+    return 0;
+}
+int mj_pool_set_refill(MjPool* P, uint64_t stride) {
+    if (!P) return fail("null pool");
+    P->refill_stride = stride;
+    return 0;
+}
+
+int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
+    if (!P) return fail("null pool");
+    hipStream_t s = (hipStream_t)stream;
+    StepParams sp;
+    sp.blocks = P->blocks;
+    sp.n_tables = P->n_tables;
+    sp.tables = g_tables.dev;
+    sp.actions[0] = a0;
+    sp.actions[1] = a1;
+    sp.q_values[0] = sp.q_values[1] = nullptr;
+    sp.deal_algo = P->deal_algo;
+    for (int a = 0; a < 2; a++) {
+        sp.enable_quick_eval[a] = P->enable_quick_eval[a];
+        sp.enable_agari_guard[a] = P->enable_agari_guard[a];
+    }
+    sp.game_length = 8;
+    sp.refill = P->refill_stride != 0;
+    sp.refill_stride = P->refill_stride;
+    sp.counters = P->counters;
+    sp.final_scores = P->final_scores;
+    sp.final_done = P->final_done;
+    sp.n_games_total = P->n_games_total;
+    if (sp.refill) hipLaunchKernelGGL(mj_k_refill, dim3(P->n_blocks), dim3(64), 0, s, sp);
+    hipLaunchKernelGGL(mj_k_step, dim3(P->n_blocks), dim3(64), 0, s, sp);
+    RowsParams rp;
+    rp.blocks = P->blocks;
+    rp.n_tables = P->n_blocks * MJ_LANES;
+    rp.rows[0] = P->rows[0];
+    rp.rows[1] = P->rows[1];
+    rp.n_rows_out = P->n_rows_dev;
+    rp.max_rows[0] = rp.max_rows[1] = P->max_rows;
+    hipLaunchKernelGGL(mj_k_rows, dim3(1), dim3(1024), 0, s, rp);
+    HIP_OK(hipMemcpyAsync(P->n_rows_host, P->n_rows_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipGetLastError());
+    P->cycles += 1;
+    P->rows_valid = false;
+    return 0;
+}
+
+int mj_rows_count(MjPool* P, int32_t out[2], void* stream) {
+    if (!P) return fail("null pool");
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    P->last_rows[0] = P->n_rows_host[0];
+    P->last_rows[1] = P->n_rows_host[1];
+    P->rows_valid = true;
+    out[0] = P->last_rows[0];
+    out[1] = P->last_rows[1];
+    if (out[0] > P->max_rows || out[1] > P->max_rows) return fail("row capacity exceeded");
+    return 0;
+}
+const uint32_t* mj_rows_dev(MjPool* P, int agent) { return P ? P->rows[agent & 1] : nullptr; }
+
+int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
+    if (!P) return fail("null pool");
+    if (!P->rows_valid) return fail("mj_rows_count must be called after mj_step and before mj_encode");
+    int n = P->last_rows[agent & 1];
+    if (n == 0) return 0;
+    EncParams ep;
+    ep.blocks = P->blocks;
+    ep.rows = P->rows[agent & 1];
+    ep.n_rows = n;
+    ep.tables = g_tables.dev;
+    ep.obs = obs;
+    ep.masks = masks;
+    ep.version = P->version;
+    ep.C = P->C;
+    ep.gather = g_tables.gather;
+    ep.n_gather = g_tables.n_gather;
+    ep.decay_lut = g_tables.decay;
+    ep.rbf_score = g_tables.rbf_score;
+    ep.rbf_6 = g_tables.rbf_6;
+    ep.rbf_12 = g_tables.rbf_12;
+    ep.rbf_23 = g_tables.rbf_23;
+    ep.with_sp = 0;
+    ep.sp_buf = nullptr;
+    size_t lds = (size_t)P->C * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + 69 * 8;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (P->timing) {
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipEventRecord(e0, s));
+    }
+    hipLaunchKernelGGL(mj_k_encode, dim3(n), dim3(ENC_THREADS), lds, s, ep);
+    if (P->timing) {
+        HIP_OK(hipEventRecord(e1, s));
+        P->events.push_back({e0, e1});
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mj_encode_timing(MjPool* P, int enable, double* total_ms, int64_t* launches) {
+    if (!P) return fail("null pool");
+    for (auto& e : P->events) {
+        hipEventSynchronize(e.second);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e.first, e.second);
+        P->timed_ms += ms;
+        P->timed_launches += 1;
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    P->events.clear();
+    if (total_ms) *total_ms = P->timed_ms;
+    if (launches) *launches = P->timed_launches;
+    P->timed_ms = 0;
+    P->timed_launches = 0;
+    P->timing = enable != 0;
+    return 0;
+}
+
+int mj_random_policy(MjPool* P, int agent, const uint8_t* masks, uint64_t seed, uint64_t cycle, int32_t* actions,
+                     void* stream) {
+    if (!P) return fail("null pool");
+    if (!P->rows_valid) return fail("mj_rows_count must be called first");
+    int n = P->last_rows[agent & 1];
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mj_k_random_policy, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, P->blocks,
+                       P->rows[agent & 1], masks, n, seed, cycle, actions);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
+    if (!P) return fail("null pool");
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long tmp[8];
+    HIP_OK(hipMemcpy(tmp, P->counters, sizeof tmp, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = tmp[i];
+    out[5] = P->cycles;
+    return 0;
+}
+
+int mj_results(MjPool* P, int32_t* scores, uint8_t* done, void* stream) {
+    if (!P) return fail("null pool");
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    HIP_OK(hipMemcpy(scores, P->final_scores, (size_t)P->n_games_total * 4 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(done, P->final_done, (size_t)P->n_games_total, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mj_pool_first_error(MjPool* P, int* table_out, void* stream) {
+    if (!P) return fail("null pool");
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<uint8_t> err(MJ_LANES);
+    for (int b = 0; b < P->n_blocks; b++) {
+        HIP_OK(hipMemcpy(err.data(), P->blocks[b].err, MJ_LANES, hipMemcpyDeviceToHost));
+        for (int l = 0; l < MJ_LANES; l++)
+            if (err[l]) {
+                if (table_out) *table_out = b * MJ_LANES + l;
+                return err[l];
+            }
+    }
+    return 0;
+}
+
+int mj_debug_table(MjPool* P, int table, void* out, size_t out_size, void* stream) {
+    if (!P || table < 0 || table >= P->n_tables) return fail("bad table");
+    if (out_size < sizeof(TableOne)) return fail("buffer too small");
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<uint8_t> blk(sizeof(TableBlock));
+    HIP_OK(hipMemcpy(blk.data(), &P->blocks[table >> 6], sizeof(TableBlock), hipMemcpyDeviceToHost));
+    auto g = build_gather();
+    int lane = table & 63;
+    for (auto& e : g) memcpy((char*)out + e.dst_off, blk.data() + e.src_off + (size_t)lane * e.size, e.size);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// Per-table deal on device: kyoku seed = SHA3-256(nonce_le64 || key_le64 || [kyoku, honba]) -> ChaCha12
+// stream -> Fisher-Yates over the 136-tile sequence (reference arena/board.rs:99-123, UNSHUFFLED :786-824).
+// The third-party pieces (sha3 0.10.8, rand_chacha 0.9.0, rand shuffle) are restated from their published
+// algorithms; `algo` selects the rand-0.8 shuffle (pinned by the reference's seeded game log) or rand-0.9.1's
+// (unpinned).
+#pragma once
+#include "mj_algo.h"
+
+MJD u64 rotl64(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+MJD u32 rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+
+__device__ static const u64 KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+// Keccak-f[1600] with the lane array fully in registers (all indices compile-time).
+MJDN void keccak_f(u64 a[25]) {
+    for (int round = 0; round < 24; round++) {
+        u64 c[5], d[5];
+#pragma unroll
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+        for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+        // rho + pi:  b[y, 2x+3y] = rot(a[x,y], r[x,y]);  index = x + 5y
+        u64 b[25];
+        constexpr int R[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+#pragma unroll
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(a[x + 5 * y], R[x + 5 * y]);
+#pragma unroll
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= KECCAK_RC[round];
+    }
+}
+
+struct ChaCha12Dev {
+    u32 key[8];
+    u32 buf[16];
+    u32 counter;
+    int idx;
+    MJD void init(const u64 seed[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            key[2 * i] = (u32)seed[i];
+            key[2 * i + 1] = (u32)(seed[i] >> 32);
+        }
+        counter = 0;
+        idx = 16;
+    }
+    MJDN void refill() {
+        u32 s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                     key[4], key[5], key[6], key[7], counter, 0u, 0u, 0u};
+        u32 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = s[i];
+#define QR(a, b, c, d)                                \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);     \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12);     \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);      \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+        for (int r = 0; r < 6; r++) {
+            QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
+            QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
+        }
+#undef QR
+#pragma unroll
+        for (int i = 0; i < 16; i++) buf[i] = x[i] + s[i];
+        counter++;
+        idx = 0;
+    }
+    MJD u32 next() {
+        if (idx >= 16) refill();
+        // buf is indexed dynamically -> lives in scratch; 16 dwords per lane, fine.
+        return buf[idx++];
+    }
+};
+
+// Writes the shuffled 136-tile sequence into wall[i * stride].
+MJDN void deal_wall(u8* wall, int stride, u64 nonce, u64 key, int kyoku, int honba, int algo) {
+    // SHA3-256 of an 18-byte message: one rate block (136 B), pad 0x06 .. 0x80
+    u64 st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    st[0] = nonce;
+    st[1] = key;
+    st[2] = (u64)(kyoku & 0xFF) | ((u64)(honba & 0xFF) << 8) | (0x06ull << 16);
+    st[16] = 0x80ull << 56;
+    keccak_f(st);
+    ChaCha12Dev rng;
+    rng.init(st);
+
+    for (int t = 0; t < 34; t++)
+        for (int k = 0; k < 4; k++) wall[(t * 4 + k) * stride] = (u8)t;
+    wall[(T_5M * 4) * stride] = T_5MR;
+    wall[(T_5P * 4) * stride] = T_5PR;
+    wall[(T_5S * 4) * stride] = T_5SR;
+
+    if (algo == 0) {  // rand 0.8: for i in (1..n).rev(): swap(i, gen_range(0..=i))
+        for (int i = 135; i >= 1; i--) {
+            u32 range = (u32)(i + 1);
+            u32 zone = (range << __clz(range)) - 1;
+            u32 j;
+            for (;;) {
+                u64 m = (u64)rng.next() * range;
+                if ((u32)m <= zone) {
+                    j = (u32)(m >> 32);
+                    break;
+                }
+            }
+            u8 a = wall[i * stride], b = wall[j * stride];
+            wall[i * stride] = b;
+            wall[j * stride] = a;
+        }
+    } else {  // rand 0.9.1: forward loop with the chunked IncreasingUniform sampler
+        u32 n = 0, chunk = 0;
+        int chunk_remaining = 1;
+        for (int i = 0; i < 136; i++) {
+            u32 next_n = n + 1;
+            int next_rem;
+            if (chunk_remaining >= 1) {
+                next_rem = chunk_remaining - 1;
+            } else {
+                u32 product = next_n, current = next_n + 1;
+                for (;;) {
+                    u64 p = (u64)product * current;
+                    if (p > 0xffffffffull) break;
+                    product = (u32)p;
+                    current += 1;
+                }
+                u32 bound = product;
+                int remaining = (int)(current - next_n);
+                u64 m = (u64)rng.next() * bound;
+                u32 res = (u32)(m >> 32), lo = (u32)m;
+                if (lo > (u32)(0u - bound)) {
+                    u32 new_hi = (u32)(((u64)rng.next() * bound) >> 32);
+                    res += (lo + new_hi) < lo;
+                }
+                chunk = res;
+                next_rem = remaining - 1;
+            }
+            u32 result;
+            if (next_rem == 0) result = chunk;
+            else {
+                result = chunk % next_n;
+                chunk /= next_n;
+            }
+            chunk_remaining = next_rem;
+            n = next_n;
+            u8 a = wall[i * stride], b = wall[result * stride];
+            wall[i * stride] = b;
+            wall[result * stride] = a;
+        }
+    }
+}

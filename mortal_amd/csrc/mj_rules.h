@@ -1,0 +1,684 @@
+// Per-lane rules engine: one table per lane, state in the SoA pool (mj_state.h).
+//
+// An mjai event is applied ONCE to the public part of a table and then to the private slice of each of
+// the four seats (the reference instead broadcasts it to four full PlayerState copies,
+// arena/board.rs:199-204 -> state/update.rs:41-122).
+// Functional specs: state/update.rs (event handlers, shanten/wait sets), state/action.rs (legal actions),
+// state/agent_helper.rs (discard candidates, agari points), arena/board.rs (BoardState::step/poll),
+// arena/game.rs (Game::poll/commit), agent/mortal.rs:200-250,292-573 (quick-eval, kan-select, action decode).
+#pragma once
+#include "mj_algo.h"
+#include "mj_deal.h"
+
+template <class BlockT>
+struct LaneT {  // a table viewed through lane `l` of a block (pool block in HBM, or the 1-lane LDS copy)
+    BlockT* B;
+    int l;
+    const MjTablesDev* T;
+};
+typedef LaneT<TableBlock> Lane;
+#define F(f) (L.B->f[L.l])
+#define F1(f, i) (L.B->f[i][L.l])
+#define F2(f, i, j) (L.B->f[i][j][L.l])
+#define F3(f, i, j, k) (L.B->f[i][j][k][L.l])
+#define BIT(t) (1ull << (t))
+
+template <class LN> MJD Hand load_hand(const LN& L, int s) {
+    Hand h;
+    h.mp = F1(hand_mp, s);
+    h.sz = F1(hand_sz, s);
+    return h;
+}
+template <class LN> MJD void store_hand(const LN& L, int s, Hand h) {
+    F1(hand_mp, s) = h.mp;
+    F1(hand_sz, s) = h.sz;
+}
+template <class LN> MJD void set_err(const LN& L, int code) {
+    if (F(err) == MJ_OK) F(err) = (u8)code;
+}
+template <class LN> MJD int dora_factor(const LN& L, int t) {  // update.rs:787-788 (derived: #indicators whose next() == t)
+    int n = F(n_dora_ind), f = 0;
+    for (int i = 0; i < n; i++) f += tile_next(F1(dora_ind, i)) == t;
+    return f;
+}
+template <class LN> MJD void pub_witness(const LN& L, int tile) {  // the public half of witness_tile (update.rs:695-726)
+    F1(pub_seen, deaka(tile)) += 1;
+    if (is_aka(tile)) F(pub_aka_seen) |= 1 << (tile - T_5MR);
+}
+template <class LN> MJD bool accepted(const LN& L, int s) { return (F(riichi_accepted) >> s) & 1; }
+template <class LN> MJD bool declared(const LN& L, int s) { return (F(riichi_declared) >> s) & 1; }
+template <class LN> MJD Melds load_melds(const LN& L, int s) {
+    Melds m;
+    m.n_chis = F2(n_melds, s, 0);
+    m.n_pons = F2(n_melds, s, 1);
+    m.n_minkans = F2(n_melds, s, 2);
+    m.n_ankans = F2(n_melds, s, 3);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        m.chis[i] = F2(chis, s, i);
+        m.pons[i] = F2(pons, s, i);
+        m.minkans[i] = F2(minkans, s, i);
+        m.ankans[i] = F2(ankans, s, i);
+    }
+    return m;
+}
+template <class LN> MJD int seat_jikaze(const LN& L, int s) { return T_E + ((s + 4 - (F(kyoku) & 3)) & 3); }  // update.rs:154-155
+template <class LN> MJD int table_bakaze(const LN& L) { return T_E + F(kyoku) / 4; }
+
+template <class LN> MJDN bool seat_has_yaku(const LN& L, int s, Hand with_tile, int winning_tile, bool is_ron) {
+    AgariIn in;
+    in.tehai = with_tile;
+    in.m = load_melds(L, s);
+    in.is_menzen = (F1(pflags, s) & PF_IS_MENZEN) != 0;
+    in.bakaze = table_bakaze(L);
+    in.jikaze = seat_jikaze(L, s);
+    in.winning_tile = winning_tile;
+    in.is_ron = is_ron;
+    return agari_search(*L.T, in, true).kind != 0;
+}
+
+// ---------------------------------------------------------------- shanten / waits (update.rs:870-953)
+template <class LN> MJD void update_shanten(const LN& L, int s) {
+    int v = calc_all(*L.T, load_hand(L, s), F1(len_div3, s));
+    F1(shanten, s) = (int8_t)max(v, 0);
+}
+template <class LN> MJDN void update_shanten_discards(const LN& L, int s) {  // 3n+2
+    Hand h = load_hand(L, s);
+    int ld3 = F1(len_div3, s), sh = F1(shanten, s);
+    u64 next = 0, keep = 0;
+    for (int t = 0; t < 34; t++) {
+        if (h.get(t) == 0) continue;
+        Hand g = h;
+        g.dec(t);
+        int after = calc_all(*L.T, g, ld3);
+        if (after < sh) next |= BIT(t);
+        else if (after == sh) keep |= BIT(t);
+    }
+    F1(next_shanten, s) = next;
+    F1(keep_shanten, s) = keep;
+    F1(has_next_shanten, s) = next != 0;
+}
+template <class LN> MJDN void update_waits_and_furiten(const LN& L, int s) {  // 3n+1
+    u8 pf = F1(pflags, s) & ~PF_AT_FURITEN;
+    u64 waits = 0;
+    if (F1(shanten, s) <= 0) {
+        Hand h = load_hand(L, s);
+        int ld3 = F1(len_div3, s);
+        u64 disc = F1(discarded, s);
+        for (int t = 0; t < 34; t++) {
+            int c = h.get(t);
+            if (c == 4) continue;
+            Hand g = h;
+            g.inc(t);
+            if (calc_all(*L.T, g, ld3) == -1) {
+                if ((disc >> t) & 1) pf |= PF_AT_FURITEN;
+                if (F1(pub_seen, t) + c < 4) waits |= BIT(t);  // tiles_seen = pub_seen + own hand
+            }
+        }
+    }
+    F1(pflags, s) = pf;
+    F1(waits, s) = waits;
+}
+
+// ---------------------------------------------------------------- event prologue (update.rs:46-60)
+template <class LN> MJD void ev_prologue(const LN& L, int actor /* -1: event without actor */) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        F1(cans, s) = 0;
+        F1(cans_target, s) = (u8)(actor >= 0 ? actor : s);
+        F1(ankan_cand, s) = 0;
+        F1(kakan_cand, s) = 0;
+        u8 pf = F1(pflags, s);
+        if (pf & PF_MARK_FURITEN) pf = (pf & ~PF_MARK_FURITEN) | PF_AT_FURITEN;
+        if (pf & PF_CHANKAN_CHANCE) pf &= ~(PF_CHANKAN_CHANCE | PF_AT_IPPATSU);
+        F1(pflags, s) = pf;
+    }
+}
+
+template <class LN> MJD void kawa_push(const LN& L, int seat, u64 entry) {
+    int n = F1(kawa_len, seat);
+    if (n >= MJ_KAWA_MAX) {
+        set_err(L, MJ_ERR_KAWA_OVERFLOW);
+        return;
+    }
+    F2(kawa, seat, n) = entry;
+    F1(kawa_len, seat) = (u8)(n + 1);
+}
+template <class LN> MJD void pad_kawa_for_pon_or_daiminkan(const LN& L, int actor, int target) {  // update.rs:810-817
+    int i = (target + 1) & 3;
+    while (i != actor) {
+        kawa_push(L, i, 0);
+        i = (i + 1) & 3;
+    }
+}
+template <class LN> MJD void hand_remove(const LN& L, int s, Hand& h, int tile) {  // move_tile Discard/FuuroConsume (update.rs:733-775)
+    h.dec(deaka(tile));
+    if (is_aka(tile)) F1(akas_in_hand, s) &= ~(1 << (tile - T_5MR));
+}
+
+// ---------------------------------------------------------------- events
+template <class LN> MJDN void ev_tsumo(const LN& L, int actor, int pai) {  // update.rs:219-309
+    ev_prologue(L, actor);
+    int tiles_left = F(tiles_left);  // already decremented by the board
+    const int s = actor;
+    F1(at_turn, s) += 1;
+    u32 cans = CAN_DISCARD;
+    F1(last_self_tsumo, s) = (u8)pai;
+    Hand h = load_hand(L, s);
+    const int dp = deaka(pai);
+    h.inc(dp);
+    if (is_aka(pai)) F1(akas_in_hand, s) |= 1 << (pai - T_5MR);
+    store_hand(L, s, h);
+    const u8 pf = F1(pflags, s);
+    const bool acc = accepted(L, s);
+
+    if (pf & PF_CAN_W_RIICHI) {
+        int kinds = 0;
+#pragma unroll
+        for (int t = 0; t < 34; t++)
+            if ((YAOKYUU_MASK >> t) & 1) kinds += h.get(t) > 0;
+        if (kinds >= 9) cans |= CAN_RYUKYOKU;
+    }
+    if (!acc) {
+        F1(cans, s) = (uint16_t)cans;  // (update_shanten_discards asserts can_discard in the reference)
+        update_shanten_discards(L, s);
+    }
+    if ((F1(waits, s) >> dp) & 1) {
+        if ((pf & PF_IS_MENZEN) || acc || tiles_left == 0 || (pf & PF_AT_RINSHAN) || (pf & PF_CAN_W_RIICHI)) {
+            cans |= CAN_TSUMO_AGARI;
+        } else if (seat_has_yaku(L, s, h, dp, false)) {
+            cans |= CAN_TSUMO_AGARI;
+        }
+    }
+    if (tiles_left != 0) {
+        const int kob = F(kans_on_board);
+        if (acc) {
+            if (kob < 4 && check_ankan_after_riichi(*L.T, h, F1(len_div3, s), pai)) {
+                cans |= CAN_ANKAN;
+                F1(ankan_cand, s) = BIT(dp);
+            }
+        } else {
+            if (kob < 4) {
+                u64 ac = 0, kc = 0;
+                int np = F2(n_melds, s, 1);
+                for (int t = 0; t < 34; t++) {
+                    int c = h.get(t);
+                    if (c == 0) continue;
+                    if (c == 4) ac |= BIT(t);
+                    else {
+                        bool in_pons = false;
+                        for (int i = 0; i < np; i++) in_pons |= F2(pons, s, i) == t;
+                        if (in_pons) kc |= BIT(t);
+                    }
+                }
+                if (ac) cans |= CAN_ANKAN;
+                if (kc) cans |= CAN_KAKAN;
+                F1(ankan_cand, s) = ac;
+                F1(kakan_cand, s) = kc;
+            }
+            int sh = F1(shanten, s);
+            if ((pf & PF_IS_MENZEN) && tiles_left >= 4 && F1(scores, s) >= 1000 &&
+                (sh == 0 || (sh == 1 && F1(has_next_shanten, s))))
+                cans |= CAN_RIICHI;
+        }
+    }
+    F1(cans, s) = (uint16_t)cans;
+}
+
+MJD u32 chi_flags_from_tile(Hand h, int tile) {  // update.rs:826-868
+    u32 r = 0;
+    int tid = deaka(tile), lit = tid % 9 + 1;
+    if (lit <= 7 && h.get(tid + 1) > 0 && h.get(tid + 2) > 0) {
+        Hand a = h;
+        a.clear(tid);
+        a.dec(tid + 1);
+        a.dec(tid + 2);
+        if (lit < 7) a.clear(tid + 3);
+        if (!a.empty()) r |= CAN_CHI_LOW;
+    }
+    if (lit >= 2 && lit <= 8 && h.get(tid - 1) > 0 && h.get(tid + 1) > 0) {
+        Hand a = h;
+        a.clear(tid);
+        a.dec(tid - 1);
+        a.dec(tid + 1);
+        if (!a.empty()) r |= CAN_CHI_MID;
+    }
+    if (lit >= 3 && h.get(tid - 2) > 0 && h.get(tid - 1) > 0) {
+        Hand a = h;
+        a.clear(tid);
+        a.dec(tid - 2);
+        a.dec(tid - 1);
+        if (lit > 3) a.clear(tid - 3);
+        if (!a.empty()) r |= CAN_CHI_HIGH;
+    }
+    return r;
+}
+
+template <class LN> MJDN void ev_dahai(const LN& L, int actor, int pai, bool tsumogiri) {  // update.rs:311-427
+    ev_prologue(L, actor);
+    const int dp = deaka(pai);
+    const int tiles_left = F(tiles_left);
+    // ---- public
+    const bool is_riichi = declared(L, actor) && !accepted(L, actor);
+    const bool is_dora = dora_factor(L, dp) > 0;
+    {
+        u64 e = KW_VALID | ((u64)pai << 1) | ((u64)is_dora << 7) | ((u64)(!tsumogiri) << 8) | ((u64)is_riichi << 9);
+        if (F1(inter_cp, 0)) e |= (1ull << 10) | ((u64)F1(inter_cp, 1) << 11) | ((u64)F1(inter_cp, 2) << 17);
+        int nk = F(inter_kan_n);
+        e |= (u64)nk << 23;
+        for (int k = 0; k < nk; k++) e |= (u64)F1(inter_kan, k) << (26 + 6 * k);
+        F(inter_kan_n) = 0;
+        F1(inter_cp, 0) = 0;
+        kawa_push(L, actor, e);
+    }
+    const u8 su = (u8)(SU_VALID | (is_dora ? SU_DORA : 0) | pai);
+    if (!tsumogiri) F1(last_tedashi, actor) = su;
+    if (is_riichi) F1(riichi_sutehai, actor) = su;
+    pub_witness(L, pai);
+#pragma unroll
+    for (int s = 0; s < 4; s++) F1(last_kawa_tile, s) = (u8)pai;
+
+    // ---- actor
+    {
+        const int s = actor;
+        Hand h = load_hand(L, s);
+        hand_remove(L, s, h, pai);
+        store_hand(L, s, h);
+        F1(forbidden, s) = 0;
+        u8 pf = F1(pflags, s) & ~(PF_AT_RINSHAN | PF_AT_IPPATSU | PF_CAN_W_RIICHI);
+        F1(pflags, s) = pf;
+        F1(discarded, s) |= BIT(dp);
+        if (!accepted(L, s)) {
+            if ((F1(next_shanten, s) >> dp) & 1) F1(shanten, s) -= 1;
+            else if (!((F1(keep_shanten, s) >> dp) & 1)) update_shanten(L, s);
+            update_waits_and_furiten(L, s);
+        } else if (!(pf & PF_AT_FURITEN) && ((F1(waits, s) >> dp) & 1)) {
+            F1(pflags, s) = pf | PF_AT_FURITEN;
+        }
+    }
+    // ---- the other three
+    for (int k = 1; k < 4; k++) {
+        const int s = (actor + k) & 3;
+        u8 pf = F1(pflags, s);
+        u32 cans = 0;
+        Hand h = load_hand(L, s);
+        const bool acc = accepted(L, s);
+        if (!(pf & PF_AT_FURITEN) && ((F1(waits, s) >> dp) & 1)) {
+            bool ron;
+            if (acc || tiles_left == 0) ron = true;
+            else {
+                Hand g = h;
+                g.inc(dp);
+                ron = seat_has_yaku(L, s, g, dp, true);
+            }
+            if (ron) {
+                cans |= CAN_RON_AGARI;
+                pf |= PF_MARK_FURITEN;
+            } else {
+                pf |= PF_AT_FURITEN;
+            }
+            F1(pflags, s) = pf;
+        }
+        if (!(acc || tiles_left == 0)) {
+            if (k == 1 && !is_jihai(pai) && F1(len_div3, s) > 0) cans |= chi_flags_from_tile(h, pai);  // kamicha discard
+            int c = h.get(dp);
+            if (c >= 2) cans |= CAN_PON;
+            if (F(kans_on_board) < 4 && c == 3) cans |= CAN_DAIMINKAN;
+        }
+        F1(cans, s) = (uint16_t)cans;
+    }
+}
+
+template <class LN> MJD void fuuro_push(const LN& L, int seat, const int* tiles, int n) {
+    int k = F1(fuuro_n, seat);
+    for (int i = 0; i < 4; i++) F3(fuuro, seat, k, i) = (u8)(i < n ? tiles[i] : MJ_NONE);
+    F1(fuuro_n, seat) = (u8)(k + 1);
+}
+template <class LN> MJD void others_on_call(const LN& L, int actor) {  // update.rs:441-449 etc.
+    for (int k = 1; k < 4; k++) {
+        int s = (actor + k) & 3;
+        F1(pflags, s) &= ~(PF_CAN_W_RIICHI | PF_AT_IPPATSU);
+    }
+}
+
+template <class LN> MJDN void ev_chi_pon(const LN& L, bool is_pon, int actor, int target, int pai, int c0, int c1) {  // update.rs:429-542
+    ev_prologue(L, actor);
+    int set[3] = {c0, c1, pai};
+    fuuro_push(L, actor, set, 3);
+    int a = deaka(c0), b = deaka(c1), mn = min(a, b), mx = max(a, b);
+    F1(inter_cp, 0) = 1;
+    F1(inter_cp, 1) = (u8)mn;
+    F1(inter_cp, 2) = (u8)mx;
+    if (is_pon) pad_kawa_for_pon_or_daiminkan(L, actor, target);
+    pub_witness(L, c0);
+    pub_witness(L, c1);
+    others_on_call(L, actor);
+
+    const int s = actor;
+    F1(cans, s) = CAN_DISCARD;
+    F1(pflags, s) &= ~PF_IS_MENZEN;
+    F1(len_div3, s) -= 1;
+    F1(last_self_tsumo, s) = MJ_NONE;
+    Hand h = load_hand(L, s);
+    hand_remove(L, s, h, c0);
+    hand_remove(L, s, h, c1);
+    store_hand(L, s, h);
+    const int tid = deaka(pai);
+    u64 forb = F1(forbidden, s);
+    if (is_pon) {
+        int n = F2(n_melds, s, 1);
+        F2(pons, s, n) = (u8)tid;
+        F2(n_melds, s, 1) = (u8)(n + 1);
+        if (h.get(tid) > 0) forb |= BIT(tid);
+    } else {
+        int n = F2(n_melds, s, 0);
+        F2(chis, s, n) = (u8)min(mn, tid);
+        F2(n_melds, s, 0) = (u8)(n + 1);
+        if (h.get(tid) > 0) forb |= BIT(tid);  // kuikae
+        if (tid < mn) {
+            if (mx % 9 < 8 && h.get(mx + 1) > 0) forb |= BIT(mx + 1);
+        } else if (tid > mx && mn % 9 > 0) {
+            if (h.get(mn - 1) > 0) forb |= BIT(mn - 1);
+        }
+    }
+    F1(forbidden, s) = forb;
+    update_shanten(L, s);
+    update_shanten_discards(L, s);
+}
+
+template <class LN> MJDN void ev_daiminkan(const LN& L, int actor, int target, int pai, int c0, int c1, int c2) {  // update.rs:544-582
+    ev_prologue(L, actor);
+    int set[4] = {c0, c1, c2, pai};
+    fuuro_push(L, actor, set, 4);
+    int nk = F(inter_kan_n);
+    if (nk < 4) F1(inter_kan, nk) = (u8)pai;
+    F(inter_kan_n) = (u8)(nk + 1);
+    pad_kawa_for_pon_or_daiminkan(L, actor, target);
+    F(kans_on_board) += 1;
+    pub_witness(L, c0);
+    pub_witness(L, c1);
+    pub_witness(L, c2);
+    others_on_call(L, actor);
+
+    const int s = actor;
+    F1(pflags, s) = (F1(pflags, s) | PF_AT_RINSHAN) & ~PF_IS_MENZEN;
+    F1(len_div3, s) -= 1;
+    Hand h = load_hand(L, s);
+    hand_remove(L, s, h, c0);
+    hand_remove(L, s, h, c1);
+    hand_remove(L, s, h, c2);
+    store_hand(L, s, h);
+    int n = F2(n_melds, s, 2);
+    F2(minkans, s, n) = (u8)deaka(pai);
+    F2(n_melds, s, 2) = (u8)(n + 1);
+    update_shanten(L, s);
+    update_waits_and_furiten(L, s);
+}
+
+template <class LN> MJDN void ev_kakan(const LN& L, int actor, int pai) {  // update.rs:584-628
+    ev_prologue(L, actor);
+    const int dp = deaka(pai);
+    int nf = F1(fuuro_n, actor);
+    for (int k = 0; k < nf; k++) {
+        if (deaka(F3(fuuro, actor, k, 0)) == dp) {
+            F3(fuuro, actor, k, 3) = (u8)pai;  // a pon has 3 tiles: the added tile takes slot 3
+            break;
+        }
+    }
+    int nk = F(inter_kan_n);
+    if (nk < 4) F1(inter_kan, nk) = (u8)pai;
+    F(inter_kan_n) = (u8)(nk + 1);
+    F(kans_on_board) += 1;
+    pub_witness(L, pai);
+    for (int k = 1; k < 4; k++) {
+        int s = (actor + k) & 3;
+        F1(last_kawa_tile, s) = (u8)pai;
+        u8 pf = F1(pflags, s);
+        if (!(pf & PF_AT_FURITEN) && ((F1(waits, s) >> dp) & 1)) {  // chankan
+            F1(cans, s) = CAN_RON_AGARI;
+            pf |= PF_MARK_FURITEN | PF_CHANKAN_CHANCE;
+        } else {
+            pf &= ~PF_AT_IPPATSU;
+        }
+        F1(pflags, s) = pf;
+    }
+    const int s = actor;
+    F1(pflags, s) |= PF_AT_RINSHAN;
+    Hand h = load_hand(L, s);
+    hand_remove(L, s, h, pai);
+    store_hand(L, s, h);
+    {  // pons.retain(!= dp); minkans.push(dp)
+        int np = F2(n_melds, s, 1), w = 0;
+        for (int i = 0; i < np; i++) {
+            u8 t = F2(pons, s, i);
+            if (t != dp) F2(pons, s, w++) = t;
+        }
+        F2(n_melds, s, 1) = (u8)w;
+        int n = F2(n_melds, s, 2);
+        F2(minkans, s, n) = (u8)dp;
+        F2(n_melds, s, 2) = (u8)(n + 1);
+    }
+    if ((F1(next_shanten, s) >> dp) & 1) F1(shanten, s) -= 1;
+    else if (!((F1(keep_shanten, s) >> dp) & 1)) update_shanten(L, s);
+    update_waits_and_furiten(L, s);
+}
+
+template <class LN> MJDN void ev_ankan(const LN& L, int actor, int tile /* deaka'd */) {  // update.rs:630-663; consumed = [akaize(t), t, t, t]
+    ev_prologue(L, actor);
+    int n = F1(ankan_n, actor);
+    F2(ankan, actor, n) = (u8)tile;
+    F1(ankan_n, actor) = (u8)(n + 1);
+    int nk = F(inter_kan_n);
+    if (nk < 4) F1(inter_kan, nk) = (u8)tile;
+    F(inter_kan_n) = (u8)(nk + 1);
+    F(kans_on_board) += 1;
+#pragma unroll
+    for (int s = 0; s < 4; s++) F1(pflags, s) &= ~(PF_CAN_W_RIICHI | PF_AT_IPPATSU);
+    pub_witness(L, akaize(tile));
+    pub_witness(L, tile);
+    pub_witness(L, tile);
+    pub_witness(L, tile);
+
+    const int s = actor;
+    F1(pflags, s) |= PF_AT_RINSHAN;
+    F1(len_div3, s) -= 1;
+    Hand h = load_hand(L, s);
+    h.clear(tile);
+    if (akaize(tile) != tile) F1(akas_in_hand, s) &= ~(1 << (akaize(tile) - T_5MR));
+    store_hand(L, s, h);
+    int m = F2(n_melds, s, 3);
+    F2(ankans, s, m) = (u8)tile;
+    F2(n_melds, s, 3) = (u8)(m + 1);
+    if (!accepted(L, s)) {
+        update_shanten(L, s);
+        update_waits_and_furiten(L, s);
+    }
+}
+
+template <class LN> MJD void ev_dora(const LN& L, int marker) {  // update.rs:780-808 (factor/owned/seen are derived, see mj_state.h)
+    ev_prologue(L, -1);
+    int n = F(n_dora_ind);
+    F1(dora_ind, n) = (u8)marker;
+    F(n_dora_ind) = (u8)(n + 1);
+    pub_witness(L, marker);
+}
+template <class LN> MJD void ev_reach(const LN& L, int actor) {  // update.rs:665-675
+    ev_prologue(L, actor);
+    F(riichi_declared) |= 1 << actor;
+    u8 pf = F1(pflags, actor);
+    pf = (pf & ~PF_IS_W_RIICHI) | ((pf & PF_CAN_W_RIICHI) ? PF_IS_W_RIICHI : 0);
+    F1(pflags, actor) = pf;
+    F1(cans, actor) = CAN_DISCARD;
+}
+template <class LN> MJD void ev_reach_accepted(const LN& L, int actor) {  // update.rs:677-686 + board.rs:342-351
+    ev_prologue(L, actor);
+    F(riichi_accepted) |= 1 << actor;
+    F1(scores, actor) -= 1000;
+    F(kyotaku) += 1;
+    F(accepted_riichis) += 1;
+    F1(pflags, actor) |= PF_AT_IPPATSU;
+}
+
+// ---------------------------------------------------------------- kyoku start (board.rs:99-136,206-239; update.rs:125-217)
+template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
+    const int kyoku = F(kyoku), honba = F(honba);
+    deal_wall(&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
+    F(yama_n) = 70;
+    F(rinshan_n) = 4;
+    F(dora_n) = 5;
+    F(tiles_left) = 70;
+    F(tsumo_actor) = 0;
+    F(riichi_to_be_accepted) = MJ_NONE;
+    F(four_wind_tile) = MJ_NONE;
+    F(accepted_riichis) = 0;
+    F(kans) = 0;
+    u32 fl = F(flags);
+    fl &= (TF_ENDED | TF_IN_RENCHAN | TF_DONE | TF_INACTIVE);
+    fl |= TF_KYOKU_STARTED | TF_CAN_FOUR_WIND | (0xFu * TF_NAGASHI0);
+    F(flags) = fl;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        F1(paos, s) = MJ_NONE;
+        F1(kyoku_deltas, s) = 0;
+        F1(kawa_len, s) = 0;
+        F1(last_tedashi, s) = 0;
+        F1(riichi_sutehai, s) = 0;
+        F1(fuuro_n, s) = 0;
+        F1(ankan_n, s) = 0;
+        F1(akas_in_hand, s) = 0;
+        F1(waits, s) = 0;
+        F1(keep_shanten, s) = 0;
+        F1(next_shanten, s) = 0;
+        F1(forbidden, s) = 0;
+        F1(discarded, s) = 0;
+        F1(ankan_cand, s) = 0;
+        F1(kakan_cand, s) = 0;
+        F1(has_next_shanten, s) = 0;
+        F1(len_div3, s) = 4;
+        F1(at_turn, s) = 0;
+        F1(last_self_tsumo, s) = MJ_NONE;
+        F1(last_kawa_tile, s) = MJ_NONE;
+        F1(cans, s) = 0;
+        F1(cans_target, s) = (u8)s;
+        F1(pflags, s) = PF_IS_MENZEN | PF_CAN_W_RIICHI;
+#pragma unroll
+        for (int k = 0; k < 4; k++) F2(n_melds, s, k) = 0;
+    }
+    F(n_dora_ind) = 0;
+    F(riichi_declared) = 0;
+    F(riichi_accepted) = 0;
+    for (int t = 0; t < 34; t++) F1(pub_seen, t) = 0;
+    F(pub_aka_seen) = 0;
+    F(kans_on_board) = 0;
+    F(inter_kan_n) = 0;
+    F1(inter_cp, 0) = 0;
+
+    // StartKyoku: first dora indicator, then 13 tiles per seat
+    int marker = F1(wall, 56 + 4);
+    F(dora_n) = 4;
+    F1(dora_ind, 0) = (u8)marker;
+    F(n_dora_ind) = 1;
+    pub_witness(L, marker);
+    for (int s = 0; s < 4; s++) {
+        Hand h = {0, 0};
+        u8 akas = 0;
+        for (int i = 0; i < 13; i++) {
+            int t = F1(wall, s * 13 + i);
+            h.inc(deaka(t));
+            if (is_aka(t)) akas |= 1 << (t - T_5MR);
+        }
+        store_hand(L, s, h);
+        F1(akas_in_hand, s) = akas;
+        update_shanten(L, s);
+        update_waits_and_furiten(L, s);
+    }
+    // first tsumo of the oya
+    const int oya = kyoku & 3;
+    int tile = F1(wall, 66 + 69);
+    F(yama_n) = 69;
+    F(tiles_left) = 69;
+    F(flags) |= TF_HAIPAI_DONE;
+    ev_tsumo(L, oya, tile);
+}
+
+// ---------------------------------------------------------------- scoring (agent_helper.rs:377-462)
+// Returns false (and flags an error) when the hand is not a hora hand.
+template <class LN> MJDN bool seat_agari_points(const LN& L, int s, bool is_ron, int n_ura, Point& out) {
+    const u8 pf = F1(pflags, s);
+    const bool is_oya = s == (F(kyoku) & 3);
+    if (!is_ron && (pf & PF_CAN_W_RIICHI)) {  // tenhou / chiihou: single yakuman, no stacking
+        out = point_yakuman(is_oya, 1);
+        return true;
+    }
+    int wt = is_ron ? F1(last_kawa_tile, s) : F1(last_self_tsumo, s);
+    if (wt == MJ_NONE) return false;
+    const bool acc = accepted(L, s);
+    const int tiles_left = F(tiles_left);
+    int add;
+    if (is_ron)
+        add = (int)acc + ((pf & PF_IS_W_RIICHI) != 0) + ((pf & PF_AT_IPPATSU) != 0) + (tiles_left == 0) +
+              ((pf & PF_CHANKAN_CHANCE) != 0);
+    else
+        add = (int)acc + ((pf & PF_IS_W_RIICHI) != 0) + ((pf & PF_AT_IPPATSU) != 0) + ((pf & PF_IS_MENZEN) != 0) +
+              (tiles_left == 0 && !(pf & PF_AT_RINSHAN)) + ((pf & PF_AT_RINSHAN) != 0);
+    Hand h = load_hand(L, s);
+    // doras_owned[0] = hand + own melds (derived; see mj_state.h)
+    int doras = 0;
+    const int nd = F(n_dora_ind);
+    const int akas = F1(akas_in_hand, s);
+    doras += __popc(akas);
+    for (int i = 0; i < nd; i++) {
+        int d = tile_next(F1(dora_ind, i));
+        doras += h.get(d);
+        int nf = F1(fuuro_n, s);
+        for (int k = 0; k < nf; k++)
+            for (int j = 0; j < 4; j++) {
+                int t = F3(fuuro, s, k, j);
+                if (t != MJ_NONE && deaka(t) == d) doras++;
+            }
+        int na = F1(ankan_n, s);
+        for (int k = 0; k < na; k++)
+            if (F2(ankan, s, k) == d) doras += 4;
+    }
+    {  // akas inside own melds
+        int nf = F1(fuuro_n, s);
+        for (int k = 0; k < nf; k++)
+            for (int j = 0; j < 4; j++) {
+                int t = F3(fuuro, s, k, j);
+                if (t != MJ_NONE && is_aka(t)) doras++;
+            }
+        int na = F1(ankan_n, s);
+        for (int k = 0; k < na; k++) {
+            int t = F2(ankan, s, k);
+            if (t == T_5M || t == T_5P || t == T_5S) doras++;
+        }
+    }
+    const int wtd = deaka(wt);
+    if (is_ron) {
+        h.inc(wtd);
+        doras += dora_factor(L, wtd);
+        if (is_aka(wt)) doras++;
+    }
+    if (acc) {
+        for (int i = 0; i < n_ura; i++) {
+            int nx = tile_next(F1(wall, 61 + i));
+            int c = h.get(nx);
+            int na = F1(ankan_n, s);
+            for (int k = 0; k < na; k++)
+                if (F2(ankan, s, k) == nx) c += 4;
+            doras += c;
+        }
+    }
+    AgariIn in;
+    in.tehai = h;
+    in.m = load_melds(L, s);
+    in.is_menzen = (pf & PF_IS_MENZEN) != 0;
+    in.bakaze = table_bakaze(L);
+    in.jikaze = seat_jikaze(L, s);
+    in.winning_tile = wtd;
+    in.is_ron = is_ron;
+    Agari a = agari_full(*L.T, in, add, doras & 0xFF);
+    if (a.kind == 0) return false;
+    out = agari_point(a, is_oya);
+    return true;
+}

@@ -1,0 +1,702 @@
+// Env-step kernels: one table per lane, 64 tables per wavefront.
+//
+//   mj_k_step   commit the policy's actions (agent/mortal.rs:292-573), advance every table to its next
+//               decision point or game end (arena/game.rs:59-218, arena/board.rs:141-161,511-678), classify the
+//               new decisions (quick-eval / kan-select, agent/mortal.rs:200-250) and count policy rows.
+//   mj_k_rows   exclusive scan of the per-table row counts -> contiguous row ids per agent + row descriptors.
+//   mj_k_random_policy   uniform-random legal action per row (BASELINE config 2), counter-based.
+#include <hip/hip_runtime.h>
+
+#include "mj_rules.h"
+
+struct Reaction {
+    u8 type;  // RX_*
+    u8 actor, target, pai;
+    u8 c0, c1, c2;
+    u8 tsumogiri;
+};
+enum { RX_NONE = 0, RX_DAHAI, RX_REACH, RX_CHI, RX_PON, RX_DAIMINKAN, RX_KAKAN, RX_ANKAN, RX_HORA, RX_RYUKYOKU };
+
+struct StepParams {
+    TableBlock* blocks;
+    int n_tables;
+    MjTablesDev tables;
+    const int* actions[2];     // per agent, indexed by row id of the previous cycle (NULL on the first cycle)
+    const float* q_values[2];  // per agent [rows][46] or NULL (needed only by the agari guard)
+    int deal_algo;
+    int enable_quick_eval[2];
+    int enable_agari_guard[2];
+    int game_length;           // 8 = hanchan
+    int refill;                // steady-state mode: restart finished tables with fresh seeds
+    uint64_t refill_stride;    // nonce increment on refill
+    unsigned long long* counters;  // [0] env steps, [1] games finished, [2] error count, [3] decisions, [4] quick-evals
+    int* final_scores;         // [n_games_total][4] written when a game finishes
+    uint8_t* final_done;       // [n_games_total]
+    int n_games_total;
+};
+
+// ---------------------------------------------------------------- discard candidates (agent_helper.rs:35-79)
+template <class LN> MJD u64 discard_candidates_aka(const LN& L, int s) {  // 37-bit set
+    if (accepted(L, s)) return BIT(F1(last_self_tsumo, s));
+    Hand h = load_hand(L, s);
+    u64 have = h.nonzero_mask();
+    u64 ret;
+    if (declared(L, s)) ret = have & (F1(shanten, s) == 1 ? F1(next_shanten, s) : F1(keep_shanten, s));
+    else ret = have & ~F1(forbidden, s);
+    int akas = F1(akas_in_hand, s);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int t5 = 4 + 9 * k;
+        if (((ret >> t5) & 1) && ((akas >> k) & 1)) {
+            ret |= BIT(34 + k);
+            if (!(h.get(t5) > 1)) ret &= ~BIT(t5);
+        }
+    }
+    return ret;
+}
+
+// ---------------------------------------------------------------- action id -> reaction (mortal.rs:338-573)
+template <class LN> MJDN Reaction decode_action(const LN& L, int s, int action, int kan_tile) {
+    Reaction r = {RX_NONE, (u8)s, 0, MJ_NONE, MJ_NONE, MJ_NONE, MJ_NONE, 0};
+    const u32 cans = F1(cans, s);
+    const int akas = F1(akas_in_hand, s);
+    const int lkt = F1(last_kawa_tile, s);
+    r.target = F1(cans_target, s);
+    auto aka_of = [&](int pai, int a, int b) -> bool {  // match on the raw id of the called tile
+        if (pai >= 27) return false;
+        int num = pai % 9, kind = pai / 9;
+        return (num == a || num == b) && ((akas >> kind) & 1);
+    };
+    if (action <= 36) {
+        if (!(cans & CAN_DISCARD) || action < 0) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+        // validate_reaction (action.rs:121-131): tile must be in hand (aka flag for red fives)
+        Hand h = load_hand(L, s);
+        bool ok = h.get(deaka(action)) > 0 && (!is_aka(action) || ((akas >> (action - T_5MR)) & 1));
+        if (!ok) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+        r.type = RX_DAHAI;
+        r.pai = (u8)action;
+        r.tsumogiri = F1(last_self_tsumo, s) == action;
+        return r;
+    }
+    switch (action) {
+        case 37:
+            if (!(cans & CAN_RIICHI)) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            r.type = RX_REACH;
+            return r;
+        case 38: {
+            if (!(cans & CAN_CHI_LOW) || lkt == MJ_NONE) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            int first = tile_next(lkt);
+            bool aka = aka_of(lkt, 2, 3);
+            r.type = RX_CHI;
+            r.pai = (u8)lkt;
+            r.c0 = (u8)(aka ? akaize(first) : first);
+            r.c1 = (u8)(aka ? akaize(tile_next(first)) : tile_next(first));
+            return r;
+        }
+        case 39: {
+            if (!(cans & CAN_CHI_MID) || lkt == MJ_NONE) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            bool aka = aka_of(lkt, 3, 5);
+            r.type = RX_CHI;
+            r.pai = (u8)lkt;
+            r.c0 = (u8)(aka ? akaize(tile_prev(lkt)) : tile_prev(lkt));
+            r.c1 = (u8)(aka ? akaize(tile_next(lkt)) : tile_next(lkt));
+            return r;
+        }
+        case 40: {
+            if (!(cans & CAN_CHI_HIGH) || lkt == MJ_NONE) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            int last = tile_prev(lkt);
+            bool aka = aka_of(lkt, 5, 6);
+            r.type = RX_CHI;
+            r.pai = (u8)lkt;
+            r.c0 = (u8)(aka ? akaize(tile_prev(last)) : tile_prev(last));
+            r.c1 = (u8)(aka ? akaize(last) : last);
+            return r;
+        }
+        case 41: {
+            if (!(cans & CAN_PON) || lkt == MJ_NONE) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            bool aka = (lkt == T_5M && (akas & 1)) || (lkt == T_5P && (akas & 2)) || (lkt == T_5S && (akas & 4));
+            r.type = RX_PON;
+            r.pai = (u8)lkt;
+            r.c0 = (u8)(aka ? akaize(lkt) : deaka(lkt));
+            r.c1 = (u8)deaka(lkt);
+            return r;
+        }
+        case 42: {
+            if (!(cans & CAN_KAN)) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            const u64 ac = F1(ankan_cand, s), kc = F1(kakan_cand, s);
+            int tile;
+            if (kan_tile >= 0) {
+                tile = kan_tile;
+                if (tile > 33 || !(((ac | kc) >> tile) & 1)) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            } else if (cans & CAN_DAIMINKAN) {
+                tile = lkt;
+            } else if (cans & CAN_ANKAN) {
+                tile = __ffsll((long long)ac) - 1;
+            } else {
+                tile = __ffsll((long long)kc) - 1;
+            }
+            if (tile < 0 || tile == MJ_NONE) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            if (cans & CAN_DAIMINKAN) {
+                r.type = RX_DAIMINKAN;
+                r.pai = (u8)tile;
+                if (is_aka(tile)) r.c0 = r.c1 = r.c2 = (u8)deaka(tile);
+                else { r.c0 = (u8)akaize(tile); r.c1 = r.c2 = (u8)tile; }
+            } else if ((cans & CAN_ANKAN) && ((ac >> deaka(tile)) & 1)) {
+                r.type = RX_ANKAN;
+                r.pai = (u8)deaka(tile);
+            } else {
+                bool aka = (tile == T_5M && (akas & 1)) || (tile == T_5P && (akas & 2)) || (tile == T_5S && (akas & 4));
+                r.type = RX_KAKAN;
+                r.pai = (u8)(aka ? akaize(tile) : deaka(tile));
+            }
+            return r;
+        }
+        case 43:
+            if (!(cans & CAN_AGARI)) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            // validate_reaction: tsumo needs can_tsumo_agari, ron needs can_ron_agari (action.rs:198-204)
+            if (r.target == s ? !(cans & CAN_TSUMO_AGARI) : !(cans & CAN_RON_AGARI)) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            r.type = RX_HORA;
+            return r;
+        case 44:
+            if (!(cans & CAN_RYUKYOKU)) { set_err(L, MJ_ERR_ILLEGAL_ACTION); return r; }
+            r.type = RX_RYUKYOKU;
+            return r;
+        default: return r;  // 45 = pass
+    }
+}
+
+// ---------------------------------------------------------------- board (arena/board.rs)
+template <class LN> MJD void abortive_ryukyoku(const LN& L) { F(flags) |= TF_HAS_ABORTIVE; }  // board.rs:502-509
+
+template <class LN> MJD void check_riichi_accepted(const LN& L) {  // board.rs:342-351
+    int a = F(riichi_to_be_accepted);
+    if (a != MJ_NONE) {
+        F(riichi_to_be_accepted) = MJ_NONE;
+        ev_reach_accepted(L, a);
+    }
+}
+template <class LN> MJD void add_new_dora(const LN& L) {  // board.rs:353-364
+    int n = F(dora_n);
+    if (n == 0) { set_err(L, MJ_ERR_WALL); return; }
+    n -= 1;
+    F(dora_n) = (u8)n;
+    ev_dora(L, F1(wall, 56 + n));
+}
+
+template <class LN> MJDN void exhaustive_ryukyoku(const LN& L) {  // board.rs:241-294
+    const int oya = F(kyoku) & 3;
+    int deltas[4] = {0, 0, 0, 0};
+    u32 fl = F(flags);
+    if (F1(shanten, oya) == 0) fl |= TF_CAN_RENCHAN;
+    else fl &= ~TF_CAN_RENCHAN;
+    bool nagashi = false;
+    for (int i = 0; i < 4; i++) {
+        if (!((fl >> (12 + i)) & 1)) continue;
+        nagashi = true;
+        for (int k = 0; k < 4; k++) {
+            int d;
+            if (i == oya) d = (k == i) ? 12000 : -4000;
+            else d = (k == oya) ? -4000 : (k == i) ? 8000 : -2000;
+            deltas[k] += d;
+        }
+    }
+    if (!nagashi) {
+        int n = 0;
+        for (int i = 0; i < 4; i++) n += F1(shanten, i) == 0;
+        int plus = n == 1 ? 3000 : n == 2 ? 1500 : n == 3 ? 1000 : 0;
+        int minus = n == 1 ? -1000 : n == 2 ? -1500 : n == 3 ? -3000 : 0;
+        if (plus > 0)
+            for (int k = 0; k < 4; k++) deltas[k] += F1(shanten, k) == 0 ? plus : minus;
+    }
+    for (int k = 0; k < 4; k++) F1(kyoku_deltas, k) += deltas[k];
+    F(flags) = fl;
+}
+
+template <class LN> MJDN void handle_hora(const LN& L, int single_actor, int single_target, const Reaction rx[4]) {  // board.rs:366-471
+    u32 fl = F(flags) | TF_HAS_HORA;
+    const int oya = F(kyoku) & 3;
+    const bool is_ron = single_actor != single_target;
+    int honba_left = F(honba);
+    int kyotaku_point = F(kyotaku) * 1000;
+    F(kyotaku) = 0;
+    const int n_ura = 5 - F(dora_n);
+    Point pts[4];
+    bool has[4] = {false, false, false, false};
+    for (int i = 0; i < 4; i++) {
+        if (rx[i].type != RX_HORA) continue;
+        if (rx[i].actor == oya) fl |= TF_CAN_RENCHAN;
+        has[i] = seat_agari_points(L, rx[i].actor, is_ron, n_ura, pts[i]);
+        if (!has[i]) set_err(L, MJ_ERR_NOT_HORA);
+    }
+    F(flags) = fl;
+    if (is_ron) {
+        for (int k = 1; k <= 3; k++) {
+            int actor = (single_target + k) & 3;
+            if (!has[actor]) continue;
+            Point p = pts[actor];
+            int d[4] = {0, 0, 0, 0};
+            int pao = F1(paos, actor);
+            if (pao != MJ_NONE) {
+                d[pao] = -p.ron / 2 - honba_left * 300;
+                d[single_target] -= p.ron / 2;
+            } else {
+                d[single_target] = -p.ron - honba_left * 300;
+            }
+            d[actor] = p.ron + kyotaku_point + honba_left * 300;
+            kyotaku_point = 0;
+            honba_left = 0;
+            for (int i = 0; i < 4; i++) F1(kyoku_deltas, i) += d[i];
+        }
+        return;
+    }
+    if (!has[single_actor]) return;
+    Point p = pts[single_actor];
+    int d[4];
+    int pao = F1(paos, single_actor);
+    if (pao != MJ_NONE) {
+        d[0] = d[1] = d[2] = d[3] = 0;
+        d[pao] = -p.ron - honba_left * 300;
+    } else {
+        for (int i = 0; i < 4; i++) d[i] = -p.tsumo_ko - honba_left * 100;
+        if (single_actor != oya) d[oya] = -p.tsumo_oya - honba_left * 100;
+    }
+    d[single_actor] = tsumo_total(p, single_actor == oya) + kyotaku_point + honba_left * 300;
+    for (int i = 0; i < 4; i++) F1(kyoku_deltas, i) += d[i];
+}
+
+// One BoardState::step (board.rs:511-678).  Returns true when the kyoku has ended.
+template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
+    if (F(accepted_riichis) == 4) {  // 四家立直
+        abortive_ryukyoku(L);
+        return true;
+    }
+    // winning reaction: Hora 0 < Daiminkan/Pon 1 < other 2 < None 3; ties -> lowest seat (min_by_key = first min)
+    int best = 0, bestp = 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int t = rx[i].type;
+        int p = t == RX_HORA ? 0 : (t == RX_DAIMINKAN || t == RX_PON) ? 1 : t == RX_NONE ? 3 : 2;
+        if (p < bestp) { bestp = p; best = i; }
+    }
+    const Reaction ev = rx[best];
+    u32 fl = F(flags);
+    if ((fl & TF_CHECK_FOUR_KAN) && ev.type != RX_HORA) {  // 四槓散了
+        abortive_ryukyoku(L);
+        return true;
+    }
+    // update_nagashi_mangan_and_four_wind (board.rs:296-312)
+    if (ev.type == RX_DAHAI) {
+        if (!is_yaokyuu(ev.pai)) fl &= ~(TF_NAGASHI0 << ev.actor);
+    } else if (ev.type == RX_CHI || ev.type == RX_PON || ev.type == RX_DAIMINKAN) {
+        fl &= ~(TF_NAGASHI0 << ev.target);
+        fl &= ~TF_CAN_FOUR_WIND;
+    } else if (ev.type == RX_ANKAN) {
+        fl &= ~TF_CAN_FOUR_WIND;
+    }
+    F(flags) = fl;
+
+    switch (ev.type) {
+        case RX_NONE: {
+            if (F(tiles_left) == 0) {
+                exhaustive_ryukyoku(L);
+                return true;
+            }
+            check_riichi_accepted(L);
+            int tile;
+            fl = F(flags);
+            if (fl & TF_DEAL_FROM_RINSHAN) {
+                fl &= ~TF_DEAL_FROM_RINSHAN;
+                int n = F(rinshan_n);
+                if (n == 0) { set_err(L, MJ_ERR_WALL); return true; }
+                n -= 1;
+                F(rinshan_n) = (u8)n;
+                tile = F1(wall, 52 + n);
+            } else {
+                int n = F(yama_n);
+                if (n == 0) { set_err(L, MJ_ERR_WALL); return true; }
+                n -= 1;
+                F(yama_n) = (u8)n;
+                tile = F1(wall, 66 + n);
+            }
+            F(tiles_left) -= 1;
+            bool dora_now = (fl & TF_NEW_DORA_AT_TSUMO) != 0;
+            fl &= ~TF_NEW_DORA_AT_TSUMO;
+            F(flags) = fl;
+            if (dora_now) add_new_dora(L);
+            ev_tsumo(L, F(tsumo_actor), tile);
+            break;
+        }
+        case RX_DAHAI: {
+            if (fl & TF_NEW_DORA_AT_DISCARD) {
+                F(flags) = fl & ~TF_NEW_DORA_AT_DISCARD;
+                add_new_dora(L);
+            }
+            ev_dahai(L, ev.actor, ev.pai, ev.tsumogiri);
+            const int next_actor = (ev.actor + 1) & 3;
+            F(tsumo_actor) = (u8)next_actor;
+            fl = F(flags);
+            if (fl & TF_CAN_FOUR_WIND) {  // check_four_wind (board.rs:314-340)
+                bool abort = false;
+                if (!(ev.pai >= T_E && ev.pai <= T_N)) {
+                    fl &= ~TF_CAN_FOUR_WIND;
+                } else if (F1(pflags, next_actor) & PF_CAN_W_RIICHI) {
+                    int fw = F(four_wind_tile);
+                    if (fw != MJ_NONE) {
+                        if (fw != ev.pai) fl &= ~TF_CAN_FOUR_WIND;
+                    } else {
+                        F(four_wind_tile) = ev.pai;
+                    }
+                } else {
+                    int fw = F(four_wind_tile);
+                    if (fw != MJ_NONE) {
+                        if (fw == ev.pai) abort = true;
+                        else fl &= ~TF_CAN_FOUR_WIND;
+                    } else {
+                        set_err(L, MJ_ERR_FOUR_WIND);
+                    }
+                }
+                F(flags) = fl;
+                if (abort) {  // 四風連打
+                    abortive_ryukyoku(L);
+                    return true;
+                }
+            }
+            if (F(kans) == 4) {
+                bool all_lt4 = true;
+                for (int s = 0; s < 4; s++) all_lt4 &= (F2(n_melds, s, 2) + F2(n_melds, s, 3)) < 4;
+                if (all_lt4) F(flags) |= TF_CHECK_FOUR_KAN;
+            }
+            break;
+        }
+        case RX_CHI:
+        case RX_PON:
+            check_riichi_accepted(L);
+            ev_chi_pon(L, ev.type == RX_PON, ev.actor, ev.target, ev.pai, ev.c0, ev.c1);
+            break;
+        case RX_ANKAN:
+            if (fl & TF_NEW_DORA_AT_DISCARD) {
+                F(flags) = fl & ~TF_NEW_DORA_AT_DISCARD;
+                add_new_dora(L);
+            }
+            ev_ankan(L, ev.actor, ev.pai);
+            add_new_dora(L);
+            F(tsumo_actor) = ev.actor;
+            F(flags) |= TF_DEAL_FROM_RINSHAN;
+            F(kans) += 1;
+            break;
+        case RX_DAIMINKAN:
+        case RX_KAKAN:
+            if (fl & TF_NEW_DORA_AT_DISCARD) F(flags) = fl | TF_NEW_DORA_AT_TSUMO;
+            check_riichi_accepted(L);
+            if (ev.type == RX_DAIMINKAN) ev_daiminkan(L, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, ev.c2);
+            else ev_kakan(L, ev.actor, ev.pai);
+            F(flags) |= TF_NEW_DORA_AT_DISCARD | TF_DEAL_FROM_RINSHAN;
+            F(tsumo_actor) = ev.actor;
+            F(kans) += 1;
+            break;
+        case RX_REACH:
+            ev_reach(L, ev.actor);
+            F(riichi_to_be_accepted) = ev.actor;
+            break;
+        case RX_HORA:
+            handle_hora(L, ev.actor, ev.target, rx);
+            return true;
+        case RX_RYUKYOKU:  // 九種九牌
+            abortive_ryukyoku(L);
+            return true;
+    }
+    // update_paos (board.rs:473-499)
+    if ((ev.type == RX_PON || ev.type == RX_DAIMINKAN) && is_jihai(ev.pai)) {
+        const int s = ev.actor;
+        u32 jz = 0;
+        for (int i = 0; i < F2(n_melds, s, 1); i++) {
+            int t = F2(pons, s, i);
+            if (t >= T_E) jz |= 1u << (t - T_E);
+        }
+        for (int i = 0; i < F2(n_melds, s, 2); i++) {
+            int t = F2(minkans, s, i);
+            if (t >= T_E) jz |= 1u << (t - T_E);
+        }
+        bool sangen = (jz & 0b1110000) == 0b1110000, suushi = (jz & 0b0001111) == 0b0001111;
+        if ((sangen && ev.pai >= T_P) || (suushi && ev.pai <= T_N)) F1(paos, s) = ev.target;
+    }
+    return false;
+}
+
+template <class LN> MJD bool any_can_act(const LN& L) {
+    return ((F1(cans, 0) | F1(cans, 1) | F1(cans, 2) | F1(cans, 3)) & CAN_ACT) != 0;
+}
+
+// Game::poll (game.rs:59-178) with BoardState::poll (board.rs:141-161) inlined.
+template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepParams& P) {
+    for (;;) {
+        u32 fl = F(flags);
+        if (fl & TF_ENDED) return;
+        if (F(err) != MJ_OK) { F(flags) = fl | TF_ENDED; return; }
+        bool kyoku_end;
+        if (!(fl & TF_KYOKU_STARTED)) {
+            const int kyoku = F(kyoku), len = P.game_length;
+            bool any30k = false;
+            for (int i = 0; i < 4; i++) any30k |= F1(scores, i) >= 30000;
+            if (kyoku >= len + 4 || (kyoku >= len && !(fl & TF_IN_RENCHAN) && any30k)) {
+                F(flags) = fl | TF_ENDED;
+                return;
+            }
+            start_kyoku(L, P.deal_algo);  // haipai + first tsumo == the first board step (board.rs:512-515)
+            kyoku_end = false;
+        } else {
+            kyoku_end = board_step(L, rx);
+        }
+        for (int i = 0; i < 4; i++) rx[i].type = RX_NONE;
+        if (!kyoku_end) {
+            if (any_can_act(L)) return;
+            continue;
+        }
+        // ---- Poll::End (board.rs:149-157, game.rs:114-174)
+        fl = F(flags);
+        for (int i = 0; i < 4; i++) F1(scores, i) += F1(kyoku_deltas, i);
+        if (fl & TF_HAS_ABORTIVE) fl |= TF_CAN_RENCHAN;
+        fl &= ~(TF_KYOKU_STARTED | TF_IN_RENCHAN);
+        for (int i = 0; i < 4; i++) F1(cans, i) = 0;
+        bool tobi = false;
+        for (int i = 0; i < 4; i++) tobi |= F1(scores, i) < 0;
+        if (tobi) {
+            F(flags) = fl | TF_ENDED;
+            return;
+        }
+        const int kyoku = F(kyoku);
+        if (fl & TF_HAS_ABORTIVE) {
+            F(honba) += 1;
+        } else if (!(fl & TF_CAN_RENCHAN)) {
+            F(kyoku) = (u8)(kyoku + 1);
+            if (fl & TF_HAS_HORA) F(honba) = 0;
+            else F(honba) += 1;
+        } else {
+            const int oya = kyoku & 3;
+            if (kyoku >= P.game_length - 1 && F1(scores, oya) >= 30000) {
+                int top = 0;
+                for (int i = 1; i < 4; i++)
+                    if (F1(scores, i) > F1(scores, top)) top = i;
+                if (top == oya) {
+                    F(flags) = fl | TF_ENDED;
+                    return;
+                }
+            }
+            fl |= TF_IN_RENCHAN;
+            F(honba) += 1;
+        }
+        F(flags) = fl;
+    }
+}
+
+__global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
+    const int table = blockIdx.x * 64 + threadIdx.x;
+    Lane L = {P.blocks + blockIdx.x, (int)threadIdx.x, &P.tables};
+    u32 fl = F(flags);
+    const bool active = table < P.n_tables && !(fl & TF_INACTIVE);
+    bool live_after = false;
+    int n_dec = 0, n_quick = 0;
+    if (active && !(fl & TF_DONE)) {
+        // ---- commit (game.rs:180-218)
+        Reaction rx[4];
+        const int pend = F(pending);
+        for (int s = 0; s < 4; s++) {
+            rx[s].type = RX_NONE;
+            if (!((pend >> s) & 1)) continue;
+            const int qp = F1(quick_pai, s);
+            if (qp != MJ_NONE) {
+                rx[s] = {RX_DAHAI, (u8)s, 0, (u8)qp, MJ_NONE, MJ_NONE, MJ_NONE, (u8)(F1(last_self_tsumo, s) == qp)};
+                continue;
+            }
+            const int agent = (F(agent_of_seat) >> s) & 1;
+            const int mr = F1(main_row, s), kr = F1(kan_row, s);
+            int action = P.actions[agent] ? P.actions[agent][mr] : 45;
+            const int kan_tile = kr >= 0 ? P.actions[agent][kr] : -1;
+            if (P.enable_agari_guard[agent] && action == 43 && P.q_values[agent]) {
+                // rule-based agari guard (mortal.rs:319-336): handled by mj_rule_based_agari in a later round
+            }
+            rx[s] = decode_action(L, s, action, kan_tile);
+        }
+        F(pending) = 0;
+        // ---- poll
+        game_poll(L, rx, P);
+        fl = F(flags);
+        if (fl & TF_ENDED) {
+            // game.rs:181-197: leftover kyotaku to the (first) top, emit the result
+            int kt = F(kyotaku);
+            if (kt > 0) {
+                int top = 0;
+                for (int i = 1; i < 4; i++)
+                    if (F1(scores, i) > F1(scores, top)) top = i;
+                F1(scores, top) += kt * 1000;
+                F(kyotaku) = 0;
+            }
+            const u32 gid = F(game_id);
+            if ((int)gid < P.n_games_total) {
+                for (int i = 0; i < 4; i++) P.final_scores[gid * 4 + i] = F1(scores, i);
+                P.final_done[gid] = F(err) == MJ_OK ? 1 : 2;
+            }
+            if (F(err) != MJ_OK) atomicAdd(&P.counters[2], 1ull);
+            atomicAdd(&P.counters[1], 1ull);
+            fl |= TF_DONE;
+            F(flags) = fl;
+            for (int a = 0; a < 2; a++) F1(n_rows, a) = 0;
+        } else {
+            live_after = true;
+            // ---- classify the new decisions (mortal.rs:200-250)
+            int pend_new = 0, nr[2] = {0, 0};
+            for (int s = 0; s < 4; s++) {
+                const u32 cans = F1(cans, s);
+                F1(main_row, s) = -1;
+                F1(kan_row, s) = -1;
+                F1(quick_pai, s) = MJ_NONE;
+                if (!(cans & CAN_ACT)) continue;
+                pend_new |= 1 << s;
+                n_dec++;
+                const int agent = (F(agent_of_seat) >> s) & 1;
+                if (P.enable_quick_eval[agent] && (cans & CAN_DISCARD) &&
+                    !(cans & (CAN_RIICHI | CAN_TSUMO_AGARI | CAN_ANKAN | CAN_KAKAN | CAN_RYUKYOKU))) {
+                    u64 dc = discard_candidates_aka(L, s);
+                    if (__popcll(dc) == 1) {
+                        F1(quick_pai, s) = (u8)(__ffsll((long long)dc) - 1);
+                        n_quick++;
+                        continue;
+                    }
+                }
+                bool need_kan;
+                if (!(cans & (CAN_ANKAN | CAN_KAKAN))) need_kan = false;
+                else if (!P.enable_quick_eval[agent]) need_kan = true;
+                else need_kan = __popcll(F1(ankan_cand, s)) + __popcll(F1(kakan_cand, s)) > 1;
+                // local row offsets for now; mj_k_rows adds the table's base
+                if (need_kan) F1(kan_row, s) = nr[agent]++;
+                F1(main_row, s) = nr[agent]++;
+            }
+            F(pending) = (u8)pend_new;
+            F1(n_rows, 0) = (u8)nr[0];
+            F1(n_rows, 1) = (u8)nr[1];
+        }
+    } else if (active) {
+        F1(n_rows, 0) = 0;
+        F1(n_rows, 1) = 0;
+    } else {
+        F1(n_rows, 0) = 0;
+        F1(n_rows, 1) = 0;
+    }
+    // env steps = tables still live after this cycle (reference: `actions += games.len()`, game.rs:303-304)
+    unsigned long long live_mask = __ballot(live_after);
+    int dec_sum = n_dec, quick_sum = n_quick;
+    for (int off = 32; off > 0; off >>= 1) {
+        dec_sum += __shfl_down(dec_sum, off);
+        quick_sum += __shfl_down(quick_sum, off);
+    }
+    if (threadIdx.x == 0) {
+        if (live_mask) atomicAdd(&P.counters[0], (unsigned long long)__popcll(live_mask));
+        if (dec_sum) atomicAdd(&P.counters[3], (unsigned long long)dec_sum);
+        if (quick_sum) atomicAdd(&P.counters[4], (unsigned long long)quick_sum);
+    }
+}
+
+// Restart finished tables with fresh seeds (steady-state throughput mode; not used in parity runs).
+__global__ __launch_bounds__(64) void mj_k_refill(StepParams P) {
+    const int table = blockIdx.x * 64 + threadIdx.x;
+    Lane L = {P.blocks + blockIdx.x, (int)threadIdx.x, &P.tables};
+    u32 fl = F(flags);
+    if (table >= P.n_tables || (fl & TF_INACTIVE) || !(fl & TF_DONE)) return;
+    F(seed_nonce) += P.refill_stride;
+    F(flags) = 0;
+    F(kyoku) = 0;
+    F(honba) = 0;
+    F(kyotaku) = 0;
+    F(err) = MJ_OK;
+    F(pending) = 0;
+    for (int i = 0; i < 4; i++) F1(scores, i) = 25000;
+}
+
+// ---------------------------------------------------------------- row assignment
+// Single-block exclusive scan over per-table row counts (both agents), then every seat's local row offset becomes
+// a global row id and the row descriptor arrays are filled.  Row order: table, seat, kan-select row before main row.
+struct RowsParams {
+    TableBlock* blocks;
+    int n_tables;
+    uint32_t* rows[2];   // out: row descriptors per agent
+    int* n_rows_out;     // out: [2] totals (device)
+    int max_rows[2];
+};
+__global__ __launch_bounds__(1024) void mj_k_rows(RowsParams P) {
+    __shared__ int s_sum[2][1024];
+    const int tid = threadIdx.x;
+    const int per = (P.n_tables + 1023) / 1024;
+    const int t0 = tid * per, t1 = min(P.n_tables, t0 + per);
+    int acc[2] = {0, 0};
+    for (int t = t0; t < t1; t++) {
+        TableBlock* B = P.blocks + (t >> 6);
+        acc[0] += B->n_rows[0][t & 63];
+        acc[1] += B->n_rows[1][t & 63];
+    }
+    s_sum[0][tid] = acc[0];
+    s_sum[1][tid] = acc[1];
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        int a0 = tid >= off ? s_sum[0][tid - off] : 0, a1 = tid >= off ? s_sum[1][tid - off] : 0;
+        __syncthreads();
+        s_sum[0][tid] += a0;
+        s_sum[1][tid] += a1;
+        __syncthreads();
+    }
+    int base[2] = {s_sum[0][tid] - acc[0], s_sum[1][tid] - acc[1]};
+    if (tid == 1023) {
+        P.n_rows_out[0] = s_sum[0][1023];
+        P.n_rows_out[1] = s_sum[1][1023];
+    }
+    for (int t = t0; t < t1; t++) {
+        TableBlock* B = P.blocks + (t >> 6);
+        const int l = t & 63;
+        const int nr0 = B->n_rows[0][l], nr1 = B->n_rows[1][l];
+        if (nr0 | nr1) {
+            const int aos = B->agent_of_seat[l];
+            for (int s = 0; s < 4; s++) {
+                const int agent = (aos >> s) & 1;
+                int kr = B->kan_row[s][l], mr = B->main_row[s][l];
+                if (kr >= 0) {
+                    kr += base[agent];
+                    B->kan_row[s][l] = kr;
+                    if (kr < P.max_rows[agent]) P.rows[agent][kr] = ROW_PACK(t, s, 1);
+                }
+                if (mr >= 0) {
+                    mr += base[agent];
+                    B->main_row[s][l] = mr;
+                    if (mr < P.max_rows[agent]) P.rows[agent][mr] = ROW_PACK(t, s, 0);
+                }
+            }
+        }
+        base[0] += nr0;
+        base[1] += nr1;
+    }
+}
+
+// ---------------------------------------------------------------- random policy (config 2)
+// action = k-th set bit of the 46-bit mask, k = splitmix64(seed ^ game*K1 ^ seat*K2 ^ kan*K3 ^ cycle*K4) >> 33 mod popcount
+__global__ void mj_k_random_policy(const TableBlock* blocks, const uint32_t* rows, const uint8_t* masks, int n_rows,
+                                   uint64_t seed, uint64_t cycle, int* actions) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint32_t d = rows[r];
+    uint32_t t = ROW_TABLE(d);
+    uint64_t game = blocks[t >> 6].game_id[t & 63];
+    uint64_t x = seed ^ (game * 0xD1B54A32D192ED03ull) ^ ((uint64_t)ROW_SEAT(d) * 0x8CB92BA72F3D8DD7ull) ^
+                 ((uint64_t)ROW_KAN(d) * 0xAEF17502108EF2D9ull) ^ (cycle * 0x94D049BB133111EBull);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    const uint8_t* m = masks + (size_t)r * 46;
+    uint64_t bits = 0;
+    for (int i = 0; i < 46; i++) bits |= (uint64_t)(m[i] != 0) << i;
+    int cnt = __popcll(bits);
+    int a = 45;
+    if (cnt > 0) {
+        int k = (int)((x >> 33) % (uint64_t)cnt);
+        for (int i = 0; i < k; i++) bits &= bits - 1;
+        a = __ffsll((long long)bits) - 1;
+    }
+    actions[r] = a;
+}

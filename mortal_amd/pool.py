@@ -1,0 +1,152 @@
+"""TablePool: the SoA pool of concurrent tables in HBM, driven through the C-ABI (include/mortal_amd.h).
+
+PyTorch is used only for device memory and the HIP stream; all compute is in libmortal_amd.so.
+Reference counterpart: `BatchGame::run` (libriichi/src/arena/game.rs:230-316).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import tables
+from ._lib import MortalAmdError, check, lib
+
+OBS_ROWS = {1: 938, 2: 942, 3: 934, 4: 1012}
+ACTION_SPACE = 46
+_tables_ready = False
+
+
+def _ensure_tables():
+    global _tables_ready
+    if not _tables_ready:
+        p = tables.payload()
+        check(lib.mj_tables_upload(p, len(p)))
+        _tables_ready = True
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class TablePool:
+    def __init__(self, n_tables, version=4, deal_algo=0, device="cuda:0", max_rows=0):
+        if not torch.cuda.is_available():
+            raise MortalAmdError("TablePool needs a HIP device (torch.cuda.is_available() is False)")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        _ensure_tables()
+        self.n_tables = n_tables
+        self.version = version
+        self.C = OBS_ROWS[version]
+        self.max_rows = max_rows or 8 * n_tables
+        self.h = lib.mj_pool_create(n_tables, version, deal_algo, self.max_rows)
+        if not self.h:
+            raise MortalAmdError(lib.mj_last_error().decode())
+        self.n_rows = [0, 0]
+        self.n_games_total = n_tables
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.mj_pool_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self, seeds, game_ids=None, agent_of_seat=None, n_games_total=None):
+        """seeds: list of (nonce, key) per table; agent_of_seat: uint8 per table, bit s = agent of seat s."""
+        assert len(seeds) == self.n_tables
+        nonces = np.ascontiguousarray([s[0] for s in seeds], dtype=np.uint64)
+        keys = np.ascontiguousarray([s[1] for s in seeds], dtype=np.uint64)
+        gid = np.ascontiguousarray(game_ids if game_ids is not None else np.arange(self.n_tables), dtype=np.uint32)
+        aos = np.ascontiguousarray(agent_of_seat if agent_of_seat is not None else np.zeros(self.n_tables),
+                                   dtype=np.uint8)
+        self.n_games_total = int(n_games_total or (int(gid.max()) + 1))
+        check(lib.mj_pool_reset(self.h, nonces.ctypes.data, keys.ctypes.data, gid.ctypes.data, aos.ctypes.data,
+                                self.n_games_total))
+        self.n_rows = [0, 0]
+
+    def configure(self, agent, enable_quick_eval=True, enable_rule_based_agari_guard=False):
+        check(lib.mj_pool_configure(self.h, agent, int(enable_quick_eval), int(enable_rule_based_agari_guard)))
+
+    def set_refill(self, nonce_stride):
+        check(lib.mj_pool_set_refill(self.h, nonce_stride))
+
+    def step(self, actions0=None, actions1=None):
+        """One arena cycle; actionsN = int32 cuda tensor with one action per row of agent N's last batch."""
+        for a in (actions0, actions1):
+            if a is not None:
+                assert a.is_cuda and a.dtype == torch.int32 and a.is_contiguous()
+        p0 = actions0.data_ptr() if actions0 is not None and actions0.numel() else None
+        p1 = actions1.data_ptr() if actions1 is not None and actions1.numel() else None
+        check(lib.mj_step(self.h, p0, p1, _stream()))
+        out = (C.c_int32 * 2)()
+        check(lib.mj_rows_count(self.h, out, _stream()))
+        self.n_rows = [out[0], out[1]]
+        return self.n_rows
+
+    def rows(self, agent):
+        """Row descriptors of the current batch as an int64 cpu array [n, 3] = (table, seat, is_kan)."""
+        n = self.n_rows[agent]
+        ptr = lib.mj_rows_dev(self.h, agent)
+        d = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            torch.cuda.current_stream().synchronize()
+            _memcpy_d2d(d.data_ptr(), ptr, 4 * n)
+        v = d.cpu().numpy().view(np.uint32)
+        return np.stack([v & 0x0FFFFFFF, (v >> 28) & 3, v >> 31], axis=1).astype(np.int64)
+
+    def encode(self, agent, obs=None, masks=None):
+        """Encode agent's rows in place into (or into fresh) device tensors. Returns (obs [n,C,34] f32, masks [n,46] bool)."""
+        n = self.n_rows[agent]
+        if obs is None:
+            obs = torch.empty((n, self.C, 34), dtype=torch.float32, device=self.device)
+        if masks is None:
+            masks = torch.empty((n, ACTION_SPACE), dtype=torch.bool, device=self.device)
+        assert obs.is_contiguous() and masks.is_contiguous() and obs.shape[0] >= n and masks.shape[0] >= n
+        if n:
+            check(lib.mj_encode(self.h, agent, obs.data_ptr(), masks.data_ptr(), _stream()))
+        return obs[:n], masks[:n]
+
+    def random_policy(self, agent, masks, seed, cycle, out=None):
+        n = self.n_rows[agent]
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            check(lib.mj_random_policy(self.h, agent, masks.data_ptr(), seed, cycle, out.data_ptr(), _stream()))
+        return out[:n]
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        check(lib.mj_counters(self.h, out, _stream()))
+        return dict(steps=out[0], games=out[1], errors=out[2], decisions=out[3], quick=out[4], cycles=out[5])
+
+    def results(self):
+        scores = np.zeros((self.n_games_total, 4), dtype=np.int32)
+        done = np.zeros(self.n_games_total, dtype=np.uint8)
+        check(lib.mj_results(self.h, scores.ctypes.data, done.ctypes.data, _stream()))
+        return scores, done
+
+    def first_error(self):
+        t = C.c_int(-1)
+        code = check(lib.mj_pool_first_error(self.h, C.byref(t), _stream()))
+        return code, t.value
+
+    def encode_timing(self, enable=True):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        check(lib.mj_encode_timing(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def debug_table(self, table):
+        size = lib.mj_debug_table_size()
+        buf = (C.c_uint8 * size)()
+        check(lib.mj_debug_table(self.h, table, buf, size, _stream()))
+        return bytes(buf)
+
+
+def _memcpy_d2d(dst, src, nbytes):
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(dst, src, nbytes, 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise MortalAmdError(f"hipMemcpy failed: {rc}")

@@ -409,14 +409,16 @@ int mjo_arena_rows(void* h, int* rows_out) {
 int mjo_arena_encode(void* h, int row0, int row1, float* obs, u8* masks) {
     return guard([&] {
         Arena* a = (Arena*)h;
-        size_t stride = (size_t)obs_rows(a->version) * 34;
+        // masks are version-independent; without an obs buffer use v3 (no SP tables) to get them cheaply
+        int version = obs ? a->version : 3;
+        size_t stride = (size_t)obs_rows(version) * 34;
         std::vector<float> tmp;
         if (!obs) tmp.resize(stride);
         for (int r = row0; r < row1; r++) {
             const Row& row = a->rows.at(r);
             const PlayerState& st = a->games[row.game]->board->player_states[row.seat];
             float* o = obs ? obs + (size_t)(r - row0) * stride : tmp.data();
-            st.encode_obs(a->version, row.is_kan != 0, o, masks + (size_t)(r - row0) * 46);
+            st.encode_obs(version, row.is_kan != 0, o, masks + (size_t)(r - row0) * 46);
         }
         return 0;
     });

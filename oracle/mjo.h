@@ -43,8 +43,8 @@ struct Error : std::runtime_error {
 // macros.rs:9-128: 0-8 m, 9-17 p, 18-26 s, 27-33 ESWNPFC, 34-36 aka 5m/5p/5s, 37 '?'
 enum : u8 { T_5M = 4, T_5P = 13, T_5S = 22, T_E = 27, T_S = 28, T_W = 29, T_N = 30, T_P = 31, T_F = 32, T_C = 33, T_5MR = 34, T_5PR = 35, T_5SR = 36, T_UNK = 37 };
 
-inline u8 deaka(u8 t) { return t == T_5MR ? T_5M : t == T_5PR ? T_5P : t == T_5SR ? T_5S : t; }       // tile.rs:68-77
-inline u8 akaize(u8 t) { return t == T_5M ? T_5MR : t == T_5P ? T_5PR : t == T_5S ? T_5SR : t; }      // tile.rs:79-88
+inline u8 deaka(u8 t) { return t == T_5MR ? (u8)T_5M : t == T_5PR ? (u8)T_5P : t == T_5SR ? (u8)T_5S : t; }       // tile.rs:68-77
+inline u8 akaize(u8 t) { return t == T_5M ? (u8)T_5MR : t == T_5P ? (u8)T_5PR : t == T_5S ? (u8)T_5SR : t; }      // tile.rs:79-88
 inline bool is_aka(u8 t) { return t >= T_5MR && t <= T_5SR; }                                          // tile.rs:90-94
 inline bool is_jihai(u8 t) { return t >= T_E && t <= T_C; }                                            // tile.rs:96-100
 inline bool is_yaokyuu(u8 t) {                                                                         // tile.rs:102-109

@@ -462,10 +462,11 @@ def random_actions(masks, rows, cycle, seed=0x9E3779B97F4A7C15):
     if n == 0:
         return np.zeros(0, dtype=np.int32)
     rows = np.asarray(rows, dtype=np.uint64)
-    x = (np.uint64(seed) ^ (rows[:, 0] * np.uint64(0xD1B54A32D192ED03)) ^ (rows[:, 1] * np.uint64(0x8CB92BA72F3D8DD7))
-         ^ (rows[:, 2] * np.uint64(0xAEF17502108EF2D9)) ^ (np.uint64(cycle) * np.uint64(0x94D049BB133111EB)))
-    # splitmix64 finaliser
     with np.errstate(over="ignore"):
+        x = (np.uint64(seed) ^ (rows[:, 0] * np.uint64(0xD1B54A32D192ED03))
+             ^ (rows[:, 1] * np.uint64(0x8CB92BA72F3D8DD7)) ^ (rows[:, 2] * np.uint64(0xAEF17502108EF2D9))
+             ^ (np.array([cycle], dtype=np.uint64) * np.uint64(0x94D049BB133111EB)))
+        # splitmix64 finaliser
         x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         x = x ^ (x >> np.uint64(31))
