@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — env steps/sec + games/sec of the MI355X table pool (BASELINE.json metric).
+
+One "step" (cycle) = every live table advanced to its next decision point with the chosen reactions applied
+(reference: one `Game::poll` + `Game::commit` round, arena/game.rs:286-304); `value` = sum over the timed cycles of
+live tables / wall time = the reference's `actions` counter per second.
+
+Default workload: 65,536 tables per GPU, uniform-random legal policy on device, obs+mask encoded for every decision
+(obs version per --version), finished tables refilled with fresh seeds so the table count stays constant.
+Synthetic fixed-seed deals: game g uses seed (10000 + g/4, 0xd5dfaa4cef265cd7) (docs/src/perf/strength.md:19).
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+KEY = 0xD5DFAA4CEF265CD7
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+STATE_READ_BYTES = 1500  # per-decision state read
+
+
+def cpu_baseline(version, budget_s=12.0, n_tables=32):
+    """Oracle arena (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+    import numpy as np  # noqa: F401
+    import oracle_lib as O
+
+    O.lib()
+    t0 = time.perf_counter()
+    cycles = rows_total = steps = batches = 0
+    while time.perf_counter() - t0 < budget_s:
+        seeds = [(10000 + (batches * n_tables + g) // 4, KEY) for g in range(n_tables)]
+        arena = O.Arena(seeds, deal_algo=0, enable_quick_eval=True, version=version, keep_log=False)
+        cycle = 0
+        while arena.n_live > 0 and time.perf_counter() - t0 < budget_s:
+            rows = arena.poll()
+            n = len(rows)
+            obs, masks = arena.encode(0, n, want_obs=True)  # the oracle encodes every decision like the GPU path
+            act = O.random_actions(masks, rows, cycle)
+            arena.commit(act)
+            cycle += 1
+            rows_total += n
+        steps += arena.steps
+        cycles += cycle
+        batches += 1
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="env steps/s", cores=1, kind="port",
+                sample=f"{batches} batches of {n_tables} tables, {cycles} cycles, {rows_total} decisions encoded "
+                       f"(obs v{version}), random-legal policy, {dt:.1f}s, oracle/libmjoracle.so on one thread; the "
+                       f"Rust reference is not buildable here (no rustc)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--tables", type=int, default=65536, help="tables per GPU")
+    ap.add_argument("--version", type=int, default=3, help="obs version (consts.rs:20-28)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from mortal_amd.pool import TablePool
+
+    N = args.tables
+    # tables shard by contiguous game-index ranges, multiples of 4 so each duplicate-deal set stays on one GPU
+    g0 = rank * N
+    seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(N)]
+    pool = TablePool(N, version=args.version, deal_algo=0, device=str(dev), max_rows=2 * N)
+    pool.reset(seeds, game_ids=np.arange(N), n_games_total=N)
+    pool.set_refill(world * N // 4)  # a finished table restarts on a seed no other table/rank uses
+    C = pool.C
+    obs = torch.empty((2 * N, C, 34), dtype=torch.float32, device=dev)
+    masks = torch.empty((2 * N, 46), dtype=torch.bool, device=dev)
+    act = torch.empty(2 * N, dtype=torch.int32, device=dev)
+
+    def cycle(i, a_prev):
+        n, _ = pool.step(a_prev, None)
+        pool.encode(0, obs, masks)
+        pool.random_policy(0, masks, 0x9E3779B97F4A7C15, i, act)
+        return act[:n], n
+
+    a_prev = None
+    for i in range(args.warmup):
+        a_prev, _ = cycle(i, a_prev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    c0 = pool.counters()
+    pool.encode_timing(True)
+    rows_timed = 0
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        a_prev, n = cycle(i, a_prev)
+        rows_timed += n
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = pool.counters()
+    enc_ms, enc_launches = pool.encode_timing(False)
+    steps = c1["steps"] - c0["steps"]
+    games = c1["games"] - c0["games"]
+    code, tbl = pool.first_error()
+    if code:
+        raise SystemExit(f"table {tbl} in error {code}")
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([steps, games, rows_timed], dtype=torch.float64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        steps, games, rows_all = (float(x) for x in s.tolist())
+        # the single collective of the data path: gather of episode returns (final scores of finished games)
+        sc, dn = pool.results()
+        ret = torch.from_numpy(sc).to(dev)
+        out = [torch.empty_like(ret) for _ in range(world)] if rank == 0 else None
+        dist.gather(ret, out, dst=0)
+    else:
+        rows_all = rows_timed
+
+    if rank == 0:
+        bytes_per_row = C * 34 * 4 + 46 + STATE_READ_BYTES
+        achieved = rows_timed * bytes_per_row / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
+        line = {
+            "metric": "env steps/sec (65536 parallel tables per GPU)",
+            "value": steps / dt,
+            "unit": "env steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/i32 state, f32 obs",
+            "data": "synthetic",
+            "games_per_sec": games / dt,
+            "decisions_per_sec": rows_all / dt,
+            "config": {
+                "workload": f"{N} tables per GPU, uniform-random legal policy on device, env-step + obs(v{args.version})"
+                            f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals",
+                "tables_per_gpu": N,
+                "obs_version": args.version,
+                "parallelism": f"tables sharded x{world}, no data-path collective (one RCCL gather of episode returns)",
+            },
+            "roofline": {
+                "kernel": "mj_k_encode",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_decision": bytes_per_row,
+                "avg_launch_ms": enc_ms / max(enc_launches, 1),
+                "launches": enc_launches,
+            },
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.version)
+        print(json.dumps(line))
+    pool.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,8 @@ int mj_pool_first_error(MjPool* pool, int* table_out, void* stream);
 /* Debug/test: copy one table's state (struct TableOne, mortal_amd/csrc/mj_state.h) to host memory. */
 int mj_debug_table(MjPool* pool, int table, void* out, size_t out_size, void* stream);
 size_t mj_debug_table_size(void);
+/* "name:elem_size:count:offset;..." describing the struct returned by mj_debug_table. */
+const char* mj_debug_layout(void);
 int mj_obs_rows(int version);
 
 #ifdef __cplusplus

@@ -13,7 +13,7 @@ SYMBOLS = [
     "mj_last_error", "mj_abi_version", "mj_tables_upload", "mj_pool_create", "mj_pool_destroy", "mj_pool_reset",
     "mj_pool_configure", "mj_pool_set_refill", "mj_step", "mj_rows_count", "mj_rows_dev", "mj_encode",
     "mj_encode_timing", "mj_random_policy", "mj_counters", "mj_results", "mj_pool_first_error", "mj_debug_table",
-    "mj_debug_table_size", "mj_obs_rows",
+    "mj_debug_table_size", "mj_debug_layout", "mj_obs_rows",
 ]
 
 
@@ -49,6 +49,7 @@ def _load():
     L.mj_pool_first_error.argtypes = [vp, vp, vp]
     L.mj_debug_table.argtypes = [vp, i32, vp, C.c_size_t, vp]
     L.mj_debug_table_size.restype = C.c_size_t
+    L.mj_debug_layout.restype = C.c_char_p
     L.mj_obs_rows.argtypes = [i32]
     return L
 

@@ -55,6 +55,12 @@ std::vector<float> build_rbf(int n_max, int cap, int intervals) {
     return out;
 }
 
+size_t enc_lds_bytes(int version) {
+    int C = version == 1 ? 938 : version == 2 ? 942 : version == 3 ? 934 : 1012;
+    int tile_rows = ((C + ENC_PASSES - 1) / ENC_PASSES + 1) & ~1;
+    return (size_t)tile_rows * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + sizeof(EncDerived);
+}
+
 std::vector<MjGatherEnt> build_gather() {
     std::vector<MjGatherEnt> v;
 #define MJ_X_GATHER(type, name, dims, count)                                                         \
@@ -73,6 +79,8 @@ struct MjPool {
     TableBlock* blocks = nullptr;
     uint32_t* rows[2] = {nullptr, nullptr};
     int* n_rows_dev = nullptr;
+    int* block_rows = nullptr;
+    TableOne* snap = nullptr;
     int* n_rows_host = nullptr;  // pinned
     unsigned long long* counters = nullptr;
     int* final_scores = nullptr;
@@ -97,6 +105,18 @@ const char* mj_last_error(void) { return g_err.c_str(); }
 int mj_abi_version(void) { return 1; }
 int mj_obs_rows(int version) { return version == 1 ? 938 : version == 2 ? 942 : version == 3 ? 934 : version == 4 ? 1012 : -1; }
 size_t mj_debug_table_size(void) { return sizeof(TableOne); }
+// "name:elem_size:count:offset;..." of struct TableOne, so a host tool can decode mj_debug_table() generically
+const char* mj_debug_layout(void) {
+    static std::string s;
+    if (s.empty()) {
+#define MJ_X_LAYOUT(type, name, dims, count) \
+    s += std::string(#name) + ":" + std::to_string(sizeof(type)) + ":" + std::to_string(count) + ":" + \
+         std::to_string(offsetof(TableOne, name)) + ";";
+        MJ_FIELDS(MJ_X_LAYOUT)
+#undef MJ_X_LAYOUT
+    }
+    return s.c_str();
+}
 
 int mj_tables_upload(const void* payload, size_t size) {
     if (g_tables.ready) return 0;
@@ -162,6 +182,8 @@ MjPool* mj_pool_create(int n_tables, int version, int deal_algo, int max_rows) {
               hipMalloc(&P->rows[0], (size_t)P->max_rows * 4) == hipSuccess &&
               hipMalloc(&P->rows[1], (size_t)P->max_rows * 4) == hipSuccess &&
               hipMalloc(&P->n_rows_dev, 2 * sizeof(int)) == hipSuccess &&
+              hipMalloc(&P->block_rows, (size_t)P->n_blocks * 2 * sizeof(int)) == hipSuccess &&
+              hipMalloc(&P->snap, (size_t)P->n_blocks * MJ_LANES * sizeof(TableOne)) == hipSuccess &&
               hipHostMalloc(&P->n_rows_host, 2 * sizeof(int)) == hipSuccess &&
               hipMalloc(&P->counters, 8 * sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
@@ -170,8 +192,11 @@ MjPool* mj_pool_create(int n_tables, int version, int deal_algo, int max_rows) {
         return nullptr;
     }
     hipMemset(P->blocks, 0, (size_t)P->n_blocks * sizeof(TableBlock));
-    size_t lds = (size_t)P->C * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + 69 * 8;
-    hipFuncSetAttribute((const void*)mj_k_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int v = 1; v <= 4; v++) {
+        const void* fn = v == 1 ? (const void*)mj_k_encode<1> : v == 2 ? (const void*)mj_k_encode<2>
+                       : v == 3 ? (const void*)mj_k_encode<3> : (const void*)mj_k_encode<4>;
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_lds_bytes(v));
+    }
     return P;
 }
 
@@ -181,6 +206,8 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->rows[0]);
     hipFree(P->rows[1]);
     hipFree(P->n_rows_dev);
+    hipFree(P->block_rows);
+    hipFree(P->snap);
     if (P->n_rows_host) hipHostFree(P->n_rows_host);
     hipFree(P->counters);
     hipFree(P->final_scores);
@@ -259,16 +286,21 @@ int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
     sp.final_scores = P->final_scores;
     sp.final_done = P->final_done;
     sp.n_games_total = P->n_games_total;
+    sp.block_rows = P->block_rows;
     if (sp.refill) hipLaunchKernelGGL(mj_k_refill, dim3(P->n_blocks), dim3(64), 0, s, sp);
     hipLaunchKernelGGL(mj_k_step, dim3(P->n_blocks), dim3(64), 0, s, sp);
     RowsParams rp;
     rp.blocks = P->blocks;
-    rp.n_tables = P->n_blocks * MJ_LANES;
+    rp.n_blocks = P->n_blocks;
+    rp.block_rows = P->block_rows;
     rp.rows[0] = P->rows[0];
     rp.rows[1] = P->rows[1];
     rp.n_rows_out = P->n_rows_dev;
     rp.max_rows[0] = rp.max_rows[1] = P->max_rows;
-    hipLaunchKernelGGL(mj_k_rows, dim3(1), dim3(1024), 0, s, rp);
+    hipLaunchKernelGGL(mj_k_scan, dim3(1), dim3(1024), 0, s, rp);
+    hipLaunchKernelGGL(mj_k_assign, dim3(P->n_blocks), dim3(64), 0, s, rp);
+    SnapParams snp = {P->blocks, P->snap, g_tables.gather, g_tables.n_gather};
+    hipLaunchKernelGGL(mj_k_snapshot, dim3(P->n_blocks), dim3(256), 0, s, snp);
     HIP_OK(hipMemcpyAsync(P->n_rows_host, P->n_rows_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(hipGetLastError());
     P->cycles += 1;
@@ -303,16 +335,13 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     ep.masks = masks;
     ep.version = P->version;
     ep.C = P->C;
-    ep.gather = g_tables.gather;
-    ep.n_gather = g_tables.n_gather;
+    ep.snap = P->snap;
     ep.decay_lut = g_tables.decay;
     ep.rbf_score = g_tables.rbf_score;
     ep.rbf_6 = g_tables.rbf_6;
     ep.rbf_12 = g_tables.rbf_12;
     ep.rbf_23 = g_tables.rbf_23;
-    ep.with_sp = 0;
-    ep.sp_buf = nullptr;
-    size_t lds = (size_t)P->C * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + 69 * 8;
+    size_t lds = enc_lds_bytes(P->version);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (P->timing) {
@@ -320,7 +349,12 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         HIP_OK(hipEventCreate(&e1));
         HIP_OK(hipEventRecord(e0, s));
     }
-    hipLaunchKernelGGL(mj_k_encode, dim3(n), dim3(ENC_THREADS), lds, s, ep);
+    switch (P->version) {
+        case 1: hipLaunchKernelGGL(mj_k_encode<1>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
+        case 2: hipLaunchKernelGGL(mj_k_encode<2>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
+        case 3: hipLaunchKernelGGL(mj_k_encode<3>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
+        default: hipLaunchKernelGGL(mj_k_encode<4>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
+    }
     if (P->timing) {
         HIP_OK(hipEventRecord(e1, s));
         P->events.push_back({e0, e1});

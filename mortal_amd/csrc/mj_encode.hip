@@ -1,17 +1,21 @@
 // Observation + legal-action-mask encoder (reference: state/obs_repr.rs:126-630, consts.rs:20-28).
 //
-// One workgroup per decision row.  The whole (C,34) f32 plane stack of the row (v4: 137,632 B) is staged in LDS:
-//   1. gather  : the row's table is copied from the field-major pool into a single-table LDS struct with all loads
-//                in flight at once (the pool layout is lane-major, so one table's fields are 64 elements apart);
-//                at the same time the LDS plane stack is zero-filled with 16-byte stores;
-//   2. derive  : unconditional-tenpai discards (agent_helper.rs:100-197) — up to 14x34 shanten probes, spread over
-//                the workgroup;
-//   3. scatter : the few hundred non-zero cells / rows are written into the LDS stack;
-//   4. stream  : LDS -> HBM with 16-byte stores, fully coalesced: exactly the algorithmic bytes reach HBM, once.
-// The 46-byte mask is produced in the same pass.
+// One workgroup (256 threads) per decision row; the (C,34) f32 plane stack (v4: 137,632 B) goes to HBM exactly
+// once, as 16-byte coalesced stores out of an LDS tile:
+//   1. load    : the row's table record (TableOne, written contiguously by mj_k_snapshot) is read into LDS with
+//                16-byte loads;
+//   2. derive  : unconditional-tenpai discards (agent_helper.rs:100-197: up to 14x34 shanten probes + yaku checks)
+//                spread over the workgroup; per-seat scalars (rank, dora counts, kawa lengths) by single lanes;
+//   3. PASSES x { zero a (C/PASSES)-row LDS tile; scatter; stream the tile out }.
+//      The scatter is THREAD-PER-TASK, not row-serial: lane t < 34 owns tile id t, one lane per kawa entry, per meld,
+//      per scalar block — each lane has a short dependency chain and only idempotent or provably unique stores, so
+//      the whole plane stack is decoded in a few hundred cycles of wall time instead of a 1000-load serial chain.
+//      Quarter-size tiles let 4 workgroups share a CU so one group's HBM stores overlap another's gather/scatter.
+// The 46-byte mask is produced in the same pass.  The v4 SP block (rows 889..1011) is written by mj_sp.hip.
 //
-// exp(-0.2 k) (obs_repr.rs:228,266) comes from a host-built LUT (glibc expf == the libm Rust links on Linux) so the
-// decay rows are bit-exact; the RBF rows of v2/v3 (obs_repr.rs:79-90) use a host LUT as well.
+// Row offsets are compile-time per version (Appendix C of SURVEY.md; each total equals consts.rs:22-25).
+// exp(-0.2 k) (obs_repr.rs:228,266) and the v2/v3 RBF rows (obs_repr.rs:79-90) come from host-built LUTs
+// (glibc expf, the libm Rust links on Linux) so those rows are bit-exact as well.
 #include <hip/hip_runtime.h>
 
 #include "mj_rules.h"
@@ -24,22 +28,71 @@ struct EncParams {
     float* obs;            // [n_rows][C][34]
     uint8_t* masks;        // [n_rows][46]
     int version;
-    int C;                 // rows per obs
-    const MjGatherEnt* gather;
-    int n_gather;
+    int C;
+    const TableOne* snap;     // per-table contiguous records written by mj_k_snapshot
     const float* decay_lut;   // [64]  expf(-0.2f * k)
-    // v2/v3 RBF rows (obs_repr.rs:79-90), host-built with the same libm: value[n][i-1] for i in 1..intervals
-    const float* rbf_score;   // [4096][9]  cap 500, 10 intervals, n = score/100 (unclamped, saturated at 4095: all-zero rows)
+    const float* rbf_score;   // [4096][9]  cap 500, 10 intervals, n = score/100 saturated at 4095 (all-zero rows)
     const float* rbf_6;       // [256][2]   cap 6, 3 intervals   (honba, kyotaku)
     const float* rbf_12;      // [256][2]   cap 12, 3 intervals  (doras owned)
     const float* rbf_23;      // [256][3]   cap 23, 4 intervals  (doras unseen)
-    int with_sp;              // v4: 1 = SP rows come from sp_buf, 0 = left zero (caller must know!)
-    const float* sp_buf;
 };
 
 #define ENC_THREADS 256
+#define ENC_PASSES 4
 
-template <class LN> MJD u64 discard_candidates_aka_enc(const LN& L, int s) {  // agent_helper.rs:35-79
+// ---------------------------------------------------------------- static row map
+template <int V>
+struct Lay {
+    static constexpr int hand = 0;
+    static constexpr int akas = 4;
+    static constexpr int scores = 7;
+    static constexpr int score_stride = V == 1 ? 1 : V == 4 ? 2 : 10;
+    static constexpr int rank = scores + 4 * score_stride;
+    static constexpr int kyoku = rank + 4;
+    static constexpr int honba = kyoku + 4;
+    static constexpr int hk_rows = V == 1 ? 10 : V == 4 ? 1 : 2;
+    static constexpr int kyotaku = honba + hk_rows;
+    static constexpr int kaze = kyotaku + hk_rows;
+    static constexpr int kig = kaze + 2;                      // kyoku-in-game (v>=2)
+    static constexpr int dora_ind = kig + (V >= 2 ? 1 : 0);
+    static constexpr int self_kawa = dora_ind + 7;            // 6x4 + 18x4
+    static constexpr int self_decay = self_kawa + 96;         // v>=3
+    static constexpr int opp0 = self_decay + (V >= 3 ? 1 : 0);
+    static constexpr int opp_extra = V == 2 ? 6 : V >= 3 ? 3 : 0;
+    static constexpr int opp_stride = 48 + 144 + opp_extra;
+    static constexpr int tiles_left = opp0 + 3 * opp_stride;
+    static constexpr int doras_owned = tiles_left + 1;
+    static constexpr int owned_stride = V == 1 ? 12 : V == 4 ? 1 : 3;
+    static constexpr int doras_unseen = doras_owned + 4 * owned_stride;
+    static constexpr int kawa_ov = doras_unseen + (V == 1 ? 23 : V == 4 ? 1 : 4);
+    static constexpr int fuuro = kawa_ov + 28;
+    static constexpr int ankan = fuuro + 80;
+    static constexpr int seen = ankan + 4;                    // v>=2: tiles_seen 1 + tedashi 9 + riichi tile 9
+    static constexpr int tedashi = seen + 1;
+    static constexpr int riichi_tile = tedashi + 9;
+    static constexpr int riichi_flags = ankan + 4 + (V >= 2 ? 19 : 0);
+    static constexpr int waits = riichi_flags + 6;
+    static constexpr int furiten = waits + 1;
+    static constexpr int shanten = furiten + 1;
+    static constexpr int self_riichi = shanten + (V == 1 ? 6 : 7);
+    static constexpr int kan_select = self_riichi + 1;
+    static constexpr int target = kan_select + 1;
+    static constexpr int discard = target + 3;
+    static constexpr int cans = discard + 5;                  // riichi, chi x3, pon, daiminkan, ankan, kakan, agari, ryukyoku
+    static constexpr int sp = cans + 10;
+    static constexpr int total = sp + (V == 4 ? 123 : 0);
+};
+static_assert(Lay<1>::total == 938 && Lay<2>::total == 942 && Lay<3>::total == 934 && Lay<4>::total == 1012, "row map");
+
+struct EncDerived {  // per-row scalars computed once in phase 2
+    unsigned long long uncond;   // 37-bit set (raw ids)
+    unsigned long long furiten[34], yaku[34];
+    int klen[4], kpad[4], max_kawa_len;
+    int owned[4], doras_seen, rank;
+    unsigned long long dora_set, dc;  // tiles with dora factor > 0; discard candidates (37-bit)
+};
+
+template <class LN> MJD u64 enc_discard_candidates_aka(const LN& L, int s) {  // agent_helper.rs:35-79
     if (accepted(L, s)) return BIT(F1(last_self_tsumo, s));
     Hand h = load_hand(L, s);
     u64 have = h.nonzero_mask();
@@ -57,47 +110,33 @@ template <class LN> MJD u64 discard_candidates_aka_enc(const LN& L, int s) {  //
     }
     return ret;
 }
+MJD u64 fold37(u64 m) {  // 37-bit raw-id set -> 34-bit deaka'd set
+    return (m & 0x3FFFFFFFFull) | (((m >> 34) & 1) << 4) | (((m >> 35) & 1) << 13) | (((m >> 36) & 1) << 22);
+}
 
+template <int V>
 __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
+    typedef Lay<V> O;
+    constexpr int C = O::total;
+    constexpr int TILE_ROWS = ((C + ENC_PASSES - 1) / ENC_PASSES + 1) & ~1;  // even -> tile bytes % 16 == 0
     extern __shared__ float4 smem4[];
-    float* obs = reinterpret_cast<float*>(smem4);
-    const int C = P.C;
-    const int n_cells = C * 34;
-    // dynamic LDS carve (no static __shared__ in front: the base must stay 16-byte aligned)
-    TableOne* st = reinterpret_cast<TableOne*>(obs + n_cells);
-    unsigned long long* s_furiten = reinterpret_cast<unsigned long long*>(
-        reinterpret_cast<char*>(st) + ((sizeof(TableOne) + 15) & ~(size_t)15));  // [34] any furiten wait per discard
-    unsigned long long* s_yaku = s_furiten + 34;                                   // [34] any live wait with yaku
-    unsigned long long* s_uncond_p = s_yaku + 34;
-#define s_uncond (*s_uncond_p)
+    float* tile = reinterpret_cast<float*>(smem4);
+    TableOne* st = reinterpret_cast<TableOne*>(tile + TILE_ROWS * 34);
+    EncDerived* D = reinterpret_cast<EncDerived*>(reinterpret_cast<char*>(st) + ((sizeof(TableOne) + 15) & ~(size_t)15));
 
     const int tid = threadIdx.x;
     const int row = blockIdx.x;
     const uint32_t desc = P.rows[row];
     const int table = ROW_TABLE(desc), p = ROW_SEAT(desc);
     const bool at_kan_select = ROW_KAN(desc);
-    const int version = P.version;
 
-    // ---- 1. gather + zero
+    // ---- 1. load the table record (contiguous, 16-byte loads)
     {
-        const char* src_base = reinterpret_cast<const char*>(P.blocks + (table >> 6));
-        const int lane = table & 63;
-        char* dst_base = reinterpret_cast<char*>(st);
-        for (int i = tid; i < P.n_gather; i += ENC_THREADS) {
-            MjGatherEnt e = P.gather[i];
-            const char* s = src_base + e.src_off + lane * e.size;
-            char* d = dst_base + e.dst_off;
-            switch (e.size) {
-                case 1: *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s); break;
-                case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
-                case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
-                default: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
-            }
-        }
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < n_cells / 4; i += ENC_THREADS) smem4[i] = z;
-        if (tid < 34) { s_furiten[tid] = 0; s_yaku[tid] = 0; }
-        if (tid == 0) s_uncond = 0;
+        const float4* src = reinterpret_cast<const float4*>(P.snap + table);
+        float4* dst4 = reinterpret_cast<float4*>(st);
+        for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += ENC_THREADS) dst4[i] = src[i];
+        if (tid < 34) { D->furiten[tid] = 0; D->yaku[tid] = 0; }
+        if (tid == 0) D->uncond = 0;
     }
     __syncthreads();
 
@@ -105,27 +144,27 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
     const u32 cans = F1(cans, p);
     const int shanten = F1(shanten, p);
     const int oya_abs = F(kyoku) & 3;
+    const Hand h = load_hand(L, p);
 
-    // ---- 2. unconditional-tenpai discards (agent_helper.rs:100-197), only consulted when shanten <= 1
+    // ---- 2a. unconditional-tenpai discards (agent_helper.rs:100-197); only consulted when shanten <= 1
+    bool uncond_scan = false;
     if ((cans & CAN_DISCARD) && shanten <= 1) {
-        const int tiles_left = F(tiles_left);
         const int lst = F1(last_self_tsumo, p);
-        const u8 pf = F1(pflags, p);
-        Hand h = load_hand(L, p);
         const int ld3 = F1(len_div3, p);
-        bool skip = tiles_left == 0 || (shanten == 1 && !F1(has_next_shanten, p));
-        bool riichi_case = false;
+        bool skip = F(tiles_left) == 0 || (shanten == 1 && !F1(has_next_shanten, p));
         if (!skip) {
             if (lst != MJ_NONE) {
                 if ((F1(waits, p) >> deaka(lst)) & 1) skip = true;
-                else if (accepted(L, p)) { skip = true; riichi_case = true; }
+                else if (accepted(L, p)) {
+                    skip = true;
+                    if (tid == 0 && !(F1(pflags, p) & PF_AT_FURITEN)) D->uncond = BIT(lst);  // raw id
+                }
             } else if (calc_all(P.tables, h, ld3) == -1) {
                 skip = true;
             }
         }
-        if (riichi_case) {
-            if (tid == 0 && !(pf & PF_AT_FURITEN)) s_uncond = BIT(lst);  // 37-bit set, raw id
-        } else if (!skip) {
+        if (!skip) {
+            uncond_scan = true;
             const u64 cand = (shanten == 1 ? F1(next_shanten, p) : F1(keep_shanten, p)) & ~F1(forbidden, p);
             const u64 disc = F1(discarded, p);
             for (int w = tid; w < 34 * 34; w += ENC_THREADS) {
@@ -136,401 +175,361 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                 if (t == d || g.get(t) == 4) continue;
                 g.inc(t);
                 if (calc_all(P.tables, g, ld3) > -1) continue;
-                if ((disc >> t) & 1) atomicOr(&s_furiten[d], 1ull);
-                else if (F1(pub_seen, t) + h.get(t) < 4) {  // tiles_seen[t] != 4 (own hand before the discard)
-                    if (seat_has_yaku(L, p, g, t, true)) atomicOr(&s_yaku[d], 1ull);
+                if ((disc >> t) & 1) atomicOr(&D->furiten[d], 1ull);
+                else if (F1(pub_seen, t) + h.get(t) < 4) {  // tiles_seen (hand before the discard) != 4
+                    if (seat_has_yaku(L, p, g, t, true)) atomicOr(&D->yaku[d], 1ull);
                 }
             }
         }
-        __syncthreads();
-        if (!skip && tid == 0) {
-            const u64 cand = (shanten == 1 ? F1(next_shanten, p) : F1(keep_shanten, p)) & ~F1(forbidden, p);
-            u64 ret = 0;
-            for (int d = 0; d < 34; d++)
-                if (((cand >> d) & 1) && !s_furiten[d] && s_yaku[d]) ret |= BIT(d);
-            const int akas = F1(akas_in_hand, p);
-            for (int k = 0; k < 3; k++) {
-                int t5 = 4 + 9 * k;
-                if (((ret >> t5) & 1) && ((akas >> k) & 1)) {
-                    ret |= BIT(34 + k);
-                    if (!(h.get(t5) > 1)) ret &= ~BIT(t5);
-                }
-            }
-            s_uncond = ret;
-        }
-        __syncthreads();
     }
-
-    // ---- 3. scatter (wave 0; control flow is uniform across the wave)
-    if (tid < 64) {
-        const int lane = tid;
-        auto fill = [&](int r, float v) {
-            if (lane < 34) obs[r * 34 + lane] = v;
-        };
-        auto fill_rows = [&](int r, int n, float v) {
-            for (int k = 0; k < n; k++) fill(r + k, v);
-        };
-        auto assign = [&](int r, int c, float v) {
-            if (lane == 0) obs[r * 34 + c] = v;
-        };
-        auto int_encode = [&](int& idx, u32 n_in, int cap, bool one_hot, bool rescale, int rbf, const float* lut) {
-            // obs_repr.rs:59-107
-            int n = (int)min(n_in, (u32)cap);
-            if (version == 1) {
-                fill_rows(idx, n, 1.f);
-                idx += cap;
-                return;
-            }
-            if (one_hot) {
-                fill(idx + n, 1.f);
-                idx += cap + 1;
-            }
-            if (rescale) {
-                fill(idx, (float)n / (float)cap);
-                idx += 1;
-            }
-            if (version != 4 && rbf) {
-                for (int i = 1; i < rbf; i++) fill(idx + i - 1, lut[i - 1]);
-                idx += rbf - 1;
-            }
-        };
-        u8* mask = P.masks + (size_t)row * 46;
-        u64 mask_bits = 0;
-        int idx = 0;
-        Hand h = load_hand(L, p);
-        // dora factor table for this kyoku (derived)
-        int n_ind = F(n_dora_ind);
-        u64 dora_set = 0;  // tiles with factor > 0
-        for (int i = 0; i < n_ind; i++) dora_set |= BIT(tile_next(F1(dora_ind, i)));
-
-        // hand thermometer (4) + akas (3)
-        if (lane < 34) {
-            int c = h.get(lane);
-            for (int k = 0; k < c; k++) obs[(idx + k) * 34 + lane] = 1.f;
-        }
-        idx += 4;
-        {
-            int akas = F1(akas_in_hand, p);
-            for (int i = 0; i < 3; i++)
-                if ((akas >> i) & 1) fill(idx + i, 1.f);
-        }
-        idx += 3;
-        // scores (rotated to the seat's perspective)
-        int sc[4];
-        for (int i = 0; i < 4; i++) sc[i] = F1(scores, (p + i) & 3);
-        for (int i = 0; i < 4; i++) {
-            int s = sc[i];
-            fill(idx, (float)min(max(s, 0), 100000) / 100000.f);
-            idx += 1;
-            if (version == 2 || version == 3) {
-                // IntegerEncoder(score as usize / 100, cap 500).rbf_intervals(10): 9 rows from the host LUT
-                u32 n = (u32)(((unsigned long long)(long long)s) / 100ull > 4095ull ? 4095u : (u32)(((unsigned long long)(long long)s) / 100ull));
-                int_encode(idx, n, 500, false, false, 10, P.rbf_score + (size_t)n * 9);
-            } else if (version == 4) {
-                fill(idx, (float)min(max(s, 0), 30000) / 30000.f);
-                idx += 1;
-            }
-        }
-        // rank (rankings.rs:8-21: stable sort by -score => ties favour the lower ABSOLUTE seat)
-        {
-            int my = F1(scores, p), rank = 0;
-            for (int a = 0; a < 4; a++) {
-                int s = F1(scores, a);
-                if (s > my || (s == my && a < p)) rank++;
-            }
-            fill(idx + rank, 1.f);
-        }
-        idx += 4;
-        const int kyoku_in_wind = F(kyoku) & 3;
-        if (version == 1) fill_rows(idx, kyoku_in_wind, 1.f);
-        else fill(idx + kyoku_in_wind, 1.f);
-        idx += 4;
-        {
-            int cap = (version == 1 || version == 4) ? 10 : 6;
-            int_encode(idx, F(honba), cap, false, version == 4, 3, P.rbf_6 + (size_t)F(honba) * 2);
-            int_encode(idx, F(kyotaku), cap, false, version == 4, 3, P.rbf_6 + (size_t)F(kyotaku) * 2);
-        }
-        const int bakaze = table_bakaze(L), jikaze = seat_jikaze(L, p);
-        assign(idx, bakaze, 1.f);
-        assign(idx + 1, jikaze, 1.f);
-        idx += 2;
-        if (version >= 2) {
-            int n = min(bakaze - T_E, 1) * 4 + kyoku_in_wind;
-            int_encode(idx, n, 7, false, true, 0, nullptr);
-        }
-        // dora indicators (tile set, 7 rows)  obs_repr.rs:694-712
-        {
-            for (int i = 0; i < n_ind; i++) {
-                int t = F1(dora_ind, i), td = deaka(t), k = 0;
-                for (int j = 0; j < i; j++) k += deaka(F1(dora_ind, j)) == td;
-                assign(idx + k, td, 1.f);
-                if (is_aka(t)) fill(idx + 4 + (t - T_5MR), 1.f);
-            }
-            idx += 7;
-        }
-        // ---- kawa.  Perspective list of abs seat a = [None if (a-p)&3 < (oya-p)&3] ++ pool kawa[a]  (update.rs:819-824)
-        int klen[4], kpad[4], max_kawa_len = 0;
+    // ---- 2b. per-seat scalars, one lane each
+    if (tid == 64) {
+        int mx = 0;
         for (int r = 0; r < 4; r++) {
             int a = (p + r) & 3;
-            kpad[r] = r < ((oya_abs - p) & 3) ? 1 : 0;
-            klen[r] = kpad[r] + F1(kawa_len, a);
-            max_kawa_len = max(max_kawa_len, klen[r]);
+            int pad = r < ((oya_abs - p) & 3) ? 1 : 0;  // pad_kawa_at_start seen from seat p (update.rs:819-824)
+            int len = pad + F1(kawa_len, a);
+            D->kpad[r] = pad;
+            D->klen[r] = len;
+            mx = max(mx, len);
         }
-        auto kawa_item = [&](int r, int i) -> u64 {  // i-th entry of relative seat r's list
-            int j = i - kpad[r];
-            return j < 0 ? 0ull : F2(kawa, (p + r) & 3, j);
-        };
-        auto enc_self_kawa = [&](u64 e, int base) {  // obs_repr.rs:714-734
-            if (e & KW_VALID) {
-                int nk = KW_NKAN(e);
-                for (int k = 0; k < nk; k++) assign(base, deaka(KW_KAN(e, k)), 1.f);
-                int t = KW_TILE(e);
-                assign(base + 1, deaka(t), 1.f);
-                if (is_aka(t)) fill(base + 2, 1.f);
-                if (KW_DORA(e)) fill(base + 3, 1.f);
-            }
-        };
-        auto enc_kawa = [&](u64 e, int base) {  // obs_repr.rs:736-773
-            if (e & KW_VALID) {
-                if (KW_HAS_CP(e)) {
-                    assign(base, KW_CP_MIN(e), 1.f);
-                    assign(base + 1, KW_CP_MAX(e), 1.f);
-                }
-                int nk = KW_NKAN(e);
-                for (int k = 0; k < nk; k++) assign(base + 2, deaka(KW_KAN(e, k)), 1.f);
-                int t = KW_TILE(e);
-                assign(base + 3, deaka(t), 1.f);
-                if (is_aka(t)) fill(base + 4, 1.f);
-                if (KW_DORA(e)) fill(base + 5, 1.f);
-                if (KW_TEDASHI(e)) fill(base + 6, 1.f);
-                if (KW_RIICHI(e)) fill(base + 7, 1.f);
-            }
-        };
-        {
-            int n = min(klen[0], 6);
-            for (int i = 0; i < n; i++) enc_self_kawa(kawa_item(0, i), idx + i * 4);
-            idx += 24;
-            n = min(klen[0], 18);
-            for (int i = 0; i < n; i++) enc_self_kawa(kawa_item(0, klen[0] - 1 - i), idx + i * 4);
-            idx += 72;
-            if (version >= 3) {
-                for (int turn = 0; turn < klen[0]; turn++) {
-                    u64 e = kawa_item(0, turn);
-                    if (e & KW_VALID) assign(idx, deaka(KW_TILE(e)), P.decay_lut[max_kawa_len - 1 - turn]);
-                }
-                idx += 1;
-            }
+        D->max_kawa_len = mx;
+        int my = F1(scores, p), rank = 0;  // rankings.rs:8-21: stable sort by -score, ties -> lower absolute seat
+        for (int a = 0; a < 4; a++) {
+            int s = F1(scores, a);
+            if (s > my || (s == my && a < p)) rank++;
         }
-        for (int r = 1; r < 4; r++) {
-            int n = min(klen[r], 6);
-            for (int i = 0; i < n; i++) enc_kawa(kawa_item(r, i), idx + i * 8);
-            idx += 48;
-            n = min(klen[r], 18);
-            for (int i = 0; i < n; i++) enc_kawa(kawa_item(r, klen[r] - 1 - i), idx + i * 8);
-            idx += 144;
-            if (version == 2) {
-                int turn = 0;
-                for (int i = 0; i < klen[r]; i++) {
-                    u64 e = kawa_item(r, i);
-                    if (!(e & KW_VALID)) continue;
-                    int rr = min(turn / 6, 2), td = deaka(KW_TILE(e));
-                    assign(idx + rr, td, 1.f);
-                    if (KW_TEDASHI(e)) assign(idx + 3 + rr, td, 1.f);
-                    turn++;
-                }
-                idx += 6;
-            } else if (version >= 3) {
-                for (int turn = 0; turn < klen[r]; turn++) {
-                    u64 e = kawa_item(r, turn);
-                    if (!(e & KW_VALID)) continue;
-                    int td = deaka(KW_TILE(e));
-                    float v = P.decay_lut[max_kawa_len - 1 - turn];
-                    assign(idx, td, v);
-                    if (KW_TEDASHI(e)) assign(idx + 1, td, v);
-                    if (KW_RIICHI(e)) assign(idx + 2, td, v);
-                }
-                idx += 3;
+        D->rank = rank;
+        D->dc = (cans & CAN_DISCARD) ? enc_discard_candidates_aka(L, p) : 0ull;
+    }
+    if (tid >= 65 && tid < 69) {  // doras_owned[r] (derived: melds of seat a; + own hand for r == 0)
+        int r = tid - 65, a = (p + r) & 3, owned = 0;
+        int nf = F1(fuuro_n, a);
+        for (int k = 0; k < nf; k++)
+            for (int j = 0; j < 4; j++) {
+                int t = F3(fuuro, a, k, j);
+                if (t != MJ_NONE) owned += dora_factor(L, deaka(t)) + (is_aka(t) ? 1 : 0);
+            }
+        int na = F1(ankan_n, a);
+        for (int k = 0; k < na; k++) {
+            int t = F2(ankan, a, k);
+            owned += 4 * dora_factor(L, t) + ((t == T_5M || t == T_5P || t == T_5S) ? 1 : 0);
+        }
+        if (r == 0) {
+            owned += __popc(F1(akas_in_hand, p) & 7);
+            int n = F(n_dora_ind);
+            for (int i = 0; i < n; i++) owned += h.get(tile_next(F1(dora_ind, i)));
+        }
+        D->owned[r] = owned & 0xFF;
+    }
+    if (tid == 69) {  // doras_seen = sum(tiles_seen x factor) + akas seen; dora_set
+        int n = F(n_dora_ind), seen = __popc((F(pub_aka_seen) | F1(akas_in_hand, p)) & 7);
+        u64 ds = 0;
+        for (int i = 0; i < n; i++) {
+            int d = tile_next(F1(dora_ind, i));
+            ds |= BIT(d);
+            seen += F1(pub_seen, d) + h.get(d);
+        }
+        D->doras_seen = seen;
+        D->dora_set = ds;
+    }
+    __syncthreads();
+    if (uncond_scan && tid == 0) {
+        const u64 cand = (shanten == 1 ? F1(next_shanten, p) : F1(keep_shanten, p)) & ~F1(forbidden, p);
+        u64 ret = 0;
+        for (int d = 0; d < 34; d++)
+            if (((cand >> d) & 1) && !D->furiten[d] && D->yaku[d]) ret |= BIT(d);
+        const int akas = F1(akas_in_hand, p);
+        for (int k = 0; k < 3; k++) {
+            int t5 = 4 + 9 * k;
+            if (((ret >> t5) & 1) && ((akas >> k) & 1)) {
+                ret |= BIT(34 + k);
+                if (!(h.get(t5) > 1)) ret &= ~BIT(t5);
             }
         }
-        fill(idx, (float)F(tiles_left) / 69.f);
-        idx += 1;
+        D->uncond = ret;
+    }
+    __syncthreads();
 
-        // doras_owned[rel] / doras_seen (derived; update.rs:733-808,955-960)
-        int akas_seen_n = __popc((int)(F(pub_aka_seen) | F1(akas_in_hand, p)) & 7);
-        int doras_seen = akas_seen_n;
-        for (int t = 0; t < 34; t++)
-            if ((dora_set >> t) & 1) doras_seen += dora_factor(L, t) * (F1(pub_seen, t) + h.get(t));
-        for (int r = 0; r < 4; r++) {
-            int a = (p + r) & 3, owned = 0;
-            int nf = F1(fuuro_n, a);
-            for (int k = 0; k < nf; k++)
-                for (int j = 0; j < 4; j++) {
-                    int t = F3(fuuro, a, k, j);
-                    if (t == MJ_NONE) continue;
-                    owned += dora_factor(L, deaka(t)) + (is_aka(t) ? 1 : 0);
-                }
-            int na = F1(ankan_n, a);
-            for (int k = 0; k < na; k++) {
-                int t = F2(ankan, a, k);
-                owned += 4 * dora_factor(L, t) + ((t == T_5M || t == T_5P || t == T_5S) ? 1 : 0);
-            }
-            if (r == 0) {
-                owned += __popc(F1(akas_in_hand, p) & 7);
-                for (int t = 0; t < 34; t++)
-                    if ((dora_set >> t) & 1) owned += dora_factor(L, t) * h.get(t);
-            }
-            int_encode(idx, (u32)(owned & 0xFF), 12, false, true, 3, P.rbf_12 + (size_t)(owned & 0xFF) * 2);
-        }
+    const int klen_all[4] = {D->klen[0], D->klen[1], D->klen[2], D->klen[3]};
+    const int max_kawa_len = D->max_kawa_len;
+    const u64 dora_set = D->dora_set;
+
+    // ---- 3. passes
+    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)row * (C * 34));
+    for (int pass = 0; pass < ENC_PASSES; pass++) {
+        const int r0 = pass * TILE_ROWS, r1 = min(C, r0 + TILE_ROWS);
+        if (r0 >= C) break;
         {
-            u32 unseen = (u32)((n_ind * 4 + 3 - doras_seen) & 0xFF);
-            int_encode(idx, unseen, 23, false, true, 4, P.rbf_23 + (size_t)unseen * 3);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = tid; i < TILE_ROWS * 34 / 4; i += ENC_THREADS) smem4[i] = z;
         }
-        // kawa_overview: the Some() entries of each kawa (tile sets, 4 x 7 rows)
-        for (int r = 0; r < 4; r++) {
-            int a = (p + r) & 3, n = F1(kawa_len, a);
-            u64 c0 = 0, c1 = 0;  // 2-bit occurrence counter per tile id, bit-sliced over the 34 ids
+        __syncthreads();
+        auto put = [&](int r, int c, float v) {
+            if (r >= r0 && r < r1) tile[(r - r0) * 34 + c] = v;
+        };
+        auto fillr = [&](int r, float v) {
+            if (r >= r0 && r < r1) {
+                float* q = tile + (r - r0) * 34;
+#pragma unroll
+                for (int c = 0; c < 34; c++) q[c] = v;
+            }
+        };
+        // obs_repr.rs:59-107 for one integer feature at row base `b`
+        auto int_encode = [&](int b, u32 n_in, int cap, bool rescale, int rbf, const float* lut) {
+            int n = (int)min(n_in, (u32)cap);
+            if (V == 1) {
+                for (int k = 0; k < n; k++) fillr(b + k, 1.f);
+                return;
+            }
+            if (rescale) {
+                fillr(b, (float)n / (float)cap);
+                b += 1;
+            }
+            if (V != 4 && rbf)
+                for (int i = 1; i < rbf; i++) fillr(b + i - 1, lut[i - 1]);
+        };
+
+        if (tid < 34) {
+            // ---- A. lane == tile id
+            const int t = tid;
+            const int c = h.get(t);
+            for (int k = 0; k < c; k++) put(O::hand + k, t, 1.f);
+            if (V >= 2) put(O::seen, t, (float)(F1(pub_seen, t) + c) / 4.f);
+            if ((F1(waits, p) >> t) & 1) put(O::waits, t, 1.f);
+            if (cans & CAN_DISCARD) {
+                if ((fold37(D->dc) >> t) & 1) put(O::discard, t, 1.f);
+                if ((F1(keep_shanten, p) >> t) & 1) put(O::discard + 1, t, 1.f);
+                if ((F1(next_shanten, p) >> t) & 1) put(O::discard + 2, t, 1.f);
+                if (shanten <= 1 && ((fold37(D->uncond) >> t) & 1)) put(O::discard + 3, t, 1.f);
+            }
+            if ((cans & CAN_ANKAN) && ((F1(ankan_cand, p) >> t) & 1)) put(O::cans + 6, t, 1.f);
+            if ((cans & CAN_KAKAN) && ((F1(kakan_cand, p) >> t) & 1)) put(O::cans + 7, t, 1.f);
+        } else if (tid < 38) {
+            // ---- B. scores (rotated)
+            const int i = tid - 34;
+            const int s = F1(scores, (p + i) & 3);
+            const int b = O::scores + i * O::score_stride;
+            fillr(b, (float)min(max(s, 0), 100000) / 100000.f);
+            if (V == 2 || V == 3) {
+                unsigned long long q = (unsigned long long)(long long)s / 100ull;  // `score as usize / 100`
+                u32 n = q > 4095ull ? 4095u : (u32)q;
+                int_encode(b + 1, n, 500, false, 10, P.rbf_score + (size_t)n * 9);
+            } else if (V == 4) {
+                fillr(b + 1, (float)min(max(s, 0), 30000) / 30000.f);
+            }
+        } else if (tid == 38) {
+            const int akas = F1(akas_in_hand, p);
+            for (int i = 0; i < 3; i++)
+                if ((akas >> i) & 1) fillr(O::akas + i, 1.f);
+            fillr(O::rank + D->rank, 1.f);
+            const int kw = F(kyoku) & 3;
+            if (V == 1) {
+                for (int k = 0; k < kw; k++) fillr(O::kyoku + k, 1.f);
+            } else {
+                fillr(O::kyoku + kw, 1.f);
+            }
+            const int cap = (V == 1 || V == 4) ? 10 : 6;
+            int_encode(O::honba, F(honba), cap, V == 4, 3, P.rbf_6 + (size_t)F(honba) * 2);
+            int_encode(O::kyotaku, F(kyotaku), cap, V == 4, 3, P.rbf_6 + (size_t)F(kyotaku) * 2);
+            const int bakaze = table_bakaze(L);
+            put(O::kaze, bakaze, 1.f);
+            put(O::kaze + 1, seat_jikaze(L, p), 1.f);
+            if (V >= 2) int_encode(O::kig, min(bakaze - T_E, 1) * 4 + kw, 7, true, 0, nullptr);
+        } else if (tid == 39) {
+            // dora indicators tile set (obs_repr.rs:694-712) + tiles_left
+            const int n = F(n_dora_ind);
+            for (int i = 0; i < n; i++) {
+                int t = F1(dora_ind, i), td = deaka(t), k = 0;
+                for (int j = 0; j < i; j++) k += deaka(F1(dora_ind, j)) == td;
+                put(O::dora_ind + k, td, 1.f);
+                if (is_aka(t)) fillr(O::dora_ind + 4 + (t - T_5MR), 1.f);
+            }
+            fillr(O::tiles_left, (float)F(tiles_left) / 69.f);
+        } else if (tid < 44) {
+            const int r = tid - 40;
+            const int ow = D->owned[r];
+            int_encode(O::doras_owned + r * O::owned_stride, (u32)ow, 12, true, 3, P.rbf_12 + (size_t)ow * 2);
+        } else if (tid == 44) {
+            const u32 unseen = (u32)((F(n_dora_ind) * 4 + 3 - D->doras_seen) & 0xFF);
+            int_encode(O::doras_unseen, unseen, 23, true, 4, P.rbf_23 + (size_t)unseen * 3);
+        } else if (tid == 45) {
+            for (int r = 1; r < 4; r++) {
+                if (declared(L, (p + r) & 3)) fillr(O::riichi_flags + r - 1, 1.f);
+                if (accepted(L, (p + r) & 3)) fillr(O::riichi_flags + 3 + r - 1, 1.f);
+            }
+            if (F1(pflags, p) & PF_AT_FURITEN) fillr(O::furiten, 1.f);
+            if (V == 1) {
+                for (int k = 0; k < min(shanten, 6); k++) fillr(O::shanten + k, 1.f);
+            } else {
+                fillr(O::shanten + min(shanten, 6), 1.f);
+            }
+            if (accepted(L, p)) fillr(O::self_riichi, 1.f);
+            if (at_kan_select) fillr(O::kan_select, 1.f);
+        } else if (tid == 46) {
+            if (cans & CAN_PASS) {  // target tile (obs_repr.rs:408-429)
+                int t = F1(last_kawa_tile, p), td = deaka(t);
+                put(O::target, td, 1.f);
+                if (is_aka(t)) fillr(O::target + 1, 1.f);
+                if ((dora_set >> td) & 1) fillr(O::target + 2, 1.f);
+            }
+            if ((cans & CAN_DISCARD) && declared(L, p)) fillr(O::discard + 4, 1.f);
+        } else if (tid == 47) {
+            if (cans & CAN_RIICHI) fillr(O::cans + 0, 1.f);
+            if (cans & CAN_CHI_LOW) fillr(O::cans + 1, 1.f);
+            if (cans & CAN_CHI_MID) fillr(O::cans + 2, 1.f);
+            if (cans & CAN_CHI_HIGH) fillr(O::cans + 3, 1.f);
+            if (cans & CAN_PON) fillr(O::cans + 4, 1.f);
+            if (cans & CAN_DAIMINKAN) fillr(O::cans + 5, 1.f);
+            if (cans & CAN_AGARI) fillr(O::cans + 8, 1.f);
+            if (cans & CAN_RYUKYOKU) fillr(O::cans + 9, 1.f);
+        } else if (tid == 48) {
+            if (pass == 0) {  // mask (obs_repr.rs:422-562)
+                u64 m = 0;
+                if (!at_kan_select) {
+                    if (cans & CAN_PASS) m |= BIT(45);
+                    if (cans & CAN_DISCARD) m |= D->dc & 0x1FFFFFFFFFull;
+                    if (cans & CAN_RIICHI) m |= BIT(37);
+                    if (cans & CAN_CHI_LOW) m |= BIT(38);
+                    if (cans & CAN_CHI_MID) m |= BIT(39);
+                    if (cans & CAN_CHI_HIGH) m |= BIT(40);
+                    if (cans & CAN_PON) m |= BIT(41);
+                    if (cans & CAN_KAN) m |= BIT(42);
+                    if (cans & CAN_AGARI) m |= BIT(43);
+                    if (cans & CAN_RYUKYOKU) m |= BIT(44);
+                } else {
+                    if ((cans & CAN_PASS) && (cans & CAN_DAIMINKAN)) m |= BIT(deaka(F1(last_kawa_tile, p)));
+                    if (cans & CAN_ANKAN) m |= F1(ankan_cand, p);
+                    if (cans & CAN_KAKAN) m |= F1(kakan_cand, p);
+                }
+                u8* mask = P.masks + (size_t)row * 46;
+                for (int i = 0; i < 46; i++) mask[i] = (u8)((m >> i) & 1);
+            }
+        } else if (tid < 55) {
+            if (V >= 2) {  // last tedashi / riichi tile of the three opponents (obs_repr.rs:337-367)
+                const int k = tid - 49, r = 1 + k % 3;
+                const int a = (p + r) & 3;
+                const int su = k < 3 ? F1(last_tedashi, a) : F1(riichi_sutehai, a);
+                const int b = (k < 3 ? O::tedashi : O::riichi_tile) + (r - 1) * 3;
+                if (su & SU_VALID) {
+                    int t = su & 63;
+                    put(b, deaka(t), 1.f);
+                    if (is_aka(t)) fillr(b + 1, 1.f);
+                    if (su & SU_DORA) fillr(b + 2, 1.f);
+                }
+            }
+        } else if (tid >= 56 && tid < 60) {
+            // kawa_overview = the Some() entries of a kawa, as a tile set (obs_repr.rs:299-301)
+            const int r = tid - 56, a = (p + r) & 3, n = F1(kawa_len, a);
+            const int b = O::kawa_ov + r * 7;
+            u64 c0 = 0, c1 = 0;  // 2-bit occurrence counter per tile id, bit-sliced
             for (int i = 0; i < n; i++) {
                 u64 e = F2(kawa, a, i);
                 if (!(e & KW_VALID)) continue;
                 int t = KW_TILE(e), td = deaka(t);
                 int k = (int)((c0 >> td) & 1) + 2 * (int)((c1 >> td) & 1);
-                assign(idx + k, td, 1.f);
-                u64 b = BIT(td), carry = c0 & b;
-                c0 ^= b;
+                put(b + k, td, 1.f);
+                u64 bt = BIT(td), carry = c0 & bt;
+                c0 ^= bt;
                 c1 ^= carry;
-                if (is_aka(t)) fill(idx + 4 + (t - T_5MR), 1.f);
+                if (is_aka(t)) fillr(b + 4 + (t - T_5MR), 1.f);
             }
-            idx += 7;
-        }
-        // fuuro_overview 4 x 4 x 5 (obs_repr.rs:303-321): row = #same tile earlier in the set
-        for (int r = 0; r < 4; r++) {
-            int a = (p + r) & 3, nf = F1(fuuro_n, a);
-            for (int k = 0; k < nf; k++) {
+        } else if (tid >= 60 && tid < 64) {
+            const int r = tid - 60, a = (p + r) & 3, na = F1(ankan_n, a);
+            for (int k = 0; k < na; k++) put(O::ankan + r, F2(ankan, a, k), 1.f);
+        } else if (tid >= 64 && tid < 80) {
+            // ---- C. fuuro sets (obs_repr.rs:303-321): row = #same tile earlier in the set
+            const int r = (tid - 64) >> 2, k = (tid - 64) & 3, a = (p + r) & 3;
+            if (k < F1(fuuro_n, a)) {
+                const int b = O::fuuro + (r * 4 + k) * 5;
+                int tl[4];
+                for (int j = 0; j < 4; j++) tl[j] = F3(fuuro, a, k, j);
                 for (int j = 0; j < 4; j++) {
-                    int t = F3(fuuro, a, k, j);
-                    if (t == MJ_NONE) continue;
-                    int td = deaka(t), i = 0;
-                    for (int q = 0; q < j; q++) {
-                        int u = F3(fuuro, a, k, q);
-                        i += u != MJ_NONE && deaka(u) == td;
-                    }
-                    assign(idx + i, td, 1.f);
-                    if (is_aka(t)) fill(idx + 4, 1.f);
+                    if (tl[j] == MJ_NONE) continue;
+                    int td = deaka(tl[j]), i = 0;
+                    for (int q = 0; q < j; q++) i += tl[q] != MJ_NONE && deaka(tl[q]) == td;
+                    put(b + i, td, 1.f);
+                    if (is_aka(tl[j])) fillr(b + 4, 1.f);
                 }
-                idx += 5;
             }
-            idx += (4 - nf) * 5;
-        }
-        for (int r = 0; r < 4; r++) {
-            int a = (p + r) & 3, na = F1(ankan_n, a);
-            for (int k = 0; k < na; k++) assign(idx, F2(ankan, a, k), 1.f);
-            idx += 1;
-        }
-        if (version >= 2) {
-            if (lane < 34) obs[idx * 34 + lane] = (float)(F1(pub_seen, lane) + h.get(lane)) / 4.f;
-            idx += 1;
-            for (int pass = 0; pass < 2; pass++)
-                for (int r = 1; r < 4; r++) {
-                    int a = (p + r) & 3;
-                    int su = pass == 0 ? F1(last_tedashi, a) : F1(riichi_sutehai, a);
-                    if (su & SU_VALID) {
-                        int t = su & 63;
-                        assign(idx, deaka(t), 1.f);
-                        if (is_aka(t)) fill(idx + 1, 1.f);
-                        if (su & SU_DORA) fill(idx + 2, 1.f);
+        } else if (tid < 80 + 4 * MJ_KAWA_MAX + 4) {
+            // ---- D. one lane per kawa entry of the perspective lists (r = relative seat, i = index incl. start pad)
+            const int q = tid - 80;
+            const int r = q / (MJ_KAWA_MAX + 1), i = q % (MJ_KAWA_MAX + 1);
+            const int len = klen_all[r];
+            if (i < len) {
+                const int a = (p + r) & 3, pad = D->kpad[r];
+                const u64 e = i < pad ? 0ull : F2(kawa, a, i - pad);
+                if (e & KW_VALID) {
+                    const int t = KW_TILE(e), td = deaka(t);
+                    const int nk = KW_NKAN(e);
+                    // slots: first six, last eighteen
+                    int slots[2], ns = 0;
+                    if (r == 0) {
+                        if (i < 6) slots[ns++] = O::self_kawa + i * 4;
+                        if (len - 1 - i < 18) slots[ns++] = O::self_kawa + 24 + (len - 1 - i) * 4;
+                        for (int s = 0; s < ns; s++) {  // obs_repr.rs:714-734
+                            const int b = slots[s];
+                            for (int k = 0; k < nk; k++) put(b, deaka(KW_KAN(e, k)), 1.f);
+                            put(b + 1, td, 1.f);
+                            if (is_aka(t)) fillr(b + 2, 1.f);
+                            if (KW_DORA(e)) fillr(b + 3, 1.f);
+                        }
+                    } else {
+                        const int ob = O::opp0 + (r - 1) * O::opp_stride;
+                        if (i < 6) slots[ns++] = ob + i * 8;
+                        if (len - 1 - i < 18) slots[ns++] = ob + 48 + (len - 1 - i) * 8;
+                        for (int s = 0; s < ns; s++) {  // obs_repr.rs:736-773
+                            const int b = slots[s];
+                            if (KW_HAS_CP(e)) {
+                                put(b, KW_CP_MIN(e), 1.f);
+                                put(b + 1, KW_CP_MAX(e), 1.f);
+                            }
+                            for (int k = 0; k < nk; k++) put(b + 2, deaka(KW_KAN(e, k)), 1.f);
+                            put(b + 3, td, 1.f);
+                            if (is_aka(t)) fillr(b + 4, 1.f);
+                            if (KW_DORA(e)) fillr(b + 5, 1.f);
+                            if (KW_TEDASHI(e)) fillr(b + 6, 1.f);
+                            if (KW_RIICHI(e)) fillr(b + 7, 1.f);
+                        }
                     }
-                    idx += 3;
+                    if (V >= 3) {
+                        // decay rows (obs_repr.rs:223-233,259-276): sequential assigns in the reference, so the LAST
+                        // entry holding a tile (resp. the last tedashi / riichi one) owns the cell.
+                        bool later_any = false, later_ted = false, later_rii = false;
+                        for (int j = i + 1; j < len; j++) {
+                            u64 f = F2(kawa, a, j - pad);
+                            if ((f & KW_VALID) && deaka(KW_TILE(f)) == td) {
+                                later_any = true;
+                                later_ted |= KW_TEDASHI(f) != 0;
+                                later_rii |= KW_RIICHI(f) != 0;
+                            }
+                        }
+                        const float v = P.decay_lut[max_kawa_len - 1 - i];
+                        if (r == 0) {
+                            if (!later_any) put(O::self_decay, td, v);
+                        } else {
+                            const int b = O::opp0 + (r - 1) * O::opp_stride + 192;
+                            if (!later_any) put(b, td, v);
+                            if (KW_TEDASHI(e) && !later_ted) put(b + 1, td, v);
+                            if (KW_RIICHI(e) && !later_rii) put(b + 2, td, v);
+                        }
+                    } else if (V == 2 && r > 0) {
+                        int turn = 0;  // index among the Some() entries (obs_repr.rs:251-258)
+                        for (int j = pad; j < i; j++) turn += (F2(kawa, a, j - pad) & KW_VALID) != 0;
+                        const int b = O::opp0 + (r - 1) * O::opp_stride + 192, rr = min(turn / 6, 2);
+                        put(b + rr, td, 1.f);
+                        if (KW_TEDASHI(e)) put(b + 3 + rr, td, 1.f);
+                    }
                 }
+            }
         }
-        for (int r = 1; r < 4; r++)
-            if (declared(L, (p + r) & 3)) fill(idx + r - 1, 1.f);
-        idx += 3;
-        for (int r = 1; r < 4; r++)
-            if (accepted(L, (p + r) & 3)) fill(idx + r - 1, 1.f);
-        idx += 3;
+        __syncthreads();
         {
-            u64 w = F1(waits, p);
-            if (lane < 34 && ((w >> lane) & 1)) obs[idx * 34 + lane] = 1.f;
-            idx += 1;
+            const int n4 = (r1 - r0) * 34 / 4;  // (r1-r0) is even except possibly the very last chunk
+            float4* d4 = dst + (size_t)r0 * 34 / 4;
+            for (int i = tid; i < n4; i += ENC_THREADS) d4[i] = smem4[i];
         }
-        if (F1(pflags, p) & PF_AT_FURITEN) fill(idx, 1.f);
-        idx += 1;
-        if (version == 1) {
-            fill_rows(idx, min(shanten, 6), 1.f);
-            idx += 6;
-        } else {
-            fill(idx + min(shanten, 6), 1.f);
-            idx += 7;
-        }
-        if (accepted(L, p)) fill(idx, 1.f);
-        idx += 1;
-        if (at_kan_select) fill(idx, 1.f);
-        idx += 1;
-
-        if (cans & CAN_PASS) {
-            int t = F1(last_kawa_tile, p), td = deaka(t);
-            assign(idx, td, 1.f);
-            if (is_aka(t)) fill(idx + 1, 1.f);
-            if ((dora_set >> td) & 1) fill(idx + 2, 1.f);
-            if (!at_kan_select) mask_bits |= BIT(45);
-            else if (cans & CAN_DAIMINKAN) mask_bits |= BIT(td);
-        }
-        idx += 3;
-        if (cans & CAN_DISCARD) {
-            u64 dc = discard_candidates_aka_enc(L, p);
-            u64 dc34 = (dc & 0x3FFFFFFFFull) | (((dc >> 34) & 1) << 4) | (((dc >> 35) & 1) << 13) | (((dc >> 36) & 1) << 22);
-            if (lane < 34 && ((dc34 >> lane) & 1)) obs[idx * 34 + lane] = 1.f;
-            if (!at_kan_select) mask_bits |= dc & 0x1FFFFFFFFFull;
-            u64 ks = F1(keep_shanten, p), ns = F1(next_shanten, p);
-            if (lane < 34 && ((ks >> lane) & 1)) obs[(idx + 1) * 34 + lane] = 1.f;
-            if (lane < 34 && ((ns >> lane) & 1)) obs[(idx + 2) * 34 + lane] = 1.f;
-            if (shanten <= 1) {
-                u64 u = s_uncond;
-                u64 u34 = (u & 0x3FFFFFFFFull) | (((u >> 34) & 1) << 4) | (((u >> 35) & 1) << 13) | (((u >> 36) & 1) << 22);
-                if (lane < 34 && ((u34 >> lane) & 1)) obs[(idx + 3) * 34 + lane] = 1.f;
-            }
-            if (declared(L, p)) fill(idx + 4, 1.f);
-        }
-        idx += 5;
-        auto flag_row = [&](u32 bit, int action) {
-            if (cans & bit) {
-                fill(idx, 1.f);
-                if (!at_kan_select) mask_bits |= BIT(action);
-            }
-            idx += 1;
-        };
-        flag_row(CAN_RIICHI, 37);
-        flag_row(CAN_CHI_LOW, 38);
-        flag_row(CAN_CHI_MID, 39);
-        flag_row(CAN_CHI_HIGH, 40);
-        flag_row(CAN_PON, 41);
-        flag_row(CAN_DAIMINKAN, 42);
-        if (cans & CAN_ANKAN) {
-            u64 c = F1(ankan_cand, p);
-            if (lane < 34 && ((c >> lane) & 1)) obs[idx * 34 + lane] = 1.f;
-            if (at_kan_select) mask_bits |= c;
-            else mask_bits |= BIT(42);
-        }
-        idx += 1;
-        if (cans & CAN_KAKAN) {
-            u64 c = F1(kakan_cand, p);
-            if (lane < 34 && ((c >> lane) & 1)) obs[idx * 34 + lane] = 1.f;
-            if (at_kan_select) mask_bits |= c;
-            else mask_bits |= BIT(42);
-        }
-        idx += 1;
-        if (cans & CAN_AGARI) {
-            fill(idx, 1.f);
-            if (!at_kan_select) mask_bits |= BIT(43);
-        }
-        idx += 1;
-        flag_row(CAN_RYUKYOKU, 44);
-        // v4 SP block (rows idx .. idx+122) is written by mj_k_sp_rows (mj_sp.hip) straight into HBM after this kernel.
-        if (lane < 46) mask[lane] = (u8)((mask_bits >> lane) & 1);
+        __syncthreads();
     }
-    __syncthreads();
-
-    // ---- 4. stream out
-    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)row * n_cells);
-    for (int i = tid; i < n_cells / 4; i += ENC_THREADS) dst[i] = smem4[i];
 }

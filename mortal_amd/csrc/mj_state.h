@@ -149,7 +149,7 @@ enum {
     X(uint8_t, agent_of_seat, , 1)       /* bit per seat: 0 = agent 0 (challenger), 1 = agent 1 (champion) */
 
 template <int LANES>
-struct TableT {
+struct alignas(16) TableT {
 #define MJ_X_DECL(type, name, dims, count) type name dims[LANES];
     MJ_FIELDS(MJ_X_DECL)
 #undef MJ_X_DECL

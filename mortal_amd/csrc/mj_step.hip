@@ -33,6 +33,7 @@ struct StepParams {
     int* final_scores;         // [n_games_total][4] written when a game finishes
     uint8_t* final_done;       // [n_games_total]
     int n_games_total;
+    int* block_rows;           // [n_blocks][2] rows wanted per 64-table block and agent (input of the row scan)
 };
 
 // ---------------------------------------------------------------- discard candidates (agent_helper.rs:35-79)
@@ -585,11 +586,16 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
     // env steps = tables still live after this cycle (reference: `actions += games.len()`, game.rs:303-304)
     unsigned long long live_mask = __ballot(live_after);
     int dec_sum = n_dec, quick_sum = n_quick;
+    int rows0 = F1(n_rows, 0), rows1 = F1(n_rows, 1);
     for (int off = 32; off > 0; off >>= 1) {
         dec_sum += __shfl_down(dec_sum, off);
         quick_sum += __shfl_down(quick_sum, off);
+        rows0 += __shfl_down(rows0, off);
+        rows1 += __shfl_down(rows1, off);
     }
     if (threadIdx.x == 0) {
+        P.block_rows[2 * blockIdx.x] = rows0;
+        P.block_rows[2 * blockIdx.x + 1] = rows1;
         if (live_mask) atomicAdd(&P.counters[0], (unsigned long long)__popcll(live_mask));
         if (dec_sum) atomicAdd(&P.counters[3], (unsigned long long)dec_sum);
         if (quick_sum) atomicAdd(&P.counters[4], (unsigned long long)quick_sum);
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(64) void mj_k_refill(StepParams P) {
     u32 fl = F(flags);
     if (table >= P.n_tables || (fl & TF_INACTIVE) || !(fl & TF_DONE)) return;
     F(seed_nonce) += P.refill_stride;
+    F(game_id) += (u32)P.n_tables;
     F(flags) = 0;
     F(kyoku) = 0;
     F(honba) = 0;
@@ -613,64 +620,106 @@ __global__ __launch_bounds__(64) void mj_k_refill(StepParams P) {
 }
 
 // ---------------------------------------------------------------- row assignment
-// Single-block exclusive scan over per-table row counts (both agents), then every seat's local row offset becomes
-// a global row id and the row descriptor arrays are filled.  Row order: table, seat, kan-select row before main row.
+// Row order: table, seat, kan-select row before the main row.  Three steps, all coalesced:
+//   mj_k_step      leaves per-table counts (n_rows) and per-block sums (block_rows, wave reduction);
+//   mj_k_scan      exclusive scan of the block sums (one workgroup; n_blocks <= a few thousand);
+//   mj_k_assign    one lane per table: wave prefix (shfl) + block base -> global row ids + row descriptors.
 struct RowsParams {
     TableBlock* blocks;
-    int n_tables;
+    int n_blocks;
+    int* block_rows;     // [n_blocks][2] in: sums, out (after scan): exclusive bases
     uint32_t* rows[2];   // out: row descriptors per agent
     int* n_rows_out;     // out: [2] totals (device)
     int max_rows[2];
 };
-__global__ __launch_bounds__(1024) void mj_k_rows(RowsParams P) {
+__global__ __launch_bounds__(1024) void mj_k_scan(RowsParams P) {
     __shared__ int s_sum[2][1024];
     const int tid = threadIdx.x;
-    const int per = (P.n_tables + 1023) / 1024;
-    const int t0 = tid * per, t1 = min(P.n_tables, t0 + per);
-    int acc[2] = {0, 0};
-    for (int t = t0; t < t1; t++) {
-        TableBlock* B = P.blocks + (t >> 6);
-        acc[0] += B->n_rows[0][t & 63];
-        acc[1] += B->n_rows[1][t & 63];
-    }
-    s_sum[0][tid] = acc[0];
-    s_sum[1][tid] = acc[1];
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        int a0 = tid >= off ? s_sum[0][tid - off] : 0, a1 = tid >= off ? s_sum[1][tid - off] : 0;
+    int carry[2] = {0, 0};
+    for (int base = 0; base < P.n_blocks; base += 1024) {
+        const int b = base + tid;
+        int v0 = b < P.n_blocks ? P.block_rows[2 * b] : 0, v1 = b < P.n_blocks ? P.block_rows[2 * b + 1] : 0;
+        s_sum[0][tid] = v0;
+        s_sum[1][tid] = v1;
         __syncthreads();
-        s_sum[0][tid] += a0;
-        s_sum[1][tid] += a1;
-        __syncthreads();
-    }
-    int base[2] = {s_sum[0][tid] - acc[0], s_sum[1][tid] - acc[1]};
-    if (tid == 1023) {
-        P.n_rows_out[0] = s_sum[0][1023];
-        P.n_rows_out[1] = s_sum[1][1023];
-    }
-    for (int t = t0; t < t1; t++) {
-        TableBlock* B = P.blocks + (t >> 6);
-        const int l = t & 63;
-        const int nr0 = B->n_rows[0][l], nr1 = B->n_rows[1][l];
-        if (nr0 | nr1) {
-            const int aos = B->agent_of_seat[l];
-            for (int s = 0; s < 4; s++) {
-                const int agent = (aos >> s) & 1;
-                int kr = B->kan_row[s][l], mr = B->main_row[s][l];
-                if (kr >= 0) {
-                    kr += base[agent];
-                    B->kan_row[s][l] = kr;
-                    if (kr < P.max_rows[agent]) P.rows[agent][kr] = ROW_PACK(t, s, 1);
-                }
-                if (mr >= 0) {
-                    mr += base[agent];
-                    B->main_row[s][l] = mr;
-                    if (mr < P.max_rows[agent]) P.rows[agent][mr] = ROW_PACK(t, s, 0);
-                }
-            }
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            int a0 = tid >= off ? s_sum[0][tid - off] : 0, a1 = tid >= off ? s_sum[1][tid - off] : 0;
+            __syncthreads();
+            s_sum[0][tid] += a0;
+            s_sum[1][tid] += a1;
+            __syncthreads();
         }
-        base[0] += nr0;
-        base[1] += nr1;
+        if (b < P.n_blocks) {
+            P.block_rows[2 * b] = carry[0] + s_sum[0][tid] - v0;
+            P.block_rows[2 * b + 1] = carry[1] + s_sum[1][tid] - v1;
+        }
+        carry[0] += s_sum[0][1023];
+        carry[1] += s_sum[1][1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        P.n_rows_out[0] = carry[0];
+        P.n_rows_out[1] = carry[1];
+    }
+}
+__global__ __launch_bounds__(64) void mj_k_assign(RowsParams P) {
+    TableBlock* B = P.blocks + blockIdx.x;
+    const int l = threadIdx.x, t = blockIdx.x * 64 + l;
+    const int nr[2] = {B->n_rows[0][l], B->n_rows[1][l]};
+    int incl[2] = {nr[0], nr[1]};
+    for (int off = 1; off < 64; off <<= 1) {
+        int a0 = __shfl_up(incl[0], off), a1 = __shfl_up(incl[1], off);
+        if (l >= off) {
+            incl[0] += a0;
+            incl[1] += a1;
+        }
+    }
+    if ((nr[0] | nr[1]) == 0) return;
+    int base[2] = {P.block_rows[2 * blockIdx.x] + incl[0] - nr[0], P.block_rows[2 * blockIdx.x + 1] + incl[1] - nr[1]};
+    const int aos = B->agent_of_seat[l];
+    for (int s = 0; s < 4; s++) {
+        const int agent = (aos >> s) & 1;
+        int kr = B->kan_row[s][l], mr = B->main_row[s][l];
+        if (kr >= 0) {
+            kr += base[agent];
+            B->kan_row[s][l] = kr;
+            if (kr < P.max_rows[agent]) P.rows[agent][kr] = ROW_PACK(t, s, 1);
+        }
+        if (mr >= 0) {
+            mr += base[agent];
+            B->main_row[s][l] = mr;
+            if (mr < P.max_rows[agent]) P.rows[agent][mr] = ROW_PACK(t, s, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- snapshot (SoA pool -> one contiguous record per table)
+// The pool is lane-major for the step kernel; the encoder wants one table's ~2.3 KB in one piece.  Every element is
+// read coalesced (64 lanes = 64 consecutive elements) and written to that table's TableOne record; the 550 small
+// writes per table land in the same few cache lines within microseconds and merge in L2.  Tables without a policy
+// row this cycle are skipped.
+struct SnapParams {
+    const TableBlock* blocks;
+    TableOne* snap;
+    const MjGatherEnt* gather;
+    int n_gather;
+};
+__global__ __launch_bounds__(256) void mj_k_snapshot(SnapParams P) {
+    const TableBlock* B = P.blocks + blockIdx.x;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    if ((B->n_rows[0][lane] | B->n_rows[1][lane]) == 0) return;
+    const char* src_base = reinterpret_cast<const char*>(B);
+    char* dst_base = reinterpret_cast<char*>(P.snap + (size_t)blockIdx.x * 64 + lane);
+    for (int g = grp; g < P.n_gather; g += 4) {
+        const MjGatherEnt e = P.gather[g];  // wave-uniform
+        const char* s = src_base + e.src_off + lane * e.size;
+        char* d = dst_base + e.dst_off;
+        switch (e.size) {
+            case 1: *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s); break;
+            case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
+            case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
+            default: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
+        }
     }
 }
 

@@ -141,7 +141,14 @@ class TablePool:
         size = lib.mj_debug_table_size()
         buf = (C.c_uint8 * size)()
         check(lib.mj_debug_table(self.h, table, buf, size, _stream()))
-        return bytes(buf)
+        raw = bytes(buf)
+        out = {}
+        for ent in lib.mj_debug_layout().decode().strip(";").split(";"):
+            name, size, count, off = ent.split(":")
+            size, count, off = int(size), int(count), int(off)
+            dt = {1: np.uint8, 2: np.uint16, 4: np.int32, 8: np.uint64}[size]
+            out[name] = np.frombuffer(raw, dtype=dt, count=count, offset=off).copy()
+        return out
 
 
 def _memcpy_d2d(dst, src, nbytes):

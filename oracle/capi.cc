@@ -239,6 +239,27 @@ int mjo_ps_snapshot(void* h, int* o) {
     for (int i = 0; i < 4; i++) o[238 + i] = s->scores[i];
     return 0;
 }
+// kawa of relative seat `rel` in the pool's u64 entry format (mortal_amd/csrc/mj_state.h KW_*); returns length
+int mjo_ps_kawa(void* h, int rel, unsigned long long* out, int max_n) {
+    PlayerState* s = (PlayerState*)h;
+    int n = 0;
+    for (auto& it : s->kawa[rel]) {
+        unsigned long long e = 0;
+        if (it) {
+            e = 1ull | ((unsigned long long)it->sutehai.tile << 1) | ((unsigned long long)it->sutehai.is_dora << 7) |
+                ((unsigned long long)it->sutehai.is_tedashi << 8) | ((unsigned long long)it->sutehai.is_riichi << 9);
+            if (it->chi_pon) {
+                int a = deaka(it->chi_pon->consumed[0]), b = deaka(it->chi_pon->consumed[1]);
+                e |= (1ull << 10) | ((unsigned long long)std::min(a, b) << 11) | ((unsigned long long)std::max(a, b) << 17);
+            }
+            e |= (unsigned long long)it->kan.size() << 23;
+            for (size_t k = 0; k < it->kan.size() && k < 4; k++) e |= (unsigned long long)it->kan[k] << (26 + 6 * k);
+        }
+        if (n < max_n) out[n] = e;
+        n++;
+    }
+    return n;
+}
 int mjo_ps_uncond_tenpai(void* h, u8* out34) {
     return guard([&] {
         bool b[34];

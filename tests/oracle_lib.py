@@ -72,6 +72,7 @@ def lib():
     L.mjo_ps_agari_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.mjo_ps_snapshot.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_ps_uncond_tenpai.argtypes = [C.c_void_p, C.c_void_p]
+    L.mjo_ps_kawa.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.mjo_ps_scene.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.mjo_ps_decode_action.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.mjo_ps_sp_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -292,6 +293,11 @@ class PlayerState:
             real_time_shanten=int(o[234]), can_w_riichi=bool(o[235]), at_ippatsu=bool(o[236]),
             at_rinshan=bool(o[237]), scores=[int(x) for x in o[238:242]],
         )
+
+    def kawa(self, rel):
+        out = np.zeros(64, dtype=np.uint64)
+        n = lib().mjo_ps_kawa(self.h, rel, ptr(out), 64)
+        return out[:n]
 
     def uncond_tenpai(self):
         out = np.zeros(34, dtype=np.uint8)

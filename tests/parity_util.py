@@ -77,6 +77,19 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
                 for x in bad:
                     hist[int(x[1])] = hist.get(int(x[1]), 0) + 1
                 lines.append(f"  histogram of differing obs rows over the batch: {sorted(hist.items())[:60]}")
+                g, seat = int(rows_o[r][0]), int(rows_o[r][1])
+                dbg = pool.debug_table(g)
+                ps = arena.player_state(g, seat)
+                oya = int(dbg["kyoku"][0]) & 3
+                for rel in range(4):
+                    a = (seat + rel) & 3
+                    kg = dbg["kawa"].reshape(4, -1)[a][: int(dbg["kawa_len"][a])]
+                    pad = 1 if rel < ((oya - seat) & 3) else 0
+                    lines.append(f"  kawa rel {rel} (abs {a}) pad {pad}: gpu    {[hex(int(x)) for x in kg]}")
+                    lines.append(f"                              oracle {[hex(int(x)) for x in ps.kawa(rel)]}")
+                lines.append(f"  oracle snapshot: {ps.snapshot()}")
+                lines.append(f"  gpu table: " + ", ".join(f"{k}={v.tolist()}" for k, v in dbg.items()
+                                                         if k not in ("wall", "kawa")))
                 raise AssertionError("\n".join(lines))
             stats["obs_checked"] += n
         act = oracle.random_actions(masks_o, rows_o, cycle, seed=policy_seed)
