@@ -50,8 +50,9 @@ void mj_pool_destroy(MjPool* pool);
 int mj_pool_reset(MjPool* pool, const uint64_t* nonces, const uint64_t* keys, const uint32_t* game_ids,
                   const uint8_t* agent_of_seat, int n_games_total);
 
-/* Per-agent engine attributes (agent/mortal.rs:53-74). */
-int mj_pool_configure(MjPool* pool, int agent, int enable_quick_eval, int enable_rule_based_agari_guard);
+/* Per-agent engine attributes (agent/mortal.rs:53-74): obs version (0 = keep), quick-eval, agari guard. */
+int mj_pool_configure(MjPool* pool, int agent, int version, int enable_quick_eval,
+                      int enable_rule_based_agari_guard);
 /* Steady-state mode for throughput runs: finished tables restart with nonce += stride. 0 disables. */
 int mj_pool_set_refill(MjPool* pool, uint64_t nonce_stride);
 

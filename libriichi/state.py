@@ -1,0 +1,5 @@
+"""libriichi.state — a "next" row of the hot-path scope table; not built this round."""
+
+
+def __getattr__(name):
+    raise NotImplementedError(f"libriichi.state.{name} is not implemented yet (SURVEY.md §8(f))")

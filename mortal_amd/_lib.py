@@ -35,7 +35,7 @@ def _load():
     L.mj_pool_create.argtypes = [i32, i32, i32, i32]
     L.mj_pool_destroy.argtypes = [vp]
     L.mj_pool_reset.argtypes = [vp, vp, vp, vp, vp, i32]
-    L.mj_pool_configure.argtypes = [vp, i32, i32, i32]
+    L.mj_pool_configure.argtypes = [vp, i32, i32, i32, i32]
     L.mj_pool_set_refill.argtypes = [vp, u64]
     L.mj_step.argtypes = [vp, vp, vp, vp]
     L.mj_rows_count.argtypes = [vp, vp, vp]

@@ -1,0 +1,187 @@
+"""Host side of the batched arena: mirrors `libriichi.arena` (reference libriichi/src/arena/one_vs_three.rs:17-113,
+two_vs_two.rs:17-110) on top of the HIP table pool.
+
+The poll/commit cycle of `BatchGame::run` (arena/game.rs:286-304) becomes, per cycle:
+    mj_step (commit + poll + classify, on device)  ->  per agent: mj_encode -> engine.react_batch -> actions
+The engine contract is the reference's (agent/mortal.rs:50-159): attributes `engine_type`, `name`, `is_oracle`,
+`version`, `enable_quick_eval`, `enable_rule_based_agari_guard`, and
+`react_batch(obs, masks, invisible_obs) -> (actions, q_values, masks, is_greedy)`.
+
+Zero-copy: `MortalEngine._react_batch` (mortal/engine.py:53-55) does `torch.as_tensor(np.stack(obs, axis=0), device=..)`.
+We pass `[proxy]` whose `__array_function__` answers `np.stack` with the pre-stacked device tensor, so the unchanged
+engine consumes the encoded batch in place.  Engines that define `react_batch_device(obs, masks)` (our extension,
+returns a device int tensor of actions) skip the `.tolist()` round trip as well.
+"""
+import numpy as np
+import torch
+
+from .pool import ACTION_SPACE, OBS_ROWS, TablePool
+from ._lib import MortalAmdError
+
+
+class _StackedBatch:
+    """Stands in for a list of per-row numpy arrays; np.stack([proxy], axis=0) returns the device tensor."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func is np.stack:
+            return self.tensor
+        return NotImplemented
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+
+def _check_engine(engine):
+    et = getattr(engine, "engine_type")
+    if et != "mortal":
+        raise NotImplementedError(f"engine_type {et!r}: only 'mortal' engines are supported on the device path "
+                                  "(mjai-log / akochan agents are out of scope, SURVEY.md §2 rows 2)")
+    if not callable(getattr(engine, "react_batch", None)):
+        raise TypeError("missing method react_batch")
+    if getattr(engine, "is_oracle"):
+        raise NotImplementedError("is_oracle engines (invisible obs, board.rs:680-782) are not supported yet")
+    if getattr(engine, "enable_rule_based_agari_guard"):
+        raise NotImplementedError("enable_rule_based_agari_guard is not supported on the device path yet")
+    return dict(name=str(engine.name), version=int(engine.version), quick=bool(engine.enable_quick_eval))
+
+
+class BatchRunner:
+    """Drives N tables to completion with up to two engines (agent 0 / agent 1)."""
+
+    def __init__(self, engines, seeds, agent_of_seat, device=None, deal_algo=0):
+        self.engines = engines
+        self.cfg = [_check_engine(e) for e in engines]
+        dev = device
+        if dev is None:
+            d0 = getattr(engines[0], "device", None)
+            dev = d0 if isinstance(d0, torch.device) and d0.type == "cuda" else torch.device("cuda:0")
+        self.device = torch.device(dev)
+        n = len(seeds)
+        self.pool = TablePool(n, version=self.cfg[0]["version"], deal_algo=deal_algo, device=str(self.device))
+        self.pool.reset(seeds, game_ids=np.arange(n), agent_of_seat=agent_of_seat, n_games_total=n)
+        for a, c in enumerate(self.cfg):
+            self.pool.configure(a, enable_quick_eval=c["quick"], version=c["version"])
+        if len(engines) == 1:
+            self.pool.configure(1, enable_quick_eval=self.cfg[0]["quick"], version=self.cfg[0]["version"])
+        self.cycles = 0
+
+    def _policy(self, agent, obs, masks):
+        eng = self.engines[agent]
+        if hasattr(eng, "react_batch_device"):
+            act = eng.react_batch_device(obs, masks)
+            return act.to(device=self.device, dtype=torch.int32).contiguous()
+        try:
+            actions, _q, _m, _g = eng.react_batch([_StackedBatch(obs)], [_StackedBatch(masks)], None)
+        except Exception as ex:  # same context string as agent/mortal.rs:149
+            raise RuntimeError(f"failed to execute `react_batch` on Python engine: {ex}") from ex
+        if len(actions) != obs.shape[0]:
+            raise RuntimeError("react_batch returned a batch of the wrong size")
+        return torch.as_tensor(actions, dtype=torch.int32, device=self.device)
+
+    def run(self, max_cycles=1 << 30):
+        pool = self.pool
+        acts = [None, None]
+        n_games = pool.n_tables
+        while True:
+            n = pool.step(acts[0], acts[1])
+            self.cycles += 1
+            code, tbl = pool.first_error() if (self.cycles & 63) == 0 else (0, -1)
+            if code:
+                raise MortalAmdError(f"table {tbl}: illegal action or rule violation (error code {code})")
+            acts = [None, None]
+            if n[0] == 0 and n[1] == 0:
+                c = pool.counters()
+                if c["games"] >= n_games:
+                    break
+                continue
+            for a in (0, 1):
+                if n[a] == 0:
+                    continue
+                obs, masks = pool.encode(a)
+                acts[a] = self._policy(a, obs, masks)
+            if self.cycles >= max_cycles:
+                raise MortalAmdError("max_cycles exceeded")
+        code, tbl = pool.first_error()
+        if code:
+            raise MortalAmdError(f"table {tbl}: illegal action or rule violation (error code {code})")
+        scores, done = pool.results()
+        if not (done == 1).all():
+            raise MortalAmdError("some games did not finish")
+        return scores
+
+    def close(self):
+        self.pool.close()
+
+
+def _rank_by_player(scores):
+    """rankings.rs:8-21: stable sort by -score; ties favour the lower seat."""
+    order = sorted(range(4), key=lambda i: -int(scores[i]))
+    rank = [0] * 4
+    for r, pid in enumerate(order):
+        rank[pid] = r
+    return rank
+
+
+class OneVsThree:
+    """libriichi.arena.OneVsThree (arena/one_vs_three.rs:17-113)."""
+
+    def __init__(self, *, disable_progress_bar=False, log_dir=None):
+        self.disable_progress_bar = disable_progress_bar
+        self.log_dir = log_dir
+
+    def py_vs_py(self, challenger, champion, seed_start, seed_count):
+        """Returns the rank histogram [1st, 2nd, 3rd, 4th] of the challenger over seed_count*4 hanchan."""
+        if self.log_dir is not None:
+            raise NotImplementedError("log_dir (mjai .json.gz dumps, result.rs:32-51) is a 'next' row (SURVEY §8(f).1)")
+        n = int(seed_count) * 4
+        seeds = [(int(seed_start[0]) + g // 4, int(seed_start[1])) for g in range(n)]  # one_vs_three.rs:140-142
+        # challenger (agent 0) sits at seat g % 4, the champion (agent 1) on the other three (one_vs_three.rs:144-191)
+        aos = np.array([0xF & ~(1 << (g % 4)) for g in range(n)], dtype=np.uint8)
+        runner = BatchRunner([challenger, champion], seeds, aos)
+        try:
+            scores = runner.run()
+        finally:
+            runner.close()
+        rankings = [0, 0, 0, 0]
+        for g in range(n):
+            rankings[_rank_by_player(scores[g])[g % 4]] += 1  # one_vs_three.rs:55-60
+        return rankings
+
+    def ako_vs_py(self, engine, seed_start, seed_count):
+        raise NotImplementedError("akochan agents are out of scope (SURVEY.md §2 row 2)")
+
+    def py_vs_ako(self, engine, seed_start, seed_count):
+        raise NotImplementedError("akochan agents are out of scope (SURVEY.md §2 row 2)")
+
+
+class TwoVsTwo:
+    """libriichi.arena.TwoVsTwo (arena/two_vs_two.rs:17-110): seed_count*2 hanchan, returns None."""
+
+    def __init__(self, *, disable_progress_bar=False, log_dir=None):
+        self.disable_progress_bar = disable_progress_bar
+        self.log_dir = log_dir
+
+    def py_vs_py(self, challenger, champion, seed_start, seed_count):
+        if self.log_dir is not None:
+            raise NotImplementedError("log_dir is a 'next' row (SURVEY §8(f).1)")
+        n = int(seed_count) * 2
+        seeds = [(int(seed_start[0]) + g // 2, int(seed_start[1])) for g in range(n)]  # two_vs_two.rs:138-140
+        # split A: challenger at seats 0,2; split B: 1,3 (two_vs_two.rs:142-172)
+        aos = np.array([0b1010 if g % 2 == 0 else 0b0101 for g in range(n)], dtype=np.uint8)
+        runner = BatchRunner([challenger, champion], seeds, aos)
+        try:
+            runner.run()
+        finally:
+            runner.close()
+        return None
+
+    def ako_vs_py(self, *a, **k):
+        raise NotImplementedError("akochan agents are out of scope")
+
+    py_vs_ako = py_vs_ako_one = ako_vs_py
+
+
+__all__ = ["OneVsThree", "TwoVsTwo", "BatchRunner", "ACTION_SPACE", "OBS_ROWS"]

@@ -75,7 +75,8 @@ std::vector<MjGatherEnt> build_gather() {
 }  // namespace
 
 struct MjPool {
-    int n_tables = 0, n_blocks = 0, version = 4, C = 1012, deal_algo = 0, max_rows = 0;
+    int n_tables = 0, n_blocks = 0, deal_algo = 0, max_rows = 0;
+    int version[2] = {4, 4};  // obs version per agent (engine.version, agent/mortal.rs:57)
     TableBlock* blocks = nullptr;
     uint32_t* rows[2] = {nullptr, nullptr};
     int* n_rows_dev = nullptr;
@@ -174,8 +175,7 @@ MjPool* mj_pool_create(int n_tables, int version, int deal_algo, int max_rows) {
     MjPool* P = new MjPool;
     P->n_tables = n_tables;
     P->n_blocks = (n_tables + MJ_LANES - 1) / MJ_LANES;
-    P->version = version;
-    P->C = mj_obs_rows(version);
+    P->version[0] = P->version[1] = version;
     P->deal_algo = deal_algo;
     P->max_rows = max_rows > 0 ? max_rows : 8 * n_tables;
     bool ok = hipMalloc(&P->blocks, (size_t)P->n_blocks * sizeof(TableBlock)) == hipSuccess &&
@@ -251,8 +251,12 @@ int mj_pool_reset(MjPool* P, const uint64_t* nonces, const uint64_t* keys, const
     return 0;
 }
 
-int mj_pool_configure(MjPool* P, int agent, int enable_quick_eval, int enable_guard) {
+int mj_pool_configure(MjPool* P, int agent, int version, int enable_quick_eval, int enable_guard) {
     if (!P || agent < 0 || agent > 1) return fail("bad agent");
+    if (version != 0) {
+        if (mj_obs_rows(version) < 0) return fail("bad obs version");
+        P->version[agent] = version;
+    }
     P->enable_quick_eval[agent] = enable_quick_eval;
     P->enable_agari_guard[agent] = enable_guard;
     if (enable_guard) return fail("enable_rule_based_agari_guard is not supported on the device path yet");
@@ -333,15 +337,15 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     ep.tables = g_tables.dev;
     ep.obs = obs;
     ep.masks = masks;
-    ep.version = P->version;
-    ep.C = P->C;
+    ep.version = P->version[agent & 1];
+    ep.C = mj_obs_rows(ep.version);
     ep.snap = P->snap;
     ep.decay_lut = g_tables.decay;
     ep.rbf_score = g_tables.rbf_score;
     ep.rbf_6 = g_tables.rbf_6;
     ep.rbf_12 = g_tables.rbf_12;
     ep.rbf_23 = g_tables.rbf_23;
-    size_t lds = enc_lds_bytes(P->version);
+    size_t lds = enc_lds_bytes(ep.version);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (P->timing) {
@@ -349,7 +353,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         HIP_OK(hipEventCreate(&e1));
         HIP_OK(hipEventRecord(e0, s));
     }
-    switch (P->version) {
+    switch (ep.version) {
         case 1: hipLaunchKernelGGL(mj_k_encode<1>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
         case 2: hipLaunchKernelGGL(mj_k_encode<2>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
         case 3: hipLaunchKernelGGL(mj_k_encode<3>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;

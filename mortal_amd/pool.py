@@ -44,6 +44,7 @@ class TablePool:
             raise MortalAmdError(lib.mj_last_error().decode())
         self.n_rows = [0, 0]
         self.n_games_total = n_tables
+        self.versions = [version, version]
 
     def close(self):
         if getattr(self, "h", None):
@@ -65,8 +66,11 @@ class TablePool:
                                 self.n_games_total))
         self.n_rows = [0, 0]
 
-    def configure(self, agent, enable_quick_eval=True, enable_rule_based_agari_guard=False):
-        check(lib.mj_pool_configure(self.h, agent, int(enable_quick_eval), int(enable_rule_based_agari_guard)))
+    def configure(self, agent, enable_quick_eval=True, enable_rule_based_agari_guard=False, version=0):
+        check(lib.mj_pool_configure(self.h, agent, int(version), int(enable_quick_eval),
+                                    int(enable_rule_based_agari_guard)))
+        if version:
+            self.versions[agent] = version
 
     def set_refill(self, nonce_stride):
         check(lib.mj_pool_set_refill(self.h, nonce_stride))
@@ -99,7 +103,7 @@ class TablePool:
         """Encode agent's rows in place into (or into fresh) device tensors. Returns (obs [n,C,34] f32, masks [n,46] bool)."""
         n = self.n_rows[agent]
         if obs is None:
-            obs = torch.empty((n, self.C, 34), dtype=torch.float32, device=self.device)
+            obs = torch.empty((n, OBS_ROWS[self.versions[agent]], 34), dtype=torch.float32, device=self.device)
         if masks is None:
             masks = torch.empty((n, ACTION_SPACE), dtype=torch.bool, device=self.device)
         assert obs.is_contiguous() and masks.is_contiguous() and obs.shape[0] >= n and masks.shape[0] >= n

@@ -1,0 +1,81 @@
+"""-m gpu: the libriichi-compatible arena (OneVsThree.py_vs_py) end to end with a random-init policy net, both through
+the legacy `react_batch` list contract (zero-copy proxy) and the device fast path, cross-checked against the oracle
+arena driven by the same network (BASELINE configs[0]-style plumbing, 8 hanchan)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KEY = 0xD5DFAA4CEF265CD7
+
+
+def _engine(version, seed, name, device_path):
+    import torch
+
+    from mortal_amd.policy import DeviceEngine, PolicyNet
+
+    torch.manual_seed(seed)
+    net = PolicyNet(version=version, conv_channels=32, num_blocks=2)
+    eng = DeviceEngine(net, version, "cuda:0", name=name, enable_amp=False)
+    if not device_path:
+        eng.react_batch_device = None
+        del eng.react_batch_device
+        # instance attribute deletion does not hide the class method: wrap instead
+        class Legacy:  # only the reference's duck-typed surface
+            pass
+        leg = Legacy()
+        for k in ("engine_type", "name", "is_oracle", "version", "enable_quick_eval", "enable_rule_based_agari_guard",
+                  "device"):
+            setattr(leg, k, getattr(eng, k))
+        leg.react_batch = eng.react_batch
+        return leg, eng
+    return eng, eng
+
+
+def _oracle_rankings(oracle, challenger, champion, seed_start, seed_count, version):
+    """The reference's BatchGame loop on the oracle, with the same two networks deciding."""
+    import torch
+
+    n = seed_count * 4
+    seeds = [(seed_start[0] + g // 4, seed_start[1]) for g in range(n)]
+    arena = oracle.Arena(seeds, deal_algo=0, enable_quick_eval=True, version=version, keep_log=False)
+    while arena.n_live > 0:
+        rows = arena.poll()
+        k = len(rows)
+        obs, masks = arena.encode(0, k, want_obs=True)
+        act = np.full(k, 45, dtype=np.int32)
+        if k:
+            is_chal = (rows[:, 1] == rows[:, 0] % 4)
+            for eng, sel in ((challenger, is_chal), (champion, ~is_chal)):
+                if sel.any():
+                    o = torch.from_numpy(obs[sel]).cuda()
+                    m = torch.from_numpy(masks[sel].astype(bool)).cuda()
+                    act[sel] = eng.react_batch_device(o, m).cpu().numpy()
+        arena.commit(act)
+    scores = np.array([arena.result(g)[0] for g in range(n)])
+    rankings = [0, 0, 0, 0]
+    for g in range(n):
+        order = sorted(range(4), key=lambda i: -int(scores[g][i]))
+        rankings[order.index(g % 4)] += 1
+    return rankings, scores
+
+
+@pytest.mark.parametrize("device_path", [False, True])
+def test_one_vs_three_py_vs_py_matches_oracle(oracle, device_path):
+    from libriichi.arena import OneVsThree
+
+    version = 3
+    chal, chal_dev = _engine(version, 1, "challenger", device_path)
+    cham, cham_dev = _engine(version, 2, "champion", device_path)
+    env = OneVsThree(disable_progress_bar=True)
+    got = env.py_vs_py(challenger=chal, champion=cham, seed_start=(10000, KEY), seed_count=2)
+    assert sum(got) == 8
+    want, _ = _oracle_rankings(oracle, chal_dev, cham_dev, (10000, KEY), 2, version)
+    assert got == want
+
+
+def test_two_vs_two_runs(oracle):
+    from libriichi.arena import TwoVsTwo
+
+    a, _ = _engine(3, 3, "a", True)
+    b, _ = _engine(3, 4, "b", True)
+    assert TwoVsTwo(disable_progress_bar=True).py_vs_py(a, b, (20000, KEY), 2) is None

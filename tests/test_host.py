@@ -1,0 +1,77 @@
+"""CPU-only checks of the host side: C-ABI exports, libriichi surface, seat/seed planning, proxy zero-copy trick."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    """The shared library must load without a GPU and export every symbol include/mortal_amd.h declares."""
+    import __graft_entry__ as g
+
+    g.build()
+    hdr = open(os.path.join(ROOT, "include", "mortal_amd.h")).read()
+    declared = set(re.findall(r"\b(mj_[a-z0-9_]+)\s*\(", hdr))
+    from mortal_amd import _lib
+
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.mj_abi_version() == 1
+    assert [L.mj_obs_rows(v) for v in (1, 2, 3, 4)] == [938, 942, 934, 1012]
+
+
+def test_libriichi_surface():
+    import libriichi
+    from libriichi import consts
+    from libriichi.consts import ACTION_SPACE, GRP_SIZE, MAX_VERSION, obs_shape, oracle_obs_shape
+
+    assert (ACTION_SPACE, GRP_SIZE, MAX_VERSION) == (46, 7, 4)
+    assert obs_shape(4) == (1012, 34) and obs_shape(1) == (938, 34) and oracle_obs_shape(3) == (217, 34)
+    assert libriichi.__profile__ and libriichi.__version__ and consts is libriichi.consts
+    from libriichi.arena import OneVsThree, TwoVsTwo
+
+    env = OneVsThree(disable_progress_bar=True, log_dir=None)
+    assert hasattr(env, "py_vs_py") and hasattr(TwoVsTwo(), "py_vs_py")
+    with pytest.raises(TypeError):
+        OneVsThree(True)  # keyword-only like the pyo3 signature (one_vs_three.rs:27)
+    with pytest.raises(NotImplementedError):
+        libriichi.stat.Stat
+
+
+def test_stack_proxy_is_zero_copy():
+    """np.stack([proxy], axis=0) must hand back the very tensor (mortal/engine.py:54 path)."""
+    import torch
+
+    from mortal_amd.arena import _StackedBatch
+
+    t = torch.zeros((5, 7, 34))
+    out = np.stack([_StackedBatch(t)], axis=0)
+    assert out is t
+    assert torch.as_tensor(out, device=torch.device("cpu")) is t
+
+
+def test_rank_and_seat_plan():
+    from mortal_amd.arena import _rank_by_player
+
+    assert _rank_by_player([25000, 25000, 30000, 20000]) == [1, 2, 0, 3]  # rankings.rs:29-65: ties -> lower seat first
+    assert _rank_by_player([25000] * 4) == [0, 1, 2, 3]
+    # challenger seat of game g is g % 4; mask bit s = 1 -> champion
+    aos = [0xF & ~(1 << (g % 4)) for g in range(8)]
+    assert aos[:4] == [0b1110, 0b1101, 0b1011, 0b0111]
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib
+
+    import mortal_amd._lib as L
+
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.MortalAmdError):
+        L._load()
+    importlib.reload(L)
