@@ -75,7 +75,7 @@ int mj_random_policy(MjPool* pool, int agent, const uint8_t* masks_dev, uint64_t
                      int32_t* actions_dev, void* stream);
 
 /* counters: [0] env steps (live tables summed over cycles), [1] games finished, [2] tables in error,
- *           [3] decisions, [4] quick-eval decisions, [5] cycles */
+ *           [3] decisions, [4] quick-eval decisions, [5] cycles, [6] SP hash-set overflows (must stay 0) */
 int mj_counters(MjPool* pool, uint64_t out[8], void* stream);
 /* Final scores [n_games_total][4] and done flags (0 running, 1 finished, 2 aborted on error) to host memory. */
 int mj_results(MjPool* pool, int32_t* scores_out, uint8_t* done_out, void* stream);

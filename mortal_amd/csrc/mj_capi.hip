@@ -12,6 +12,7 @@
 #include "../../include/mortal_amd.h"
 #include "mj_step.hip"
 #include "mj_encode.hip"
+#include "mj_sp.hip"
 
 namespace {
 
@@ -82,6 +83,10 @@ struct MjPool {
     int* n_rows_dev = nullptr;
     int* block_rows = nullptr;
     TableOne* snap = nullptr;
+    SpWork* sp_work = nullptr;      // lazily allocated on the first v4 encode
+    int sp_grid = 0;
+    int* sp_queue = nullptr;
+    unsigned long long* sp_err = nullptr;
     int* n_rows_host = nullptr;  // pinned
     unsigned long long* counters = nullptr;
     int* final_scores = nullptr;
@@ -208,6 +213,9 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->n_rows_dev);
     hipFree(P->block_rows);
     hipFree(P->snap);
+    hipFree(P->sp_work);
+    hipFree(P->sp_queue);
+    hipFree(P->sp_err);
     if (P->n_rows_host) hipHostFree(P->n_rows_host);
     hipFree(P->counters);
     hipFree(P->final_scores);
@@ -364,6 +372,28 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         P->events.push_back({e0, e1});
     }
     HIP_OK(hipGetLastError());
+    if (ep.version == 4) {  // SP block, rows 889..1011 (mj_sp.hip)
+        if (!P->sp_work) {
+            P->sp_grid = 1024;
+            HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
+            HIP_OK(hipMalloc(&P->sp_queue, sizeof(int)));
+            HIP_OK(hipMalloc(&P->sp_err, 2 * sizeof(unsigned long long)));
+            HIP_OK(hipMemset(P->sp_err, 0, 2 * sizeof(unsigned long long)));
+        }
+        HIP_OK(hipMemsetAsync(P->sp_queue, 0, sizeof(int), s));
+        SpParams sp;
+        sp.snap = P->snap;
+        sp.rows = P->rows[agent & 1];
+        sp.n_rows = n;
+        sp.tables = g_tables.dev;
+        sp.obs = obs;
+        sp.work = P->sp_work;
+        sp.queue = P->sp_queue;
+        sp.err = P->sp_err;
+        int grid = n < P->sp_grid ? n : P->sp_grid;
+        hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
+        HIP_OK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -406,6 +436,12 @@ int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
     HIP_OK(hipMemcpy(tmp, P->counters, sizeof tmp, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = tmp[i];
     out[5] = P->cycles;
+    if (P->sp_err) {
+        unsigned long long e2[2];
+        HIP_OK(hipMemcpy(e2, P->sp_err, sizeof e2, hipMemcpyDeviceToHost));
+        out[6] = e2[0];
+        out[7] = e2[1];
+    }
     return 0;
 }
 

@@ -1,0 +1,747 @@
+// Single-player tables of obs v4 (rows 889..1011) on device.
+//
+// Reference: PlayerState::single_player_tables (state/agent_helper.rs:509-593) -> SPCalculator::calc
+// (algo/sp/calc.rs:84-133, production flags: no tegawari, no shanten-down, maximise EV, sorted) and the encoder block
+// obs_repr.rs:564-692.  The reference is a memoised depth-first recursion (draw -> discard -> draw ...) over hand
+// states with order-sensitive f32 sums.  On the GPU the same values are produced LEVEL-SYNCHRONOUSLY by one workgroup
+// per decision:
+//   expand   : for shanten level L = s .. 1, every 3n+1 state of level L (one thread per state) enumerates its
+//              children  (required draw t, shanten-keeping discard d)  and inserts them into a per-workgroup hash set
+//              (64-bit tag claimed by atomicCAS, full 256-bit key verified after a barrier);
+//   evaluate : for L = 0 .. s, one thread per state reproduces draw_without_tegawari (calc.rs:447-561) with the
+//              reference's exact loop order (draw tiles ascending, aka after its plain tile; i, j ascending), reading
+//              the children's 3x17 values through the hash set and folding discards like discard_slow (calc.rs:563-637).
+// Memoisation in the reference is a pure cache, so evaluating every reachable state exactly once gives bit-identical
+// f32 results as long as each state's own accumulation order is kept — it is.  Compiled with -ffp-contract=off
+// (Rust never fuses a*b+c).
+#include <hip/hip_runtime.h>
+
+#include "mj_rules.h"
+
+#define SP_THREADS 256
+#define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
+#define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
+#define SP_MAX_CAND 14
+
+struct SpNode {                // one 3n+1 state
+    u64 k0, k1, k2, k3;        // hand.mp | hand.sz + akas_in_hand<<48 | wall.mp | wall.sz + akas_in_wall<<48
+    float tenpai[SP_T], win[SP_T], ev[SP_T];
+};
+struct SpWork {                // per-workgroup scratch in HBM (persistent workgroups)
+    u64 tag[SP_CAP];
+    SpNode node[SP_CAP];
+    u32 list[SP_CAP];          // slots grouped by level: level L occupies [lvl_begin[L], lvl_end[L])
+};
+
+struct SpParams {
+    const TableOne* snap;
+    const uint32_t* rows;
+    int n_rows;
+    MjTablesDev tables;
+    float* obs;                // [n_rows][1012][34]; rows 889.. are zero on entry (written by mj_k_encode<4>)
+    SpWork* work;              // [gridDim.x]
+    int* queue;                // dynamic row queue (zeroed before launch)
+    unsigned long long* err;   // [0] hash-capacity overflows, [1] tag collisions with different keys
+};
+
+// algo/data/uradora_prob_table.txt (values restated; calc.rs:17)
+__device__ static const float SP_URADORA[5][13] = {
+    {0.639485f, 0.327801f, 0.0327134f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.406736f, 0.42281f, 0.147966f, 0.021674f, 0.0008142f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.257516f, 0.406819f, 0.246851f, 0.0757724f, 0.0122266f, 0.0008004f, 1.43e-5f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.162199f, 0.346513f, 0.301539f, 0.142396f, 0.0401276f, 0.0066491f, 0.0005575f, 1.85e-5f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.101768f, 0.275319f, 0.313742f, 0.20189f, 0.081774f, 0.0215394f, 0.0035918f, 0.0003607f, 1.52e-5f, 3e-7f, 0.f, 0.f, 0.f}};
+__device__ static const u8 SP_DISCARD_PRIO[38] = {  // tile.rs:21-28
+    6, 5, 4, 3, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 3, 4, 5, 6, 7, 7, 7, 7, 7, 7, 7, 1, 1, 1, 0};
+MJD int cmp_discard_priority(int l, int r) {  // tile.rs:169-177
+    int pl = SP_DISCARD_PRIO[l], pr = SP_DISCARD_PRIO[r];
+    if (pl != pr) return pl < pr ? -1 : 1;
+    if (r != l) return r < l ? -1 : 1;
+    return 0;
+}
+
+struct SpState {  // sp/state.rs:9-20 (n_extra_tsumo is always 0 with the production flags)
+    Hand h, w;
+    u32 akas;     // bits 0..2 akas_in_hand, 3..5 akas_in_wall
+};
+MJD void sp_discard(SpState& s, int tile) {  // state.rs:57-65
+    s.h.dec(deaka(tile));
+    if (is_aka(tile)) s.akas &= ~(1u << (tile - T_5MR));
+}
+MJD void sp_deal(SpState& s, int tile) {     // state.rs:77-86
+    s.w.dec(deaka(tile));
+    s.h.inc(deaka(tile));
+    if (is_aka(tile)) {
+        s.akas &= ~(8u << (tile - T_5MR));
+        s.akas |= 1u << (tile - T_5MR);
+    }
+}
+MJD void sp_key(const SpState& s, u64 k[4]) {
+    k[0] = s.h.mp;
+    k[1] = s.h.sz | ((u64)(s.akas & 7) << 48);
+    k[2] = s.w.mp;
+    k[3] = s.w.sz | ((u64)((s.akas >> 3) & 7) << 48);
+}
+MJD u64 sp_hash(const u64 k[4]) {
+    u64 h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        h ^= k[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+        h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+        h ^= h >> 31;
+    }
+    return h | 1ull;  // never 0 (0 = empty slot)
+}
+
+struct SpCtx {  // per-decision constants (LDS)
+    Melds melds;
+    int len_div3, bakaze, jikaze, is_menzen, num_doras_in_fuuro, n_dora, calc_double_riichi, calc_haitei,
+        prefer_riichi, T, n_left;
+    int dora_ind[5];
+    float tsumo_prob[4][SP_T];
+    float not_tsumo[124][SP_T];   // MAX_TILES_LEFT + 1 = 123 rows (calc.rs:14,148-167); row = sum of required tiles
+    // level bookkeeping
+    int lvl_begin[5], lvl_end[5];
+    int n_list;
+    int overflow;
+    // candidates
+    int n_cand;
+    int cand_tile[SP_MAX_CAND], cand_slot[SP_MAX_CAND], cand_down[SP_MAX_CAND], cand_nreq[SP_MAX_CAND];
+    u64 cand_req[SP_MAX_CAND];
+    int order[SP_MAX_CAND];
+    float cand_tp0[SP_MAX_CAND], cand_wp0[SP_MAX_CAND], cand_ev0[SP_MAX_CAND];
+};
+
+// hash-set insert; returns the slot or -1 on overflow.  `fresh` tells whether this call created the slot.
+__device__ int sp_insert(SpWork* W, SpCtx* X, const SpState& s, bool& fresh) {
+    u64 k[4];
+    sp_key(s, k);
+    const u64 h = sp_hash(k);
+    u32 pos = (u32)(h >> 20) & (SP_CAP - 1);
+    fresh = false;
+    for (int probe = 0; probe < SP_CAP; probe++) {
+        u64 old = atomicCAS((unsigned long long*)&W->tag[pos], 0ull, (unsigned long long)h);
+        if (old == 0ull) {
+            SpNode& n = W->node[pos];
+            n.k0 = k[0]; n.k1 = k[1]; n.k2 = k[2]; n.k3 = k[3];
+            fresh = true;
+            return (int)pos;
+        }
+        if (old == h) return (int)pos;  // same tag: key equality is verified by sp_verify after the barrier
+        pos = (pos + 1) & (SP_CAP - 1);
+    }
+    X->overflow = 1;
+    return -1;
+}
+__device__ int sp_lookup(const SpWork* W, const SpState& s) {
+    u64 k[4];
+    sp_key(s, k);
+    const u64 h = sp_hash(k);
+    u32 pos = (u32)(h >> 20) & (SP_CAP - 1);
+    for (int probe = 0; probe < SP_CAP; probe++) {
+        // tags are claimed with L2 atomics; read them at agent scope so a stale L1 line can never be observed
+        u64 t = __hip_atomic_load(&W->tag[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == h) {
+            const SpNode& n = W->node[pos];
+            if (n.k0 == k[0] && n.k1 == k[1] && n.k2 == k[2] && n.k3 == k[3]) return (int)pos;
+        } else if (t == 0ull) {
+            return -1;
+        }
+        pos = (pos + 1) & (SP_CAP - 1);
+    }
+    return -1;
+}
+MJD SpState sp_state_of(const SpNode& n) {
+    SpState s;
+    s.h.mp = n.k0;
+    s.h.sz = n.k1 & 0xFFFFFFFFFFFFull;
+    s.w.mp = n.k2;
+    s.w.sz = n.k3 & 0xFFFFFFFFFFFFull;
+    s.akas = (u32)((n.k1 >> 48) & 7) | ((u32)((n.k3 >> 48) & 7) << 3);
+    return s;
+}
+
+// get_score (calc.rs:640-758).  `s` already contains the winning tile.
+__device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState& s, int win_tile, float scores[4]) {
+    AgariIn in;
+    in.tehai = s.h;
+    in.m = X->melds;
+    in.is_menzen = X->is_menzen != 0;
+    in.bakaze = X->bakaze;
+    in.jikaze = X->jikaze;
+    in.winning_tile = deaka(win_tile);
+    in.is_ron = false;
+    const bool is_oya = X->jikaze == T_E;
+    const int additional = X->is_menzen ? (X->prefer_riichi ? 2 : 1) : 0;
+    int num_doras = 0;
+    for (int i = 0; i < X->n_dora; i++) num_doras += s.h.get(tile_next(X->dora_ind[i]));
+    num_doras += __popc(s.akas & 7) + X->num_doras_in_fuuro;
+    num_doras &= 0xFF;
+    Agari a = agari_full(T, in, additional, num_doras);
+    if (a.kind == 0) return false;
+    if (a.kind == 2) {
+        float v = (float)tsumo_total(point_yakuman(is_oya, a.han), is_oya);
+        scores[0] = scores[1] = scores[2] = scores[3] = v;
+        return true;
+    }
+    const int fu = a.fu, han = a.han & 0xFF;
+    const bool assume_riichi = X->is_menzen && X->prefer_riichi;
+    if (assume_riichi && X->n_dora == 1) {
+        int n_ind[5] = {0, 0, 0, 0, 0}, sum_ind = 0;
+        for (int t = 0; t < 34; t++) {
+            int c = s.h.get(t);
+            if (c == 0) continue;
+            int ic = s.w.get(tile_prev(t));
+            n_ind[c] = (n_ind[c] + ic) & 0xFF;
+            sum_ind = (sum_ind + ic) & 0xFF;
+        }
+        int n_left = 0;
+        for (int t = 0; t < 34; t++) n_left += s.w.get(t);
+        n_left &= 0xFF;
+        float up[5];
+        up[0] = (float)((n_left - sum_ind) & 0xFF) / (float)n_left;
+        for (int i = 1; i < 5; i++) up[i] = (float)n_ind[i] / (float)n_left;
+        for (int i = 0; i < 4; i++) {
+            float sc = 0.f;
+            for (int j = 0; j < 5; j++) {
+                float p = up[j];
+                if (p == 0.f) continue;
+                float pt = (float)tsumo_total(point_calc(is_oya, fu, (han + i + j) & 0xFF), is_oya);
+                sc += pt * p;
+            }
+            scores[i] = sc;
+        }
+    } else if (assume_riichi && X->n_dora > 1) {
+        for (int i = 0; i < 4; i++) {
+            float sc = 0.f;
+            for (int j = 0; j < 13; j++) {
+                float p = SP_URADORA[X->n_dora - 1][j];
+                if (p == 0.f) continue;
+                float pt = (float)tsumo_total(point_calc(is_oya, fu, (han + i + j) & 0xFF), is_oya);
+                sc += pt * p;
+            }
+            scores[i] = sc;
+        }
+    } else {
+        for (int i = 0; i < 4; i++) scores[i] = (float)tsumo_total(point_calc(is_oya, fu, (han + i) & 0xFF), is_oya);
+    }
+    return true;
+}
+
+// Visit one 3n+1 state of shanten level L.
+//   EVAL == false : insert every child state (level L-1) into the hash set, appending fresh slots to the list.
+//   EVAL == true  : compute the state's tenpai/win/ev arrays (draw_without_tegawari_slow, calc.rs:454-561).
+template <bool EVAL>
+__device__ void sp_visit(const MjTablesDev& Tb, SpWork* W, SpCtx* X, int slot, int L) {
+    SpNode& node = W->node[slot];
+    const SpState S = sp_state_of(node);
+    const int ld3 = X->len_div3, T = X->T;
+    float tenpai[SP_T], win[SP_T], ev[SP_T];
+    if (EVAL)
+        for (int i = 0; i < SP_T; i++) tenpai[i] = win[i] = ev[i] = 0.f;
+
+    // get_draw_tiles (state.rs:132-174): which wall tiles lower the shanten number
+    u64 req = 0;
+    int sum_required = 0;
+    for (int t = 0; t < 34; t++) {
+        int c = S.w.get(t);
+        if (c == 0) continue;
+        Hand g = S.h;
+        g.inc(t);
+        if (calc_all(Tb, g, ld3) - L == -1) {
+            req |= BIT(t);
+            sum_required += c;
+        }
+    }
+    sum_required &= 0xFF;
+    const float* nt = X->not_tsumo[min(sum_required, 123)];
+
+    for (int t = 0; t < 34; t++) {
+        if (!((req >> t) & 1)) continue;
+        const int cnt = S.w.get(t);
+        const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+        // draw entries in the reference's order: plain tile (count-1 if the aka is still in the wall), then the aka
+        for (int variant = 0; variant < 2; variant++) {
+            int tile, count;
+            if (!aka_in_wall) {
+                if (variant == 1) break;
+                tile = t;
+                count = cnt;
+            } else if (variant == 0) {
+                if (cnt < 2) continue;
+                tile = t;
+                count = cnt - 1;
+            } else {
+                tile = akaize(t);
+                count = 1;
+            }
+            SpState S1 = S;
+            sp_deal(S1, tile);
+            float nx_tenpai[SP_T], nx_win[SP_T], nx_ev[SP_T], scores[4];
+            bool is_scores = false;
+            if (L > 0) {
+                // discard_slow (calc.rs:570-637) over the shanten-keeping discards of S1
+                int max_values[SP_T], max_tiles[SP_T];
+                if (EVAL)
+                    for (int i = 0; i < SP_T; i++) {
+                        nx_tenpai[i] = nx_win[i] = nx_ev[i] = -3.40282347e+38f;
+                        max_values[i] = INT_MIN;
+                        max_tiles[i] = T_UNK;
+                    }
+                for (int d = 0; d < 34; d++) {
+                    int c = S1.h.get(d);
+                    if (c == 0) continue;
+                    Hand g = S1.h;
+                    g.dec(d);
+                    if (calc_all(Tb, g, ld3) - (L - 1) != 0) continue;
+                    int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+                    if (d == T_5M && (S1.akas & 1) && c == 1) dt = T_5MR;
+                    else if (d == T_5P && (S1.akas & 2) && c == 1) dt = T_5PR;
+                    else if (d == T_5S && (S1.akas & 4) && c == 1) dt = T_5SR;
+                    SpState S2 = S1;
+                    sp_discard(S2, dt);
+                    if (!EVAL) {
+                        bool fresh;
+                        int cs = sp_insert(W, X, S2, fresh);
+                        if (fresh && cs >= 0) {
+                            int idx = atomicAdd(&X->n_list, 1);
+                            if (idx < SP_CAP) W->list[idx] = (u32)cs;
+                            else X->overflow = 1;
+                        }
+                    } else {
+                        int cs = sp_lookup(W, S2);
+                        if (cs < 0) { X->overflow = 1; continue; }
+                        const SpNode& ch = W->node[cs];
+                        for (int i = 0; i < T; i++) {
+                            int value = (int)ch.ev[i];  // `as i32` (maximize_win_prob = false)
+                            if (value > max_values[i] || (value == max_values[i] && cmp_discard_priority(dt, max_tiles[i]) > 0)) {
+                                nx_tenpai[i] = ch.tenpai[i];
+                                nx_win[i] = ch.win[i];
+                                nx_ev[i] = ch.ev[i];
+                                max_values[i] = value;
+                                max_tiles[i] = dt;
+                            }
+                        }
+                    }
+                }
+                if (!EVAL) continue;
+            } else {
+                if (!EVAL) continue;
+                if (!sp_get_score(Tb, X, S1, tile, scores)) continue;
+                is_scores = true;
+            }
+            // accumulate (calc.rs:486-548)
+            const float* tp = X->tsumo_prob[count - 1];
+            const bool assume_riichi = X->is_menzen && X->prefer_riichi;
+            for (int i = 0; i < T; i++) {
+                const float m = nt[i];
+                if (m == 0.f) break;
+                for (int j = i; j < T; j++) {
+                    const float n = nt[j];
+                    if (n == 0.f) break;
+                    const float prob = tp[j] * n / m;
+                    if (is_scores) {
+                        int han_plus = (int)(assume_riichi && X->calc_double_riichi && i == 0) + (int)(assume_riichi && j == i) +
+                                       (int)(X->calc_haitei && j == T - 1);
+                        win[i] += prob;
+                        ev[i] += prob * scores[han_plus];
+                    } else {
+                        if (L == 1) tenpai[i] += prob;
+                        if (j < T - 1) {
+                            if (L > 1) tenpai[i] += prob * nx_tenpai[j + 1];
+                            win[i] += prob * nx_win[j + 1];
+                            ev[i] += prob * nx_ev[j + 1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (EVAL)
+        for (int i = 0; i < SP_T; i++) {
+            node.tenpai[i] = tenpai[i];
+            node.win[i] = win[i];
+            node.ev[i] = ev[i];
+        }
+}
+
+MJD u64 sp_required_tiles(const MjTablesDev& Tb, const SpState& s, int ld3, int& num) {  // state.rs:176-200
+    const int sh = calc_all(Tb, s.h, ld3);
+    u64 m = 0;
+    num = 0;
+    for (int t = 0; t < 34; t++) {
+        int c = s.w.get(t);
+        if (c == 0) continue;
+        Hand g = s.h;
+        g.inc(t);
+        if (calc_all(Tb, g, ld3) < sh) {
+            m |= BIT(t);
+            num += c;
+        }
+    }
+    num &= 0xFF;
+    return m;
+}
+MJD int f32_total_cmp(float a, float b) {
+    int x = __float_as_int(a), y = __float_as_int(b);
+    x ^= (int)((unsigned)(x >> 31) >> 1);
+    y ^= (int)((unsigned)(y >> 31) >> 1);
+    return (x > y) - (x < y);
+}
+
+__global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
+    __shared__ SpCtx X;
+    __shared__ TableOne st;
+    __shared__ int s_row;
+    SpWork* W = P.work + blockIdx.x;
+    const int tid = threadIdx.x;
+    constexpr int O_SP = 889;  // Lay<4>::sp
+
+    // the hash tags must start empty
+    for (int i = tid; i < SP_CAP; i += SP_THREADS) W->tag[i] = 0ull;
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) s_row = atomicAdd(P.queue, 1);
+        __syncthreads();
+        const int row = s_row;
+        if (row >= P.n_rows) break;
+        const uint32_t desc = P.rows[row];
+        const int table = ROW_TABLE(desc), p = ROW_SEAT(desc);
+        {
+            const float4* src = reinterpret_cast<const float4*>(P.snap + table);
+            float4* d4 = reinterpret_cast<float4*>(&st);
+            for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += SP_THREADS) d4[i] = src[i];
+        }
+        __syncthreads();
+        LaneT<TableOne> L = {&st, 0, &P.tables};
+        float* out = P.obs + (size_t)row * (1012 * 34);
+        const u32 cans = F1(cans, p);
+        const bool can_discard0 = (cans & CAN_DISCARD) != 0;
+        const Hand h0 = load_hand(L, p);
+        const int ld3 = F1(len_div3, p);
+        const int tiles_left = F(tiles_left);
+
+        // ---- single_player_tables preconditions (agent_helper.rs:509-530) + real_time_shanten (:467-503)
+        int cur_shanten;
+        {
+            const int sh = F1(shanten, p);
+            if (!can_discard0) cur_shanten = sh;
+            else if (sh > 0) cur_shanten = F1(has_next_shanten, p) ? sh - 1 : sh;
+            else if (F1(last_self_tsumo, p) != MJ_NONE) cur_shanten = ((F1(waits, p) >> deaka(F1(last_self_tsumo, p))) & 1) ? -1 : 0;
+            else cur_shanten = calc_all(P.tables, h0, ld3);
+        }
+        int tsumos_left, calc_haitei;
+        if (can_discard0) {
+            tsumos_left = tiles_left / 4;
+            calc_haitei = tiles_left % 4 == 0;
+        } else {
+            int target = (F1(cans_target, p) + 4 - p) & 3;
+            int at_next = max(tiles_left - (4 - target), 0);
+            tsumos_left = at_next / 4;
+            calc_haitei = at_next % 4 == 0;
+        }
+        const bool ok = tiles_left >= 4 && cur_shanten >= 0 && tsumos_left >= 1;
+        __syncthreads();
+        if (!ok) {
+            // Err path (obs_repr.rs:612-623): max EV = minimal tsumo agari points, everything else zero
+            if (tid == 0) {
+                float v = 0.f;
+                if (cans & CAN_AGARI) {
+                    const bool is_ron = (cans & CAN_RON_AGARI) != 0;
+                    if ((is_ron && (cans & CAN_RON_AGARI)) || (cans & CAN_TSUMO_AGARI)) {
+                        Point pt;
+                        if (seat_agari_points(L, p, is_ron, 0, pt)) v = (float)tsumo_total(pt, p == (F(kyoku) & 3));
+                    }
+                }
+                X.cand_ev0[0] = v;
+            }
+            __syncthreads();
+            const float v = X.cand_ev0[0];
+            if (tid < 34) {
+                out[(O_SP + 0) * 34 + tid] = fminf(fmaxf(v, 0.f), 100000.f) / 100000.f;
+                out[(O_SP + 1) * 34 + tid] = fminf(fmaxf(v, 0.f), 30000.f) / 30000.f;
+            }
+            __syncthreads();
+            continue;
+        }
+
+        // ---- calculator set-up (agent_helper.rs:532-586, calc.rs:84-167)
+        bool can_discard = can_discard0;
+        SpState root;
+        root.h = h0;
+        int akas_hand = F1(akas_in_hand, p) & 7;
+        const bool after_riichi = can_discard0 && accepted(L, p);
+        const int last_tsumo = F1(last_self_tsumo, p);
+        if (after_riichi) {
+            root.h.dec(deaka(last_tsumo));
+            if (is_aka(last_tsumo)) akas_hand &= ~(1 << (last_tsumo - T_5MR));
+            can_discard = false;
+        }
+        {
+            Hand w = {0, 0};
+            for (int t = 0; t < 34; t++) {
+                int seen = F1(pub_seen, t) + h0.get(t);  // tiles_seen = public + own hand (incl. the tile just drawn)
+                int left = (4 - seen) & 7;
+                for (int k = 0; k < left; k++) w.inc(t);
+            }
+            root.w = w;
+            int akas_seen = (F(pub_aka_seen) | F1(akas_in_hand, p)) & 7;
+            root.akas = (u32)akas_hand | ((u32)(~akas_seen & 7) << 3);
+        }
+        if (tid == 0) {
+            X.melds = load_melds(L, p);
+            X.len_div3 = ld3;
+            X.bakaze = table_bakaze(L);
+            X.jikaze = seat_jikaze(L, p);
+            X.is_menzen = (F1(pflags, p) & PF_IS_MENZEN) != 0;
+            X.n_dora = F(n_dora_ind);
+            for (int i = 0; i < 5; i++) X.dora_ind[i] = i < X.n_dora ? F1(dora_ind, i) : T_UNK;
+            // num_doras_in_fuuro (agent_helper.rs:533-545) = doras_owned[0] - doras in hand - akas in hand
+            int nf = 0;
+            if (!(X.is_menzen && F1(ankan_n, p) == 0)) {
+                int fn = F1(fuuro_n, p);
+                for (int k = 0; k < fn; k++)
+                    for (int j = 0; j < 4; j++) {
+                        int t = F3(fuuro, p, k, j);
+                        if (t != MJ_NONE) nf += dora_factor(L, deaka(t)) + (is_aka(t) ? 1 : 0);
+                    }
+                int na = F1(ankan_n, p);
+                for (int k = 0; k < na; k++) {
+                    int t = F2(ankan, p, k);
+                    nf += 4 * dora_factor(L, t) + ((t == T_5M || t == T_5P || t == T_5S) ? 1 : 0);
+                }
+            }
+            X.num_doras_in_fuuro = nf & 0xFF;
+            X.prefer_riichi = F1(scores, p) >= 1000;
+            X.calc_double_riichi = can_discard0 && (F1(pflags, p) & PF_CAN_W_RIICHI) != 0;
+            X.calc_haitei = calc_haitei;
+            X.T = tsumos_left;
+            int n_left = 0;
+            for (int t = 0; t < 34; t++) n_left += root.w.get(t);
+            X.n_left = n_left & 0xFF;
+            X.n_list = 0;
+            X.overflow = 0;
+            X.n_cand = 0;
+            for (int l = 0; l < 5; l++) X.lvl_begin[l] = X.lvl_end[l] = 0;
+        }
+        __syncthreads();
+        const int T = X.T, n_left = X.n_left;
+        // build_tsumo_prob_table / build_not_tsumo_prob_table (calc.rs:135-167)
+        if (tid < 4 * SP_T) {
+            int i = tid / SP_T, j = tid % SP_T;
+            X.tsumo_prob[i][j] = j < T ? (float)(i + 1) / (float)(n_left - j) : 0.f;
+        }
+        if (tid < 124) {
+            float* r = X.not_tsumo[tid];
+            for (int j = 0; j < SP_T; j++) r[j] = 0.f;
+            if (tid <= 122 && tid < n_left + 1) {
+                r[0] = 1.f;
+                int lim = min(T - 1, n_left - tid);
+                for (int j = 0; j < lim; j++) r[j + 1] = r[j] * (float)(n_left - tid - j) / (float)(n_left - j);
+            }
+        }
+        __syncthreads();
+
+        // ---- candidates: analyze_discard / analyze_draw (+ *_simple for shanten > 3)  (calc.rs:205-312)
+        if (tid == 0) {
+            int n = 0;
+            if (can_discard) {
+                for (int d = 0; d < 34; d++) {
+                    int c = root.h.get(d);
+                    if (c == 0) continue;
+                    Hand g = root.h;
+                    g.dec(d);
+                    int diff = calc_all(P.tables, g, ld3) - cur_shanten;
+                    int dt = d;
+                    if (d == T_5M && (root.akas & 1) && c == 1) dt = T_5MR;
+                    else if (d == T_5P && (root.akas & 2) && c == 1) dt = T_5PR;
+                    else if (d == T_5S && (root.akas & 4) && c == 1) dt = T_5SR;
+                    if (cur_shanten <= 3 && diff != 0) continue;
+                    X.cand_tile[n] = dt;
+                    X.cand_down[n] = cur_shanten > 3 && diff == 1;
+                    n++;
+                }
+            } else {
+                X.cand_tile[0] = T_UNK;
+                X.cand_down[0] = 0;
+                n = 1;
+            }
+            X.n_cand = n;
+        }
+        __syncthreads();
+        const int n_cand = X.n_cand;
+        if (tid < n_cand) {
+            SpState s = root;
+            if (can_discard) sp_discard(s, X.cand_tile[tid]);
+            int num;
+            X.cand_req[tid] = sp_required_tiles(P.tables, s, ld3, num);
+            X.cand_nreq[tid] = num;
+            X.cand_slot[tid] = -1;
+            X.cand_tp0[tid] = X.cand_wp0[tid] = X.cand_ev0[tid] = 0.f;
+        }
+        __syncthreads();
+
+        const bool with_probs = cur_shanten <= 3;
+        if (with_probs) {
+            // root states = level cur_shanten
+            if (tid == 0) {
+                for (int c = 0; c < n_cand; c++) {
+                    SpState s = root;
+                    if (can_discard) sp_discard(s, X.cand_tile[c]);
+                    bool fresh;
+                    int slot = sp_insert(W, &X, s, fresh);
+                    X.cand_slot[c] = slot;
+                    if (fresh && slot >= 0) W->list[X.n_list++] = (u32)slot;
+                }
+                X.lvl_begin[cur_shanten] = 0;
+                X.lvl_end[cur_shanten] = X.n_list;
+            }
+            __syncthreads();
+            // expand top-down
+            for (int lv = cur_shanten; lv >= 1; lv--) {
+                const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
+                for (int i = b + tid; i < e; i += SP_THREADS) sp_visit<false>(P.tables, W, &X, (int)W->list[i], lv);
+                __syncthreads();
+                if (tid == 0) {
+                    X.lvl_begin[lv - 1] = e;
+                    X.lvl_end[lv - 1] = min(X.n_list, SP_CAP);
+                }
+                __syncthreads();
+            }
+            // evaluate bottom-up
+            for (int lv = 0; lv <= cur_shanten; lv++) {
+                const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
+                for (int i = b + tid; i < e; i += SP_THREADS) sp_visit<true>(P.tables, W, &X, (int)W->list[i], lv);
+                __syncthreads();
+            }
+        }
+
+        // ---- sort (calc.rs:181-188 / 196-199) + encode (obs_repr.rs:564-692)
+        if (tid == 0) {
+            for (int c = 0; c < n_cand; c++) {
+                X.order[c] = c;
+                int slot = X.cand_slot[c];
+                if (with_probs && slot >= 0) {  // Candidate::from clamps (candidate.rs:46-70); shanten 0 => tenpai = 1
+                    const SpNode& nd = W->node[slot];
+                    float tp = cur_shanten == 0 ? 1.f : nd.tenpai[0];
+                    X.cand_tp0[c] = fminf(fmaxf(tp, 0.f), 1.f);
+                    X.cand_wp0[c] = fminf(fmaxf(nd.win[0], 0.f), 1.f);
+                    X.cand_ev0[c] = fmaxf(nd.ev[0], 0.f);
+                }
+            }
+            auto cmp = [&](int l, int r, int by) -> int {  // candidate.rs:73-106, by: 0 EV, 3 NotShantenDown
+                if (X.cand_tile[l] == X.cand_tile[r]) return 0;
+                int o;
+                if (by <= 0 && (o = f32_total_cmp(X.cand_ev0[l], X.cand_ev0[r])) != 0) return o;
+                if (by <= 1 && (o = f32_total_cmp(X.cand_wp0[l], X.cand_wp0[r])) != 0) return o;
+                if (by <= 2 && (o = f32_total_cmp(X.cand_tp0[l], X.cand_tp0[r])) != 0) return o;
+                if (!X.cand_down[l] && X.cand_down[r]) return 1;
+                if (X.cand_down[l] && !X.cand_down[r]) return -1;
+                if (X.cand_nreq[l] != X.cand_nreq[r]) return X.cand_nreq[l] < X.cand_nreq[r] ? -1 : 1;
+                return cmp_discard_priority(X.cand_tile[l], X.cand_tile[r]);
+            };
+            const int by = with_probs ? 0 : 3;
+            for (int i = 1; i < n_cand; i++) {  // stable insertion sort, descending: before(l, r) = cmp(r, l) < 0
+                int v = X.order[i], j = i - 1;
+                while (j >= 0 && cmp(X.order[j], v, by) < 0) {
+                    X.order[j + 1] = X.order[j];
+                    j--;
+                }
+                X.order[j + 1] = v;
+            }
+            // the candidate with the most required tiles: Iterator::max_by keeps the LAST maximum (obs_repr.rs:589-596)
+            int best = -1;
+            for (int k = 0; k < n_cand; k++) {
+                int c = X.order[k];
+                if (best < 0 || cmp(c, best, 3) >= 0) best = c;
+            }
+            X.lvl_begin[4] = best;
+        }
+        __syncthreads();
+        {
+            const int first = n_cand > 0 ? X.order[0] : -1;
+            const float max_ev = (with_probs && first >= 0 && T > 0) ? X.cand_ev0[first] : 0.f;
+            if (tid < 34) {
+                out[(O_SP + 0) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 100000.f) / 100000.f;
+                out[(O_SP + 1) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 30000.f) / 30000.f;
+            }
+            // required tiles
+            if (can_discard0 && !after_riichi) {
+                for (int c = tid / 34; c < n_cand; c += SP_THREADS / 34) {
+                    int t = tid % 34;
+                    if (tid >= (SP_THREADS / 34) * 34) break;
+                    if ((X.cand_req[c] >> t) & 1) {
+                        int dtid = deaka(X.cand_tile[c]);
+                        out[(O_SP + 2 + (X.cand_down[c] ? 34 : 0) + dtid) * 34 + t] = 1.f;
+                    }
+                }
+                if (tid == 0 && X.lvl_begin[4] >= 0) out[(O_SP + 70) * 34 + deaka(X.cand_tile[X.lvl_begin[4]])] = 1.f;
+            } else if (can_discard0) {
+                // discard after riichi: `cans.can_discard` is still true in the encoder (obs_repr.rs:580), the single
+                // candidate's tile was patched to the drawn tile (agent_helper.rs:588-590)
+                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 2 + deaka(last_tsumo)) * 34 + tid] = 1.f;
+                if (tid == 0) out[(O_SP + 70) * 34 + deaka(last_tsumo)] = 1.f;
+            } else {
+                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 71) * 34 + tid] = 1.f;
+            }
+            // sp table (obs_repr.rs:644-692)
+            const float ev_scale = max_ev < 1.f ? 0.f : 1.f / max_ev;
+            bool table_ok = with_probs && first >= 0 && X.cand_tp0[first] > 0.f;
+            if (table_ok) {
+                if (can_discard0) {
+                    for (int c = tid / SP_T; c < n_cand; c += SP_THREADS / SP_T) {
+                        if (tid >= (SP_THREADS / SP_T) * SP_T) break;
+                        const int turn = tid % SP_T;
+                        if (turn >= T) continue;
+                        const SpNode& nd = W->node[X.cand_slot[c]];
+                        // take_while(p > 0) on the clamped tenpai probs
+                        bool alive = true;
+                        for (int q = 0; q <= turn && alive; q++) {
+                            float tpq = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.tenpai[q], 0.f), 1.f);
+                            alive = tpq > 0.f;
+                        }
+                        if (!alive) continue;
+                        const int col = after_riichi ? deaka(last_tsumo) : deaka(X.cand_tile[c]);
+                        float tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.tenpai[turn], 0.f), 1.f);
+                        float wpv = fminf(fmaxf(nd.win[turn], 0.f), 1.f);
+                        float evv = fmaxf(nd.ev[turn], 0.f);
+                        out[(O_SP + 72 + turn) * 34 + col] = tpv;
+                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = wpv;
+                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = fminf(evv * ev_scale, 1.f);
+                    }
+                } else {
+                    const SpNode& nd = W->node[X.cand_slot[first]];
+                    for (int w = tid; w < SP_T * 34; w += SP_THREADS) {
+                        const int turn = w / 34, col = w % 34;
+                        if (turn >= T) continue;
+                        bool alive = true;
+                        for (int q = 0; q <= turn && alive; q++) {
+                            float tpq = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.tenpai[q], 0.f), 1.f);
+                            alive = tpq > 0.f;
+                        }
+                        if (!alive) continue;
+                        float tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.tenpai[turn], 0.f), 1.f);
+                        float wpv = fminf(fmaxf(nd.win[turn], 0.f), 1.f);
+                        float evv = fmaxf(nd.ev[turn], 0.f);
+                        out[(O_SP + 72 + turn) * 34 + col] = tpv;
+                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = wpv;
+                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = fminf(evv * ev_scale, 1.f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- reset the hash set for the next row
+        {
+            const int n = min(X.n_list, SP_CAP);
+            for (int i = tid; i < n; i += SP_THREADS) W->tag[W->list[i]] = 0ull;
+            if (X.overflow && tid == 0) {
+                atomicAdd(&P.err[0], 1ull);
+                for (int i = 0; i < SP_CAP; i++) W->tag[i] = 0ull;
+            }
+        }
+        __syncthreads();
+    }
+}

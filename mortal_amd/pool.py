@@ -122,7 +122,8 @@ class TablePool:
     def counters(self):
         out = (C.c_uint64 * 8)()
         check(lib.mj_counters(self.h, out, _stream()))
-        return dict(steps=out[0], games=out[1], errors=out[2], decisions=out[3], quick=out[4], cycles=out[5])
+        return dict(steps=out[0], games=out[1], errors=out[2], decisions=out[3], quick=out[4], cycles=out[5],
+                    sp_overflow=out[6])
 
     def results(self):
         scores = np.zeros((self.n_games_total, 4), dtype=np.int32)

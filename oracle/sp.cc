@@ -9,6 +9,8 @@
 
 namespace mjo {
 
+long g_sp_stats[8] = {0,0,0,0,0,0,0,0};  // debug: draw-cache inserts per shanten level [0..3], discard [4..7]
+
 namespace {
 
 constexpr int SHANTEN_THRES = 3;                 // calc.rs:13
@@ -371,6 +373,7 @@ struct Calc {  // calc.rs:64-78
             }
         }
         draw_cache[shanten][state] = vals;
+        g_sp_stats[shanten]++;
         return vals;
     }
 
@@ -420,6 +423,7 @@ struct Calc {  // calc.rs:64-78
             }
         }
         discard_cache[shanten][state] = vals;
+        g_sp_stats[4 + shanten]++;
         return vals;
     }
 

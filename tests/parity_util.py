@@ -8,8 +8,67 @@ def default_seeds(n, start=10000):
     return [(start + g // 4, KEY) for g in range(n)]
 
 
+DISCARD_ROW = {1: 923, 2: 927, 3: 919, 4: 874}  # first row of the 5-row discard block (obs_repr.rs:431-476)
+
+
+def greedy_actions(masks, rows, cycle, obs_rows3, seed):
+    """A test policy that plays towards tenpai so that riichi / ron / tsumo / furiten / SP paths are exercised:
+    always agari, usually riichi, discards that lower (else keep) the shanten number, occasional calls.
+    obs_rows3 = the [n, 3, 34] slice (discard candidates, keep-shanten, next-shanten rows) of the encoded obs."""
+    masks = np.asarray(masks, dtype=bool)
+    n = len(masks)
+    act = np.full(n, 45, dtype=np.int32)
+    if n == 0:
+        return act
+    rows = np.asarray(rows, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) ^ (rows[:, 0] * np.uint64(0xD1B54A32D192ED03)) ^ (rows[:, 1] * np.uint64(0x8CB92BA72F3D8DD7))
+             ^ (rows[:, 2] * np.uint64(0xAEF17502108EF2D9)) ^ (np.array([cycle], dtype=np.uint64) * np.uint64(0x94D049BB133111EB)))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    h = (x >> np.uint64(20)).astype(np.int64)
+    deaka = np.arange(37)
+    deaka[34:] = [4, 13, 22]
+
+    def pick(cands, hv):
+        idx = np.flatnonzero(cands)
+        return int(idx[hv % len(idx)])
+
+    for r in range(n):
+        m, hv = masks[r], int(h[r])
+        if rows[r, 2]:  # kan-select row: any legal tile
+            act[r] = pick(m, hv)
+            continue
+        if m[43]:
+            act[r] = 43
+        elif m[37] and hv % 8 != 0:
+            act[r] = 37
+        elif m[44] and hv % 2 == 0:
+            act[r] = 44
+        elif m[42] and m[:37].any() and hv % 3 == 0:
+            act[r] = 42
+        elif m[:37].any():
+            legal = m[:37]
+            nxt = legal & (obs_rows3[r, 2][deaka] > 0)
+            keep = legal & (obs_rows3[r, 1][deaka] > 0)
+            act[r] = pick(nxt if nxt.any() else keep if keep.any() else legal, hv // 7)
+        else:  # reaction to a discard
+            if m[41] and hv % 3 == 0:
+                act[r] = 41
+            elif m[38:41].any() and hv % 4 == 0:
+                act[r] = 38 + pick(m[38:41], hv // 5)
+            elif m[42] and hv % 2 == 0:
+                act[r] = 42
+            else:
+                act[r] = 45
+        assert m[act[r]], (r, act[r])
+    return act
+
+
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
-                 policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True):
+                 policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
+                 policy="random"):
     """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch."""
     import torch
 
@@ -92,7 +151,11 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
                                                          if k not in ("wall", "kawa")))
                 raise AssertionError("\n".join(lines))
             stats["obs_checked"] += n
-        act = oracle.random_actions(masks_o, rows_o, cycle, seed=policy_seed)
+        if policy == "greedy":
+            d0 = DISCARD_ROW[version]
+            act = greedy_actions(masks_o, rows_o, cycle, obs_g[:, d0:d0 + 3].cpu().numpy(), policy_seed)
+        else:
+            act = oracle.random_actions(masks_o, rows_o, cycle, seed=policy_seed)
         arena.commit(act)
         actions = torch.from_numpy(act).to(pool.device)
         stats["cycles"] += 1

@@ -13,10 +13,10 @@ def test_lockstep_v3_256_tables(oracle):
     assert st["scores_checked"] == 256 and st["obs_checked"] > 100000
 
 
-def test_lockstep_v4_nonsp_rows(oracle):
-    """v4 layout: rows 0..888 (everything except the SP block) bit-exact; masks every cycle."""
-    st = parity_util.run_lockstep(oracle, 64, version=4, max_cycles=3000, obs_every=7)
-    assert st["scores_checked"] == 64
+def test_lockstep_v4_full_obs_with_sp(oracle):
+    """v4: all 1012 rows incl. the SP block (rows 889..1011, f32 bit-exact), sampled every 7th cycle; masks every cycle."""
+    st = parity_util.run_lockstep(oracle, 64, version=4, max_cycles=3000, obs_every=7, sp_rows_checked=True)
+    assert st["scores_checked"] == 64 and st["counters"]["sp_overflow"] == 0
 
 
 def test_lockstep_4096_tables_masks_scores(oracle):
@@ -24,3 +24,18 @@ def test_lockstep_4096_tables_masks_scores(oracle):
     st = parity_util.run_lockstep(oracle, 4096, version=3, max_cycles=3000, compare_obs=False)
     assert st["scores_checked"] == 4096
     assert st["counters"]["steps"] == st["oracle_steps"]
+
+
+def test_lockstep_greedy_policy_v3(oracle):
+    """A shanten-greedy policy (always agari, mostly riichi, calls) drives the games through tenpai / riichi / ron /
+    furiten / kan paths that uniform-random play rarely reaches; v3 obs compared every cycle."""
+    st = parity_util.run_lockstep(oracle, 256, version=3, max_cycles=3000, obs_every=1, policy="greedy")
+    assert st["scores_checked"] == 256
+
+
+def test_lockstep_greedy_policy_v4_sp(oracle):
+    """Same policy with obs v4: hands sit at 0..3 shanten most of the time, so the SP block is exercised with real
+    probability tables (f32 bit-exact)."""
+    st = parity_util.run_lockstep(oracle, 32, version=4, max_cycles=3000, obs_every=4, policy="greedy",
+                                  sp_rows_checked=True)
+    assert st["scores_checked"] == 32 and st["counters"]["sp_overflow"] == 0
