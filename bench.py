@@ -9,7 +9,8 @@ Default workload: 65,536 tables per GPU, uniform-random legal policy on device, 
 (obs version per --version), finished tables refilled with fresh seeds so the table count stays constant.
 Synthetic fixed-seed deals: game g uses seed (10000 + g/4, 0xd5dfaa4cef265cd7) (docs/src/perf/strength.md:19).
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 1 --steps 30 --warmup 10            # obs v4 (SP tables included; SP dominates the cycle)
+  python bench.py --gpus 1 --steps 200 --warmup 30 --version 3  # obs v3 (no SP block): the env-step + encode path alone
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 """
@@ -62,10 +63,10 @@ def cpu_baseline(version, budget_s=12.0, n_tables=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU")
-    ap.add_argument("--version", type=int, default=3, help="obs version (consts.rs:20-28)")
+    ap.add_argument("--version", type=int, default=4, help="obs version (consts.rs:20-28); 4 = reference default incl. SP tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -169,6 +169,59 @@ MJD int calc_all(const MjTablesDev& T, Hand h, int len_div3) {  // shanten.rs:13
     return s;
 }
 
+
+// ---------------------------------------------------------------- incremental shanten (for the SP kernel)
+// A hand that differs from a base hand by +1/-1 tiles only changes the table row of the touched suit(s), so the
+// base rows are loaded once and every probe costs one gather instead of four (and the gathers of a whole probe
+// batch are independent, i.e. in flight together).
+struct ShBase {
+    u32 key[4];
+    u64 row[4];
+    int pairs, kinds, kpairs, kkinds;  // chitoi / kokushi counters (shanten.rs:104-137)
+};
+MJD int sh_suit(int t) { return t < 9 ? 0 : t < 18 ? 1 : t < 27 ? 2 : 3; }
+MJD u32 sh_pow(int t) {  // weight of tile t inside its suit key (first tile most significant)
+    const int e = t < 27 ? 8 - t % 9 : 6 - (t - 27);
+    u32 p = 1;
+    for (int i = 0; i < e; i++) p *= 5;
+    return p;
+}
+MJD u64 sh_load(const MjTablesDev& T, int suit, u32 key) {
+    return suit < 3 ? sh_row(T.suhai, T.n_suhai, key) : sh_row(T.jihai, T.n_jihai, key);
+}
+MJD ShBase sh_base(const MjTablesDev& T, Hand h) {
+    ShBase b;
+    b.key[0] = suit_key9(h.mp);
+    b.key[1] = suit_key9(h.mp >> 27);
+    b.key[2] = suit_key9(h.sz);
+    b.key[3] = suit_key7(h.sz >> 27);
+#pragma unroll
+    for (int i = 0; i < 4; i++) b.row[i] = sh_load(T, i, b.key[i]);
+    b.pairs = b.kinds = b.kpairs = b.kkinds = 0;
+#pragma unroll
+    for (int t = 0; t < 34; t++) {
+        int c = h.get(t);
+        b.kinds += c > 0;
+        b.pairs += c >= 2;
+        if ((YAOKYUU_MASK >> t) & 1) {
+            b.kkinds += c > 0;
+            b.kpairs += c >= 2;
+        }
+    }
+    return b;
+}
+MJD int sh_eval(u64 rm, u64 rp, u64 rs, u64 rz, int len_div3, int pairs, int kinds, int kpairs, int kkinds) {
+    int v[10];
+    sh_unpack(rm, v);
+    sh_add_suhai(v, rp, len_div3);
+    sh_add_suhai(v, rs, len_div3);
+    int s = sh_add_jihai_final(v, rz, len_div3) - 1;
+    if (s <= 0 || len_div3 < 4) return s;
+    s = min(s, 7 - pairs + (kinds >= 7 ? 0 : 7 - kinds) - 1);
+    if (s > 0) s = min(s, 14 - kkinds - (kpairs > 0) - 1);
+    return s;
+}
+
 // ---------------------------------------------------------------- points (point.rs:13-112)
 // The reference's match table equals the textbook formula on its whole domain (its own test,
 // point.rs:121-153, asserts exactly that), so the device uses the closed form.
@@ -270,15 +323,15 @@ MJDN u32 tile14_and_key(Hand h, u8 tile14[14]) {
     for (int i = n14; i < 14; i++) tile14[i] = 0;
     return key;
 }
-MJD int agari_find(const MjTablesDev& T, u32 key) {  // index or -1 (binary search over sorted keys)
-    int lo = 0, hi = (int)T.n_agari;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        u32 k = T.agari_keys[mid];
-        if (k < key) lo = mid + 1;
-        else hi = mid;
+MJD int agari_find(const MjTablesDev& T, u32 key) {  // index or -1; hashed (1-2 gathers instead of a 14-step bisection)
+    u32 pos = (key * 0x9E3779B1u) >> 17;
+    for (int probe = 0; probe < 32768; probe++) {
+        const u64 e = T.agari_hash[pos];
+        if (e == 0ull) return -1;
+        if ((u32)(e >> 32) == key) return (int)(u32)e - 1;
+        pos = (pos + 1) & 32767;
     }
-    return (lo < (int)T.n_agari && T.agari_keys[lo] == key) ? lo : -1;
+    return -1;
 }
 
 // One decomposition of the concealed part + the caller's melds (agari.rs:100-124, 287-761).

@@ -151,10 +151,16 @@ int mj_tables_upload(const void* payload, size_t size) {
         keys[i] = rec[0];
         for (int k = 0; k < 5; k++) divs[(size_t)i * 5 + k] = rec[1 + k];
     }
-    uint64_t *d_s, *d_j;
+    std::vector<uint64_t> ahash(32768, 0);
+    for (uint32_t i = 0; i < na; i++) {
+        uint32_t pos = (keys[i] * 0x9E3779B1u) >> 17;
+        while (ahash[pos]) pos = (pos + 1) & 32767;
+        ahash[pos] = ((uint64_t)keys[i] << 32) | (uint64_t)(i + 1);
+    }
+    uint64_t *d_s, *d_j, *d_h;
     uint32_t *d_k, *d_d;
-    if (upload(suhai, &d_s) || upload(jihai, &d_j) || upload(keys, &d_k) || upload(divs, &d_d)) return -1;
-    g_tables.dev = {d_s, ns, d_j, nj, d_k, d_d, na};
+    if (upload(suhai, &d_s) || upload(jihai, &d_j) || upload(keys, &d_k) || upload(divs, &d_d) || upload(ahash, &d_h)) return -1;
+    g_tables.dev = {d_s, ns, d_j, nj, d_k, d_h, d_d, na};
     auto g = build_gather();
     g_tables.n_gather = (int)g.size();
     if (upload(g, &g_tables.gather)) return -1;
@@ -377,8 +383,8 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
             P->sp_grid = 1024;
             HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
             HIP_OK(hipMalloc(&P->sp_queue, sizeof(int)));
-            HIP_OK(hipMalloc(&P->sp_err, 2 * sizeof(unsigned long long)));
-            HIP_OK(hipMemset(P->sp_err, 0, 2 * sizeof(unsigned long long)));
+            HIP_OK(hipMalloc(&P->sp_err, 24 * sizeof(unsigned long long)));
+            HIP_OK(hipMemset(P->sp_err, 0, 24 * sizeof(unsigned long long)));
         }
         HIP_OK(hipMemsetAsync(P->sp_queue, 0, sizeof(int), s));
         SpParams sp;
@@ -390,6 +396,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         sp.work = P->sp_work;
         sp.queue = P->sp_queue;
         sp.err = P->sp_err;
+        sp.prof = getenv("MJ_SP_PROF") ? P->sp_err : nullptr;
         int grid = n < P->sp_grid ? n : P->sp_grid;
         hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
         HIP_OK(hipGetLastError());
@@ -437,10 +444,13 @@ int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
     for (int i = 0; i < 8; i++) out[i] = tmp[i];
     out[5] = P->cycles;
     if (P->sp_err) {
-        unsigned long long e2[2];
+        unsigned long long e2[24];
         HIP_OK(hipMemcpy(e2, P->sp_err, sizeof e2, hipMemcpyDeviceToHost));
         out[6] = e2[0];
         out[7] = e2[1];
+        if (getenv("MJ_SP_PROF"))
+            fprintf(stderr, "[sp prof] rows %llu setup %llu expand %llu evalL0 %llu evalL>0 %llu encode %llu states %llu (wall_clock64 ticks, 100 MHz)\n",
+                    e2[1], e2[2], e2[3], e2[4], e2[5], e2[6], e2[7]);
     }
     return 0;
 }

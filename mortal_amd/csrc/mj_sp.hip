@@ -23,14 +23,19 @@
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
 
+#define SP_POOL (SP_CAP * 32)   // child-slot pool entries per workgroup
 struct SpNode {                // one 3n+1 state
     u64 k0, k1, k2, k3;        // hand.mp | hand.sz + akas_in_hand<<48 | wall.mp | wall.sz + akas_in_wall<<48
     float tenpai[SP_T], win[SP_T], ev[SP_T];
-};
+    u32 child_off;             // expansion results, reused by the evaluation pass:
+    u64 req;                   //   required draw tiles,
+    u64 keep[34];              //   per required tile t the shanten-keeping discards of h + t,
+};                             //   and the children's hash slots in pool[child_off ..] (order: t, variant, d ascending)
 struct SpWork {                // per-workgroup scratch in HBM (persistent workgroups)
     u64 tag[SP_CAP];
     SpNode node[SP_CAP];
     u32 list[SP_CAP];          // slots grouped by level: level L occupies [lvl_begin[L], lvl_end[L])
+    unsigned short pool[SP_POOL];
 };
 
 struct SpParams {
@@ -41,7 +46,8 @@ struct SpParams {
     float* obs;                // [n_rows][1012][34]; rows 889.. are zero on entry (written by mj_k_encode<4>)
     SpWork* work;              // [gridDim.x]
     int* queue;                // dynamic row queue (zeroed before launch)
-    unsigned long long* err;   // [0] hash-capacity overflows, [1] tag collisions with different keys
+    unsigned long long* prof;  // NULL or [24] phase timers
+    unsigned long long* err;   // [0] hash-capacity overflows, [1] rows; cycle sums: [2] setup [3] expand [4] eval L0 [5] eval L>0 [6] encode; [7] states
 };
 
 // algo/data/uradora_prob_table.txt (values restated; calc.rs:17)
@@ -104,7 +110,9 @@ struct SpCtx {  // per-decision constants (LDS)
     // level bookkeeping
     int lvl_begin[5], lvl_end[5];
     int n_list;
+    int n_pool;
     int overflow;
+    unsigned long long* prof;  // optional phase timers (MJ_SP_PROF)
     // candidates
     int n_cand;
     int cand_tile[SP_MAX_CAND], cand_slot[SP_MAX_CAND], cand_down[SP_MAX_CAND], cand_nreq[SP_MAX_CAND];
@@ -229,38 +237,188 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
     return true;
 }
 
-// Visit one 3n+1 state of shanten level L.
-//   EVAL == false : insert every child state (level L-1) into the hash set, appending fresh slots to the list.
-//   EVAL == true  : compute the state's tenpai/win/ev arrays (draw_without_tegawari_slow, calc.rs:454-561).
+// Per-team LDS scratch of sp_visit_team.
+struct SpTeam {
+    u64 rowt[34];            // table row of (h + t) in suit(t)
+    u64 rowd[34];            // table row of (h - d) in suit(d)
+    u64 keep[34];            // per required tile t: set of shanten-keeping discards of h + t
+    int coff[34];            // per required tile t: offset of its first child inside the node's child list
+    float sc[34][2][4];      // level 0: get_score() of every (winning tile, variant), one lane each
+    u8 tiles[36];            // required tiles in ascending order
+};
+
+// Visit one 3n+1 state of shanten level L with a TEAM of 32 lanes (half a wavefront).
+//   EVAL == false (L >= 1): find the required draws and shanten-keeping discards, insert every child state (level
+//                  L-1) into the hash set, and leave req / keep / child slots in the node for the evaluation pass.
+//   EVAL == true : compute the state's tenpai/win/ev arrays (draw_without_tegawari_slow, calc.rs:454-561).
+// The kernel is bound by 8-byte table / hash-set gathers (64-byte sectors), so the work is organised in PHASES whose
+// gathers are independent and in flight together, and nothing is gathered twice:
+//   A  34 "+t" shanten probes, one lane per tile (1 gather each)          -> required set (ballot); rows of h-d
+//   B  (required t, d) "-d" probes; only same-suit pairs need a gather    -> keep[t] (LDS atomicOr)
+//   C  children (t, variant, keep d): hash-set insert                     -> child slots in the pool
+//   D  (EVAL) per required tile in the reference's order: fold the children like discard_slow (calc.rs:570-637) and
+//      accumulate like calc.rs:486-548.  The per-turn arrays live one turn per lane (lane i owns index i), so every
+//      accumulator is a register and the `next[j+1]` operands arrive by intra-team shuffles; per accumulator the
+//      additions happen in the reference's order (draw tiles ascending, aka after its plain tile, j ascending),
+//      hence bit-identical f32 sums.
 template <bool EVAL>
-__device__ void sp_visit(const MjTablesDev& Tb, SpWork* W, SpCtx* X, int slot, int L) {
+__device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
+    const int ln = threadIdx.x & 31;
+    const int sh32 = threadIdx.x & 32;  // bit offset of this team inside the wave's 64-bit ballot
     SpNode& node = W->node[slot];
     const SpState S = sp_state_of(node);
     const int ld3 = X->len_div3, T = X->T;
-    float tenpai[SP_T], win[SP_T], ev[SP_T];
-    if (EVAL)
-        for (int i = 0; i < SP_T; i++) tenpai[i] = win[i] = ev[i] = 0.f;
-
-    // get_draw_tiles (state.rs:132-174): which wall tiles lower the shanten number
+    float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
     u64 req = 0;
-    int sum_required = 0;
-    for (int t = 0; t < 34; t++) {
-        int c = S.w.get(t);
-        if (c == 0) continue;
-        Hand g = S.h;
-        g.inc(t);
-        if (calc_all(Tb, g, ld3) - L == -1) {
-            req |= BIT(t);
-            sum_required += c;
+    int child_base = 0;
+
+    if (!EVAL || L == 0) {
+        // ---- A
+        const ShBase B = sh_base(Tb, S.h);
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int t = ln + 32 * rnd;
+            bool is_req = false;
+            if (t < 34) {
+                u64 r = 0, rd = 0;
+                const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
+                if (!EVAL && hc > 0) rd = sh_load(Tb, st, B.key[st] - sh_pow(t));
+                if (S.w.get(t) > 0) {
+                    r = sh_load(Tb, st, B.key[st] + sh_pow(t));
+                    int sh = sh_eval(st == 0 ? r : B.row[0], st == 1 ? r : B.row[1], st == 2 ? r : B.row[2], st == 3 ? r : B.row[3],
+                                     ld3, B.pairs + (hc == 1), B.kinds + (hc == 0), B.kpairs + (yao && hc == 1),
+                                     B.kkinds + (yao && hc == 0));
+                    is_req = sh - L == -1;
+                }
+                TM->rowt[t] = r;
+                TM->rowd[t] = rd;
+                TM->keep[t] = 0;
+            }
+            const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull;
+            req |= bal << (32 * rnd);
         }
+        req &= (1ull << 34) - 1;
+        int n_tiles = 0;
+        for (int t = 0; t < 34; t++)
+            if ((req >> t) & 1) {
+                if (ln == 0) TM->tiles[n_tiles] = (u8)t;
+                n_tiles++;
+            }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+
+        if (!EVAL) {
+            // ---- B: (required t, d) probes
+            for (int item = ln; item < n_tiles * 34; item += 32) {
+                const int t = TM->tiles[item / 34], d = item % 34;
+                const int c = S.h.get(d) + (d == t);  // count of d after the draw
+                if (c == 0) continue;
+                const int st = sh_suit(t), sd = sh_suit(d);
+                const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
+                const u64 row_t = TM->rowt[t];
+                u64 r0 = B.row[0], r1 = B.row[1], r2 = B.row[2], r3 = B.row[3];
+                const u64 rd = sd == st ? (d == t ? B.row[st] : sh_load(Tb, st, B.key[st] + sh_pow(t) - sh_pow(d))) : TM->rowd[d];
+                if (st == 0) r0 = row_t; else if (st == 1) r1 = row_t; else if (st == 2) r2 = row_t; else r3 = row_t;
+                if (sd == 0) r0 = rd; else if (sd == 1) r1 = rd; else if (sd == 2) r2 = rd; else r3 = rd;
+                const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
+                const int kpairs = B.kpairs + (yt && hct == 1) - (yd && c == 2), kkinds = B.kkinds + (yt && hct == 0) - (yd && c == 1);
+                if (sh_eval(r0, r1, r2, r3, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0)
+                    atomicOr((unsigned long long*)&TM->keep[t], 1ull << d);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // child list layout: for each required tile, `variants(t) * popcount(keep[t])` slots
+            int total = 0;
+            for (int ti = 0; ti < n_tiles; ti++) {
+                const int t = TM->tiles[ti];
+                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
+                if (ln == 0) TM->coff[t] = total;
+                total += nvar * __popcll(TM->keep[t]);
+            }
+            if (ln == 0) {
+                child_base = atomicAdd(&X->n_pool, total);
+                if (child_base + total > SP_POOL) { X->overflow = 1; child_base = 0; }
+                node.child_off = (u32)child_base;
+                node.req = req;
+            }
+            child_base = __shfl(child_base, 0, 32);
+            if (ln < 2) {
+                for (int t = ln; t < 34; t += 2) node.keep[t] = TM->keep[t];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // ---- C: children
+            for (int item = ln; item < n_tiles * 68; item += 32) {
+                const int t = TM->tiles[item / 68], variant = (item / 34) & 1, d = item % 34;
+                const u64 kp = TM->keep[t];
+                if (!((kp >> d) & 1)) continue;
+                const int cnt = S.w.get(t);
+                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                int tile, vidx;  // vidx: index of this variant among the tile's existing draw entries
+                if (!aka_in_wall) { if (variant == 1) continue; tile = t; vidx = 0; }
+                else if (variant == 0) { if (cnt < 2) continue; tile = t; vidx = 0; }
+                else { tile = akaize(t); vidx = cnt >= 2 ? 1 : 0; }
+                SpState S2 = S;
+                sp_deal(S2, tile);
+                const int c = S2.h.get(d);
+                int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+                if (d == T_5M && (S2.akas & 1) && c == 1) dt = T_5MR;
+                else if (d == T_5P && (S2.akas & 2) && c == 1) dt = T_5PR;
+                else if (d == T_5S && (S2.akas & 4) && c == 1) dt = T_5SR;
+                sp_discard(S2, dt);
+                bool fresh;
+                const int cs = sp_insert(W, X, S2, fresh);
+                if (fresh && cs >= 0) {
+                    int idx = atomicAdd(&X->n_list, 1);
+                    if (idx < SP_CAP) W->list[idx] = (u32)cs;
+                    else X->overflow = 1;
+                }
+                const int pos = child_base + TM->coff[t] + vidx * __popcll(kp) + __popcll(kp & ((1ull << d) - 1));
+                if (pos < SP_POOL) W->pool[pos] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
+            }
+            return;
+        }
+        // level 0 (tenpai): score every winning draw (calc.rs:640-758), one lane per (tile, variant); keep[t] bit v
+        // records that variant v of tile t has a yaku
+        for (int item = ln; item < n_tiles * 2; item += 32) {
+            const int t = TM->tiles[item >> 1], variant = item & 1;
+            const int cnt = S.w.get(t);
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            int tile;
+            if (!aka_in_wall) { if (variant == 1) continue; tile = t; }
+            else if (variant == 0) { if (cnt < 2) continue; tile = t; }
+            else tile = akaize(t);
+            SpState S1 = S;
+            sp_deal(S1, tile);
+            float scv[4];
+            if (sp_get_score(Tb, X, S1, tile, scv)) {
+                for (int q = 0; q < 4; q++) TM->sc[t][variant][q] = scv[q];
+                atomicOr((unsigned long long*)&TM->keep[t], 1ull << variant);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    } else {
+        req = node.req;
+        child_base = (int)node.child_off;
     }
+
+    // ---- D (EVAL)
+    int sum_required = 0;
+    for (int t = 0; t < 34; t++)
+        if ((req >> t) & 1) sum_required += S.w.get(t);
     sum_required &= 0xFF;
     const float* nt = X->not_tsumo[min(sum_required, 123)];
-
+    const float my_m = ln < T ? nt[ln] : 0.f;  // not_tsumo_probs[i] of this lane's turn
+    const bool assume_riichi = X->is_menzen && X->prefer_riichi;
+    int cpos = child_base;  // running position inside the node's child list
     for (int t = 0; t < 34; t++) {
         if (!((req >> t) & 1)) continue;
         const int cnt = S.w.get(t);
         const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+        const u64 keep = L > 0 ? node.keep[t] : 0ull;
+        const int nk = __popcll(keep);
         // draw entries in the reference's order: plain tile (count-1 if the aka is still in the wall), then the aka
         for (int variant = 0; variant < 2; variant++) {
             int tile, count;
@@ -276,94 +434,101 @@ __device__ void sp_visit(const MjTablesDev& Tb, SpWork* W, SpCtx* X, int slot, i
                 tile = akaize(t);
                 count = 1;
             }
-            SpState S1 = S;
-            sp_deal(S1, tile);
-            float nx_tenpai[SP_T], nx_win[SP_T], nx_ev[SP_T], scores[4];
+            float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;  // lane i: folded values at turn i
+            float scores[4] = {0.f, 0.f, 0.f, 0.f};
             bool is_scores = false;
             if (L > 0) {
-                // discard_slow (calc.rs:570-637) over the shanten-keeping discards of S1
-                int max_values[SP_T], max_tiles[SP_T];
-                if (EVAL)
-                    for (int i = 0; i < SP_T; i++) {
-                        nx_tenpai[i] = nx_win[i] = nx_ev[i] = -3.40282347e+38f;
-                        max_values[i] = INT_MIN;
-                        max_tiles[i] = T_UNK;
-                    }
-                for (int d = 0; d < 34; d++) {
-                    int c = S1.h.get(d);
-                    if (c == 0) continue;
-                    Hand g = S1.h;
-                    g.dec(d);
-                    if (calc_all(Tb, g, ld3) - (L - 1) != 0) continue;
-                    int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
-                    if (d == T_5M && (S1.akas & 1) && c == 1) dt = T_5MR;
-                    else if (d == T_5P && (S1.akas & 2) && c == 1) dt = T_5PR;
-                    else if (d == T_5S && (S1.akas & 4) && c == 1) dt = T_5SR;
-                    SpState S2 = S1;
-                    sp_discard(S2, dt);
-                    if (!EVAL) {
-                        bool fresh;
-                        int cs = sp_insert(W, X, S2, fresh);
-                        if (fresh && cs >= 0) {
-                            int idx = atomicAdd(&X->n_list, 1);
-                            if (idx < SP_CAP) W->list[idx] = (u32)cs;
-                            else X->overflow = 1;
-                        }
-                    } else {
-                        int cs = sp_lookup(W, S2);
-                        if (cs < 0) { X->overflow = 1; continue; }
-                        const SpNode& ch = W->node[cs];
-                        for (int i = 0; i < T; i++) {
-                            int value = (int)ch.ev[i];  // `as i32` (maximize_win_prob = false)
-                            if (value > max_values[i] || (value == max_values[i] && cmp_discard_priority(dt, max_tiles[i]) > 0)) {
-                                nx_tenpai[i] = ch.tenpai[i];
-                                nx_win[i] = ch.win[i];
-                                nx_ev[i] = ch.ev[i];
-                                max_values[i] = value;
-                                max_tiles[i] = dt;
+                // discard_slow (calc.rs:570-637): fold the children in ascending discard order
+                const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;  // akas_in_hand after the draw
+                int max_value = INT_MIN, max_tile = T_UNK;
+                u64 rest = keep;
+                for (int k0 = 0; k0 < nk; k0 += 4) {
+                    // gather up to 4 children first (independent loads in flight together), then fold them in order
+                    float ct[4], cw[4], ce[4];
+                    int cdt[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        cdt[q] = -1;
+                        if (k0 + q < nk) {
+                            const int d = __ffsll((long long)rest) - 1;
+                            rest &= rest - 1;
+                            const int cs = W->pool[min(cpos + k0 + q, SP_POOL - 1)];
+                            if (cs != 0xFFFF) {
+                                const int c = S.h.get(d) + (d == t);
+                                int dt = d;
+                                if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
+                                else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
+                                else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
+                                cdt[q] = dt;
+                                if (ln < T) {
+                                    const SpNode& ch = W->node[cs];
+                                    ct[q] = ch.tenpai[ln];
+                                    cw[q] = ch.win[ln];
+                                    ce[q] = ch.ev[ln];
+                                }
+                            } else {
+                                X->overflow = 1;
                             }
                         }
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (cdt[q] < 0 || ln >= T) continue;
+                        const int value = (int)ce[q];  // `as i32` (maximize_win_prob = false)
+                        if (value > max_value || (value == max_value && cmp_discard_priority(cdt[q], max_tile) > 0)) {
+                            nx_t = ct[q];
+                            nx_w = cw[q];
+                            nx_e = ce[q];
+                            max_value = value;
+                            max_tile = cdt[q];
+                        }
+                    }
                 }
-                if (!EVAL) continue;
+                cpos += nk;
             } else {
-                if (!EVAL) continue;
-                if (!sp_get_score(Tb, X, S1, tile, scores)) continue;
+                if (!((TM->keep[t] >> variant) & 1)) continue;  // no yaku with this tile
+#pragma unroll
+                for (int q = 0; q < 4; q++) scores[q] = TM->sc[t][variant][q];
                 is_scores = true;
             }
-            // accumulate (calc.rs:486-548)
+            // accumulate (calc.rs:486-548): lane i runs j = i .. T-1; `break`s become predicates (not_tsumo is monotone)
             const float* tp = X->tsumo_prob[count - 1];
-            const bool assume_riichi = X->is_menzen && X->prefer_riichi;
-            for (int i = 0; i < T; i++) {
-                const float m = nt[i];
-                if (m == 0.f) break;
-                for (int j = i; j < T; j++) {
-                    const float n = nt[j];
-                    if (n == 0.f) break;
-                    const float prob = tp[j] * n / m;
+            float vt[SP_T], vw[SP_T], ve[SP_T], pr[SP_T];
+#pragma unroll
+            for (int j = 0; j < SP_T; j++) {
+                // next[j + 1] comes from lane j + 1 (only used when j < T - 1)
+                vt[j] = __shfl(nx_t, (j + 1) & 31, 32);
+                vw[j] = __shfl(nx_w, (j + 1) & 31, 32);
+                ve[j] = __shfl(nx_e, (j + 1) & 31, 32);
+                const float n = nt[j];  // rows are zero-padded beyond T
+                pr[j] = (j < T && j >= ln && ln < T && my_m != 0.f && n != 0.f) ? tp[j] * n / my_m : -1.f;
+            }
+#pragma unroll
+            for (int j = 0; j < SP_T; j++) {
+                const float prob = pr[j];
+                if (prob >= 0.f) {  // probabilities are never negative; -1 marks "not part of this lane's sum"
                     if (is_scores) {
-                        int han_plus = (int)(assume_riichi && X->calc_double_riichi && i == 0) + (int)(assume_riichi && j == i) +
+                        int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
                                        (int)(X->calc_haitei && j == T - 1);
-                        win[i] += prob;
-                        ev[i] += prob * scores[han_plus];
+                        acc_w += prob;
+                        acc_e += prob * scores[han_plus];
                     } else {
-                        if (L == 1) tenpai[i] += prob;
+                        if (L == 1) acc_t += prob;
                         if (j < T - 1) {
-                            if (L > 1) tenpai[i] += prob * nx_tenpai[j + 1];
-                            win[i] += prob * nx_win[j + 1];
-                            ev[i] += prob * nx_ev[j + 1];
+                            if (L > 1) acc_t += prob * vt[j];
+                            acc_w += prob * vw[j];
+                            acc_e += prob * ve[j];
                         }
                     }
                 }
             }
         }
     }
-    if (EVAL)
-        for (int i = 0; i < SP_T; i++) {
-            node.tenpai[i] = tenpai[i];
-            node.win[i] = win[i];
-            node.ev[i] = ev[i];
-        }
+    if (ln < SP_T) {
+        node.tenpai[ln] = ln < T ? acc_t : 0.f;
+        node.win[ln] = ln < T ? acc_w : 0.f;
+        node.ev[ln] = ln < T ? acc_e : 0.f;
+    }
 }
 
 MJD u64 sp_required_tiles(const MjTablesDev& Tb, const SpState& s, int ld3, int& num) {  // state.rs:176-200
@@ -390,10 +555,11 @@ MJD int f32_total_cmp(float a, float b) {
     return (x > y) - (x < y);
 }
 
-__global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
+__global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ TableOne st;
     __shared__ int s_row;
+    __shared__ SpTeam s_team[SP_THREADS / 32];
     SpWork* W = P.work + blockIdx.x;
     const int tid = threadIdx.x;
     constexpr int O_SP = 889;  // Lay<4>::sp
@@ -409,6 +575,7 @@ __global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
         if (row >= P.n_rows) break;
         const uint32_t desc = P.rows[row];
         const int table = ROW_TABLE(desc), p = ROW_SEAT(desc);
+        long long t_0 = wall_clock64(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0;
         {
             const float4* src = reinterpret_cast<const float4*>(P.snap + table);
             float4* d4 = reinterpret_cast<float4*>(&st);
@@ -522,7 +689,9 @@ __global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
             for (int t = 0; t < 34; t++) n_left += root.w.get(t);
             X.n_left = n_left & 0xFF;
             X.n_list = 0;
+            X.n_pool = 0;
             X.overflow = 0;
+            X.prof = P.prof;
             X.n_cand = 0;
             for (int l = 0; l < 5; l++) X.lvl_begin[l] = X.lvl_end[l] = 0;
         }
@@ -584,6 +753,8 @@ __global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
         __syncthreads();
 
         const bool with_probs = cur_shanten <= 3;
+        t_1 = wall_clock64();
+        t_2 = t_3 = t_4 = t_1;
         if (with_probs) {
             // root states = level cur_shanten
             if (tid == 0) {
@@ -602,7 +773,7 @@ __global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int i = b + tid; i < e; i += SP_THREADS) sp_visit<false>(P.tables, W, &X, (int)W->list[i], lv);
+                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<false>(P.tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 __syncthreads();
                 if (tid == 0) {
                     X.lvl_begin[lv - 1] = e;
@@ -610,12 +781,15 @@ __global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
                 }
                 __syncthreads();
             }
+            t_2 = wall_clock64();
             // evaluate bottom-up
             for (int lv = 0; lv <= cur_shanten; lv++) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int i = b + tid; i < e; i += SP_THREADS) sp_visit<true>(P.tables, W, &X, (int)W->list[i], lv);
+                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<true>(P.tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 __syncthreads();
+                if (lv == 0) t_3 = wall_clock64();
             }
+            t_4 = wall_clock64();
         }
 
         // ---- sort (calc.rs:181-188 / 196-199) + encode (obs_repr.rs:564-692)
@@ -733,6 +907,18 @@ __global__ __launch_bounds__(SP_THREADS) void mj_k_sp(SpParams P) {
             }
         }
         __syncthreads();
+        if (tid == 0) {
+            long long t_5 = wall_clock64();
+            atomicAdd(&P.err[1], 1ull);
+            atomicAdd(&P.err[2], (unsigned long long)(t_1 - t_0));
+            if (with_probs) {
+                atomicAdd(&P.err[3], (unsigned long long)(t_2 - t_1));
+                atomicAdd(&P.err[4], (unsigned long long)(t_3 - t_2));
+                atomicAdd(&P.err[5], (unsigned long long)(t_4 - t_3));
+                atomicAdd(&P.err[6], (unsigned long long)(t_5 - t_4));
+                atomicAdd(&P.err[7], (unsigned long long)X.n_list);
+            }
+        }
         // ---- reset the hash set for the next row
         {
             const int n = min(X.n_list, SP_CAP);

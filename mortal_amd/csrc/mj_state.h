@@ -175,6 +175,7 @@ struct MjTablesDev {
     const uint64_t* jihai;
     uint32_t n_jihai;
     const uint32_t* agari_keys;  // sorted
+    const uint64_t* agari_hash;  // open addressing, 2^15 slots: (key << 32) | (index + 1), 0 = empty
     const uint32_t* agari_divs;  // n x 5: n_div, div[4]
     uint32_t n_agari;
 };
