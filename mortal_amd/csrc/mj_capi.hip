@@ -161,6 +161,7 @@ int mj_tables_upload(const void* payload, size_t size) {
     uint32_t *d_k, *d_d;
     if (upload(suhai, &d_s) || upload(jihai, &d_j) || upload(keys, &d_k) || upload(divs, &d_d) || upload(ahash, &d_h)) return -1;
     g_tables.dev = {d_s, ns, d_j, nj, d_k, d_h, d_d, na};
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_mj_tables), &g_tables.dev, sizeof(MjTablesDev)));
     auto g = build_gather();
     g_tables.n_gather = (int)g.size();
     if (upload(g, &g_tables.gather)) return -1;
@@ -378,7 +379,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         P->events.push_back({e0, e1});
     }
     HIP_OK(hipGetLastError());
-    if (ep.version == 4) {  // SP block, rows 889..1011 (mj_sp.hip)
+    if (ep.version == 4 && !getenv("MJ_DEBUG_SKIP_SP")) {  // SP block, rows 889..1011 (mj_sp.hip)
         if (!P->sp_work) {
             P->sp_grid = 1024;
             HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));

@@ -38,7 +38,12 @@ struct EncParams {
 };
 
 #define ENC_THREADS 256
+#ifndef ENC_PASSES
 #define ENC_PASSES 4
+#endif
+#ifndef ENC_NT
+#define ENC_NT 1   // non-temporal stores for the plane stack: it is written once and never re-read by this kernel
+#endif
 
 // ---------------------------------------------------------------- static row map
 template <int V>
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
     }
     __syncthreads();
 
-    LaneT<TableOne> L = {st, 0, &P.tables};
+    LaneT<TableOne> L = {st, 0, &c_mj_tables};
     const u32 cans = F1(cans, p);
     const int shanten = F1(shanten, p);
     const int oya_abs = F(kyoku) & 3;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                     skip = true;
                     if (tid == 0 && !(F1(pflags, p) & PF_AT_FURITEN)) D->uncond = BIT(lst);  // raw id
                 }
-            } else if (calc_all(P.tables, h, ld3) == -1) {
+            } else if (calc_all(c_mj_tables, h, ld3) == -1) {
                 skip = true;
             }
         }
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                 g.dec(d);
                 if (t == d || g.get(t) == 4) continue;
                 g.inc(t);
-                if (calc_all(P.tables, g, ld3) > -1) continue;
+                if (calc_all(c_mj_tables, g, ld3) > -1) continue;
                 if ((disc >> t) & 1) atomicOr(&D->furiten[d], 1ull);
                 else if (F1(pub_seen, t) + h.get(t) < 4) {  // tiles_seen (hand before the discard) != 4
                     if (seat_has_yaku(L, p, g, t, true)) atomicOr(&D->yaku[d], 1ull);
@@ -526,9 +531,24 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         }
         __syncthreads();
         {
-            const int n4 = (r1 - r0) * 34 / 4;  // (r1-r0) is even except possibly the very last chunk
-            float4* d4 = dst + (size_t)r0 * 34 / 4;
-            for (int i = tid; i < n4; i += ENC_THREADS) d4[i] = smem4[i];
+            // Stream the tile out with 16-byte non-temporal stores (written once, never re-read by this kernel).
+            typedef float vfloat4 __attribute__((ext_vector_type(4)));
+            const int n4 = (r1 - r0) * 34 / 4;  // (r1-r0) is even
+            vfloat4* d4 = reinterpret_cast<vfloat4*>(dst + (size_t)r0 * 34 / 4);
+            const vfloat4* s4 = reinterpret_cast<const vfloat4*>(smem4);
+            // Rows are only 32-byte aligned (C*136 B per row), so shift the lane->address map by the chunk's offset
+            // inside its 128-byte line: every wave then stores a 1 KiB segment that starts on a 128-byte boundary and
+            // no cache line is written in two halves by two different waves (PMC WRITE_SIZE showed 1.37x the
+            // algorithmic bytes without this).
+            const int shift = (int)((reinterpret_cast<uintptr_t>(d4) >> 4) & 7);
+            for (int i = tid - shift; i < n4; i += ENC_THREADS) {
+                if (i < 0) continue;
+#if ENC_NT
+                __builtin_nontemporal_store(s4[i], d4 + i);
+#else
+                d4[i] = s4[i];
+#endif
+            }
         }
         __syncthreads();
     }

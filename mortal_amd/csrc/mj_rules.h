@@ -10,6 +10,11 @@
 #include "mj_algo.h"
 #include "mj_deal.h"
 
+// Lookup tables of the process (set once by mj_tables_upload).  A __constant__ symbol rather than a kernel argument:
+// taking the address of a by-value kernel parameter makes hipcc copy the WHOLE parameter struct to scratch in every
+// thread (160 B x 256 threads per encoded row showed up as +34 % HBM write traffic in the PMC counters).
+__constant__ MjTablesDev c_mj_tables;
+
 template <class BlockT>
 struct LaneT {  // a table viewed through lane `l` of a block (pool block in HBM, or the 1-lane LDS copy)
     BlockT* B;

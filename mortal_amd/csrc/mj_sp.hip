@@ -582,7 +582,10 @@ __global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
             for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += SP_THREADS) d4[i] = src[i];
         }
         __syncthreads();
-        LaneT<TableOne> L = {&st, 0, &P.tables};
+        LaneT<TableOne> L;
+        L.B = &st;
+        L.l = 0;
+        L.T = &c_mj_tables;
         float* out = P.obs + (size_t)row * (1012 * 34);
         const u32 cans = F1(cans, p);
         const bool can_discard0 = (cans & CAN_DISCARD) != 0;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
             if (!can_discard0) cur_shanten = sh;
             else if (sh > 0) cur_shanten = F1(has_next_shanten, p) ? sh - 1 : sh;
             else if (F1(last_self_tsumo, p) != MJ_NONE) cur_shanten = ((F1(waits, p) >> deaka(F1(last_self_tsumo, p))) & 1) ? -1 : 0;
-            else cur_shanten = calc_all(P.tables, h0, ld3);
+            else cur_shanten = calc_all(c_mj_tables, h0, ld3);
         }
         int tsumos_left, calc_haitei;
         if (can_discard0) {
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
                     if (c == 0) continue;
                     Hand g = root.h;
                     g.dec(d);
-                    int diff = calc_all(P.tables, g, ld3) - cur_shanten;
+                    int diff = calc_all(c_mj_tables, g, ld3) - cur_shanten;
                     int dt = d;
                     if (d == T_5M && (root.akas & 1) && c == 1) dt = T_5MR;
                     else if (d == T_5P && (root.akas & 2) && c == 1) dt = T_5PR;
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
             SpState s = root;
             if (can_discard) sp_discard(s, X.cand_tile[tid]);
             int num;
-            X.cand_req[tid] = sp_required_tiles(P.tables, s, ld3, num);
+            X.cand_req[tid] = sp_required_tiles(c_mj_tables, s, ld3, num);
             X.cand_nreq[tid] = num;
             X.cand_slot[tid] = -1;
             X.cand_tp0[tid] = X.cand_wp0[tid] = X.cand_ev0[tid] = 0.f;
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<false>(P.tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<false>(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 __syncthreads();
                 if (tid == 0) {
                     X.lvl_begin[lv - 1] = e;
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
             // evaluate bottom-up
             for (int lv = 0; lv <= cur_shanten; lv++) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<true>(P.tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<true>(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 __syncthreads();
                 if (lv == 0) t_3 = wall_clock64();
             }
