@@ -202,10 +202,17 @@ int mjo_ps_call(void* h, int what, int arg) {
             case 2: return (int)s->rule_based_agari();
             case 3: return s->real_time_shanten();
             case 4: return s->yaokyuu_kind_count();
+            case 5: s->add_dora_indicator((u8)arg); return 0;
             default: return -2;
         }
     });
 }
+int mjo_ps_set_scores(void* h, const int* scores) {
+    PlayerState* s = (PlayerState*)h;
+    for (int i = 0; i < 4; i++) s->scores[i] = scores[i];
+    return 0;
+}
+int mjo_ps_get_rank(void* h, const int* scores_rel) { return ((PlayerState*)h)->get_rank(scores_rel); }
 int mjo_ps_agari_points(void* h, int is_ron, const u8* ura, int n_ura, int* out) {
     return guard([&] {
         Point p = ((PlayerState*)h)->agari_points(is_ron != 0, ura, n_ura);

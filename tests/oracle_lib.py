@@ -73,6 +73,8 @@ def lib():
     L.mjo_ps_snapshot.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_ps_uncond_tenpai.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_ps_kawa.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.mjo_ps_set_scores.argtypes = [C.c_void_p, C.c_void_p]
+    L.mjo_ps_get_rank.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_ps_scene.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.mjo_ps_decode_action.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.mjo_ps_sp_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -293,6 +295,14 @@ class PlayerState:
             real_time_shanten=int(o[234]), can_w_riichi=bool(o[235]), at_ippatsu=bool(o[236]),
             at_rinshan=bool(o[237]), scores=[int(x) for x in o[238:242]],
         )
+
+    def set_scores(self, scores):
+        a = np.array(scores, dtype=np.int32)
+        lib().mjo_ps_set_scores(self.h, ptr(a))
+
+    def get_rank(self, scores_rel):
+        a = np.array(scores_rel, dtype=np.int32)
+        return lib().mjo_ps_get_rank(self.h, ptr(a))
 
     def kawa(self, rel):
         out = np.zeros(64, dtype=np.uint64)
