@@ -30,16 +30,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 STATE_READ_BYTES = 1500  # per-decision state read
 
 
-def cpu_baseline(version, budget_s=12.0, n_tables=32):
-    """Oracle arena (CPU restatement, 1 thread) on a bounded sample of the same workload."""
-    import numpy as np  # noqa: F401
+def _cpu_worker(version, budget_s, n_tables, wid):
+    """One CPU worker process: oracle arenas of n_tables tables, back to back, until the time budget is spent."""
     import oracle_lib as O
 
     O.lib()
     t0 = time.perf_counter()
     cycles = rows_total = steps = batches = 0
     while time.perf_counter() - t0 < budget_s:
-        seeds = [(10000 + (batches * n_tables + g) // 4, KEY) for g in range(n_tables)]
+        g0 = (wid * 1000 + batches) * n_tables
+        seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(n_tables)]
         arena = O.Arena(seeds, deal_algo=0, enable_quick_eval=True, version=version, keep_log=False)
         cycle = 0
         while arena.n_live > 0 and time.perf_counter() - t0 < budget_s:
@@ -53,11 +53,37 @@ def cpu_baseline(version, budget_s=12.0, n_tables=32):
         steps += arena.steps
         cycles += cycle
         batches += 1
-    dt = time.perf_counter() - t0
-    return dict(value=steps / dt, unit="env steps/s", cores=1, kind="port",
-                sample=f"{batches} batches of {n_tables} tables, {cycles} cycles, {rows_total} decisions encoded "
-                       f"(obs v{version}), random-legal policy, {dt:.1f}s, oracle/libmjoracle.so on one thread; the "
-                       f"Rust reference is not buildable here (no rustc)")
+    return dict(steps=steps, cycles=cycles, rows=rows_total, arenas=batches, dt=time.perf_counter() - t0)
+
+
+def cpu_baseline(version, budget_s=12.0, n_tables=16):
+    """Oracle arena (CPU restatement) on a bounded sample of the same workload: one worker PROCESS per host core, each
+    running independent arenas (tables are independent, like the reference's rayon loop over games,
+    arena/game.rs:286-296).  value = sum over workers of steps_i / dt_i (all workers run concurrently)."""
+    import subprocess
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), "--version", str(version),
+                               "--cpu-budget", str(budget_s), "--cpu-tables", str(n_tables)],
+                              stdout=subprocess.PIPE, env=env) for w in range(cores)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode == 0:
+            res.append(json.loads(out.decode().strip().splitlines()[-1]))
+    if not res:
+        raise SystemExit("cpu baseline workers failed")
+    value = sum(r["steps"] / r["dt"] for r in res)
+    tot = {k: sum(r[k] for r in res) for k in ("steps", "cycles", "rows", "arenas")}
+    return dict(value=value, unit="env steps/s", cores=len(res), kind="port",
+                sample=f"{len(res)} processes (1 per core) x arenas of {n_tables} tables for {budget_s:.0f}s each: "
+                       f"{tot['arenas']} arenas, {tot['cycles']} cycles, {tot['steps']} env steps, {tot['rows']} decisions "
+                       f"encoded (obs v{version}), random-legal policy, oracle/libmjoracle.so; the Rust reference is "
+                       f"not buildable here (no rustc)")
 
 
 def main():
@@ -68,7 +94,13 @@ def main():
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU")
     ap.add_argument("--version", type=int, default=4, help="obs version (consts.rs:20-28); 4 = reference default incl. SP tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-tables", type=int, default=16, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker >= 0:
+        print(json.dumps(_cpu_worker(args.version, args.cpu_budget, args.cpu_tables, args.cpu_worker)))
+        return
 
     import numpy as np
     import torch
@@ -124,6 +156,7 @@ def main():
     dt = time.perf_counter() - t0
     c1 = pool.counters()
     enc_ms, enc_launches = pool.encode_timing(False)
+    sp_ms, sp_launches = pool.sp_timing()
     steps = c1["steps"] - c0["steps"]
     games = c1["games"] - c0["games"]
     code, tbl = pool.first_error()
@@ -148,6 +181,16 @@ def main():
     if rank == 0:
         bytes_per_row = C * 34 * 4 + 46 + STATE_READ_BYTES
         achieved = rows_timed * bytes_per_row / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
+        # HBM traffic of the encode kernel from the separate rocprofv3 --pmc passes (tools/profile_round.sh ->
+        # profiles/pmc_encode.json: WRITE_SIZE + 2 x FETCH_SIZE per decision), scaled to this run's rows per launch
+        traffic = traffic_src = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_encode.json")
+        if os.path.exists(pmc_file) and enc_launches and args.version == 4:
+            pmc = json.load(open(pmc_file))
+            if "write_bytes_per_decision" in pmc and "fetch_bytes_per_decision" in pmc:
+                per = pmc["write_bytes_per_decision"] + pmc["fetch_bytes_per_decision"]
+                traffic = per * rows_timed / enc_launches
+                traffic_src = f"profiles/pmc_encode.json ({per:.0f} B/decision, PMC passes at {pmc['tables']} tables)"
         line = {
             "metric": "env steps/sec (65536 parallel tables per GPU)",
             "value": steps / dt,
@@ -177,14 +220,21 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "B/launch",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_per_row * rows_timed / max(enc_launches, 1),
                 "bytes_per_decision": bytes_per_row,
                 "avg_launch_ms": enc_ms / max(enc_launches, 1),
                 "launches": enc_launches,
             },
+            # share of the timed wall clock spent in each timed kernel (HIP events); for obs v4 the SP-table kernel
+            # (single-player win/tenpai probability tables, obs rows 889..1011) dominates the cycle
+            "kernel_ms_per_step": {"mj_k_encode": enc_ms / args.steps, "mj_k_sp": sp_ms / args.steps,
+                                   "everything_else": (dt * 1e3 - enc_ms - sp_ms) / args.steps},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.version)
+            line["cpu_baseline"] = cpu_baseline(args.version, args.cpu_budget, args.cpu_tables)
         print(json.dumps(line))
     pool.close()
     if world > 1:

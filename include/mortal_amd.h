@@ -59,6 +59,11 @@ int mj_pool_set_refill(MjPool* pool, uint64_t nonce_stride);
 /* One arena cycle.  actions_dev[a] = int32 device array with one action id (0..45) per row of agent a's previous
  * batch (NULL on the first cycle or when that agent had no rows). */
 int mj_step(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_dev1, void* stream);
+/* Same, with the q-values of each batch (f32 device array [n_rows][46], agent/mortal.rs:126,150).  Needed when an agent
+ * was configured with enable_rule_based_agari_guard: an agari (action 43) that PlayerState::rule_based_agari
+ * (state/agent_helper.rs:251-368) rejects is replaced by the best other action, exactly as agent/mortal.rs:319-336. */
+int mj_step_q(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_dev1, const float* q_dev0,
+              const float* q_dev1, void* stream);
 
 /* Number of policy rows per agent produced by the last mj_step (synchronises `stream`). */
 int mj_rows_count(MjPool* pool, int32_t n_rows_out[2], void* stream);
@@ -69,6 +74,8 @@ const uint32_t* mj_rows_dev(MjPool* pool, int agent);
 int mj_encode(MjPool* pool, int agent, float* obs_dev, uint8_t* masks_dev, void* stream);
 /* Average duration (ms) of the encode kernel launches timed with HIP events since the last call, and their count. */
 int mj_encode_timing(MjPool* pool, int enable, double* total_ms_out, int64_t* launches_out);
+/* Same for the SP-table kernel (obs v4 rows 889..1011) launched by mj_encode; collected while encode timing is enabled. */
+int mj_sp_timing(MjPool* pool, double* total_ms_out, int64_t* launches_out);
 
 /* Uniform-random legal action per row, counter-based (seed, game id, seat, kan flag, cycle). */
 int mj_random_policy(MjPool* pool, int agent, const uint8_t* masks_dev, uint64_t seed, uint64_t cycle,

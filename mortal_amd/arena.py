@@ -43,9 +43,8 @@ def _check_engine(engine):
         raise TypeError("missing method react_batch")
     if getattr(engine, "is_oracle"):
         raise NotImplementedError("is_oracle engines (invisible obs, board.rs:680-782) are not supported yet")
-    if getattr(engine, "enable_rule_based_agari_guard"):
-        raise NotImplementedError("enable_rule_based_agari_guard is not supported on the device path yet")
-    return dict(name=str(engine.name), version=int(engine.version), quick=bool(engine.enable_quick_eval))
+    return dict(name=str(engine.name), version=int(engine.version), quick=bool(engine.enable_quick_eval),
+                guard=bool(getattr(engine, "enable_rule_based_agari_guard")))
 
 
 class BatchRunner:
@@ -63,35 +62,45 @@ class BatchRunner:
         self.pool = TablePool(n, version=self.cfg[0]["version"], deal_algo=deal_algo, device=str(self.device))
         self.pool.reset(seeds, game_ids=np.arange(n), agent_of_seat=agent_of_seat, n_games_total=n)
         for a, c in enumerate(self.cfg):
-            self.pool.configure(a, enable_quick_eval=c["quick"], version=c["version"])
+            self.pool.configure(a, enable_quick_eval=c["quick"], version=c["version"], enable_rule_based_agari_guard=c["guard"])
         if len(engines) == 1:
-            self.pool.configure(1, enable_quick_eval=self.cfg[0]["quick"], version=self.cfg[0]["version"])
+            self.pool.configure(1, enable_quick_eval=self.cfg[0]["quick"], version=self.cfg[0]["version"],
+                                enable_rule_based_agari_guard=self.cfg[0]["guard"])
         self.cycles = 0
 
     def _policy(self, agent, obs, masks):
+        """-> (actions int32 cuda [n], q_values f32 cuda [n,46] or None).  q-values are kept only for a guarded agent."""
         eng = self.engines[agent]
+        guard = self.cfg[agent]["guard"]
         if hasattr(eng, "react_batch_device"):
-            act = eng.react_batch_device(obs, masks)
-            return act.to(device=self.device, dtype=torch.int32).contiguous()
+            out = eng.react_batch_device(obs, masks)
+            act, q = out if isinstance(out, tuple) else (out, None)
+            if guard and q is None:
+                raise RuntimeError("enable_rule_based_agari_guard: react_batch_device must return (actions, q_values)")
+            q = q.to(device=self.device, dtype=torch.float32).contiguous() if guard else None
+            return act.to(device=self.device, dtype=torch.int32).contiguous(), q
         try:
-            actions, _q, _m, _g = eng.react_batch([_StackedBatch(obs)], [_StackedBatch(masks)], None)
+            actions, q_values, _m, _g = eng.react_batch([_StackedBatch(obs)], [_StackedBatch(masks)], None)
         except Exception as ex:  # same context string as agent/mortal.rs:149
             raise RuntimeError(f"failed to execute `react_batch` on Python engine: {ex}") from ex
         if len(actions) != obs.shape[0]:
             raise RuntimeError("react_batch returned a batch of the wrong size")
-        return torch.as_tensor(actions, dtype=torch.int32, device=self.device)
+        q = torch.as_tensor(q_values, dtype=torch.float32, device=self.device).contiguous() if guard else None
+        return torch.as_tensor(actions, dtype=torch.int32, device=self.device), q
 
     def run(self, max_cycles=1 << 30):
         pool = self.pool
         acts = [None, None]
+        qs = [None, None]
         n_games = pool.n_tables
         while True:
-            n = pool.step(acts[0], acts[1])
+            n = pool.step(acts[0], acts[1], qs[0], qs[1])
             self.cycles += 1
             code, tbl = pool.first_error() if (self.cycles & 63) == 0 else (0, -1)
             if code:
                 raise MortalAmdError(f"table {tbl}: illegal action or rule violation (error code {code})")
             acts = [None, None]
+            qs = [None, None]
             if n[0] == 0 and n[1] == 0:
                 c = pool.counters()
                 if c["games"] >= n_games:
@@ -101,7 +110,7 @@ class BatchRunner:
                 if n[a] == 0:
                     continue
                 obs, masks = pool.encode(a)
-                acts[a] = self._policy(a, obs, masks)
+                acts[a], qs[a] = self._policy(a, obs, masks)
             if self.cycles >= max_cycles:
                 raise MortalAmdError("max_cycles exceeded")
         code, tbl = pool.first_error()

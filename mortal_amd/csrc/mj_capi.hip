@@ -100,7 +100,7 @@ struct MjPool {
     bool rows_valid = false;
     // encode timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events, sp_events;
     double timed_ms = 0;
     int64_t timed_launches = 0;
 };
@@ -274,7 +274,6 @@ int mj_pool_configure(MjPool* P, int agent, int version, int enable_quick_eval, 
     }
     P->enable_quick_eval[agent] = enable_quick_eval;
     P->enable_agari_guard[agent] = enable_guard;
-    if (enable_guard) return fail("enable_rule_based_agari_guard is not supported on the device path yet");
     return 0;
 }
 int mj_pool_set_refill(MjPool* P, uint64_t stride) {
@@ -284,7 +283,12 @@ int mj_pool_set_refill(MjPool* P, uint64_t stride) {
 }
 
 int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
+    return mj_step_q(P, a0, a1, nullptr, nullptr, stream);
+}
+int mj_step_q(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, const float* q1, void* stream) {
     if (!P) return fail("null pool");
+    if ((P->enable_agari_guard[0] && a0 && !q0) || (P->enable_agari_guard[1] && a1 && !q1))
+        return fail("enable_rule_based_agari_guard needs the q-values of the batch (mj_step_q)");
     hipStream_t s = (hipStream_t)stream;
     StepParams sp;
     sp.blocks = P->blocks;
@@ -292,7 +296,8 @@ int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
     sp.tables = g_tables.dev;
     sp.actions[0] = a0;
     sp.actions[1] = a1;
-    sp.q_values[0] = sp.q_values[1] = nullptr;
+    sp.q_values[0] = q0;
+    sp.q_values[1] = q1;
     sp.deal_algo = P->deal_algo;
     for (int a = 0; a < 2; a++) {
         sp.enable_quick_eval[a] = P->enable_quick_eval[a];
@@ -399,7 +404,17 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         sp.err = P->sp_err;
         sp.prof = getenv("MJ_SP_PROF") ? P->sp_err : nullptr;
         int grid = n < P->sp_grid ? n : P->sp_grid;
+        hipEvent_t s0 = nullptr, s1 = nullptr;
+        if (P->timing) {
+            HIP_OK(hipEventCreate(&s0));
+            HIP_OK(hipEventCreate(&s1));
+            HIP_OK(hipEventRecord(s0, s));
+        }
         hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
+        if (P->timing) {
+            HIP_OK(hipEventRecord(s1, s));
+            P->sp_events.push_back({s0, s1});
+        }
         HIP_OK(hipGetLastError());
     }
     return 0;
@@ -422,6 +437,25 @@ int mj_encode_timing(MjPool* P, int enable, double* total_ms, int64_t* launches)
     P->timed_ms = 0;
     P->timed_launches = 0;
     P->timing = enable != 0;
+    return 0;
+}
+
+int mj_sp_timing(MjPool* P, double* total_ms, int64_t* launches) {
+    if (!P) return fail("null pool");
+    double tot = 0;
+    int64_t n = 0;
+    for (auto& e : P->sp_events) {
+        hipEventSynchronize(e.second);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e.first, e.second);
+        tot += ms;
+        n += 1;
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    P->sp_events.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
     return 0;
 }
 

@@ -608,7 +608,8 @@ template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
 
 // ---------------------------------------------------------------- scoring (agent_helper.rs:377-462)
 // Returns false (and flags an error) when the hand is not a hora hand.
-template <class LN> MJDN bool seat_agari_points(const LN& L, int s, bool is_ron, int n_ura, Point& out) {
+// `ura` = explicit ura indicators (rule-based agari guard); NULL = the table's own ura markers wall[61..].
+template <class LN> MJDN bool seat_agari_points(const LN& L, int s, bool is_ron, int n_ura, Point& out, const u8* ura = nullptr) {
     const u8 pf = F1(pflags, s);
     const bool is_oya = s == (F(kyoku) & 3);
     if (!is_ron && (pf & PF_CAN_W_RIICHI)) {  // tenhou / chiihou: single yakuman, no stacking
@@ -666,7 +667,7 @@ template <class LN> MJDN bool seat_agari_points(const LN& L, int s, bool is_ron,
     }
     if (acc) {
         for (int i = 0; i < n_ura; i++) {
-            int nx = tile_next(F1(wall, 61 + i));
+            int nx = tile_next(ura ? ura[i] : F1(wall, 61 + i));
             int c = h.get(nx);
             int na = F1(ankan_n, s);
             for (int k = 0; k < na; k++)
@@ -686,4 +687,83 @@ template <class LN> MJDN bool seat_agari_points(const LN& L, int s, bool is_ron,
     if (a.kind == 0) return false;
     out = agari_point(a, is_oya);
     return true;
+}
+
+// ---------------------------------------------------------------- rule-based agari guard (agent_helper.rs:251-368)
+// Whether seat s should take the agari it has been offered: always, except at all-last as a non-oya in 4th place when the
+// (optimistically ura-boosted) win would neither lift it out of last place nor end with everybody below 30000.
+template <class LN> MJDN bool rule_based_agari(const LN& L, int s) {
+    const u32 cans = F1(cans, s);
+    if (!(cans & (CAN_TSUMO_AGARI | CAN_RON_AGARI))) return false;
+    const bool is_ron = (cans & CAN_RON_AGARI) != 0;
+    const int target = F1(cans_target, s);
+    const int kyoku_abs = F(kyoku), bak = kyoku_abs >> 2, kyoku = kyoku_abs & 3, oya = kyoku;
+    const bool is_all_last = bak == 0 ? false : bak == 1 ? kyoku == 3 : true;
+    int sc[4];
+    for (int i = 0; i < 4; i++) sc[i] = F1(scores, i);
+    auto rank_of = [&](const int* v) {
+        int r = 0;
+        for (int a = 0; a < 4; a++)
+            if (v[a] > v[s] || (v[a] == v[s] && a < s)) r++;
+        return r;
+    };
+    auto all_below_30k = [](const int* v) { return v[0] < 30000 && v[1] < 30000 && v[2] < 30000 && v[3] < 30000; };
+    if (!is_all_last || oya == s || rank_of(sc) < 3) return true;
+    if (bak == 2) {
+        if (kyoku < 3) return true;
+    } else if (all_below_30k(sc)) {
+        return true;
+    }
+    Point pt;
+    bool ok;
+    if (accepted(L, s)) {
+        // optimistic ura: indicators chosen to hit the most numerous kinds of the hand first (:287-318)
+        Hand h = load_hand(L, s);
+        u8 full[34], seen[34];
+        for (int t = 0; t < 34; t++) {
+            full[t] = (u8)h.get(t);
+            seen[t] = (u8)(F1(pub_seen, t) + full[t]);
+        }
+        const int na = F1(ankan_n, s);
+        for (int k = 0; k < na; k++) full[F2(ankan, s, k)] += 4;
+        u8 ura[5];
+        int n_ura = 0;
+        const int n_ind = F(n_dora_ind);
+        bool done = false;
+        // stable order by count descending == scan counts 8..1 (a kind holds at most 4 + 4), ascending tile id inside
+        for (int c = 8; c >= 1 && !done; c--)
+            for (int t = 0; t < 34 && !done; t++) {
+                if (full[t] != c) continue;
+                const int ind = tile_prev(t);
+                for (;;) {
+                    if (n_ura >= n_ind) {
+                        done = true;
+                        break;
+                    }
+                    if (seen[ind] >= 4) break;
+                    ura[n_ura++] = (u8)ind;
+                    seen[ind]++;
+                }
+            }
+        ok = seat_agari_points(L, s, is_ron, n_ura, pt, ura);
+    } else {
+        ok = seat_agari_points(L, s, is_ron, 0, pt);
+    }
+    if (!ok) {
+        set_err(L, MJ_ERR_NOT_HORA);
+        return true;
+    }
+    const int honba = F(honba), kyotaku = F(kyotaku);
+    if (is_ron) {
+        sc[s] += pt.ron + kyotaku * 1000 + honba * 300;
+        sc[target] -= pt.ron + honba * 300;
+    } else {
+        sc[s] += pt.tsumo_oya + 2 * pt.tsumo_ko + kyotaku * 1000 + honba * 300;
+        for (int a = 0; a < 4; a++) {
+            if (a == s) continue;
+            sc[a] -= (a == oya ? pt.tsumo_oya : pt.tsumo_ko) + honba * 100;
+        }
+    }
+    if (all_below_30k(sc)) return true;
+    return rank_of(sc) < 3;
 }

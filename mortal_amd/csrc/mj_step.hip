@@ -513,8 +513,22 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
             const int mr = F1(main_row, s), kr = F1(kan_row, s);
             int action = P.actions[agent] ? P.actions[agent][mr] : 45;
             const int kan_tile = kr >= 0 ? P.actions[agent][kr] : -1;
-            if (P.enable_agari_guard[agent] && action == 43 && P.q_values[agent]) {
-                // rule-based agari guard (mortal.rs:319-336): handled by mj_rule_based_agari in a later round
+            if (P.enable_agari_guard[agent] && action == 43 && !rule_based_agari(L, s)) {
+                // mortal.rs:319-336: take the best alternative; q[43] := f32::MIN, then Iterator::max_by(total_cmp),
+                // which keeps the LAST of equal maxima
+                const float* q = P.q_values[agent] + (size_t)mr * 46;
+                int best = 0;
+                int best_key = INT_MIN;
+                for (int a = 0; a < 46; a++) {
+                    const float v = a == 43 ? -3.40282347e+38f : q[a];
+                    int k = __float_as_int(v);
+                    k ^= (int)((unsigned)(k >> 31) >> 1);  // f32::total_cmp key
+                    if (k >= best_key) {
+                        best_key = k;
+                        best = a;
+                    }
+                }
+                action = best;
             }
             rx[s] = decode_action(L, s, action, kan_tile);
         }

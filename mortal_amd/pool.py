@@ -75,14 +75,20 @@ class TablePool:
     def set_refill(self, nonce_stride):
         check(lib.mj_pool_set_refill(self.h, nonce_stride))
 
-    def step(self, actions0=None, actions1=None):
-        """One arena cycle; actionsN = int32 cuda tensor with one action per row of agent N's last batch."""
+    def step(self, actions0=None, actions1=None, q0=None, q1=None):
+        """One arena cycle; actionsN = int32 cuda tensor with one action per row of agent N's last batch; qN = that
+        batch's q-values (f32 cuda [n, 46]), needed only by an agent configured with the rule-based agari guard."""
         for a in (actions0, actions1):
             if a is not None:
                 assert a.is_cuda and a.dtype == torch.int32 and a.is_contiguous()
+        for q in (q0, q1):
+            if q is not None:
+                assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.shape[-1] == 46
         p0 = actions0.data_ptr() if actions0 is not None and actions0.numel() else None
         p1 = actions1.data_ptr() if actions1 is not None and actions1.numel() else None
-        check(lib.mj_step(self.h, p0, p1, _stream()))
+        pq0 = q0.data_ptr() if q0 is not None and q0.numel() else None
+        pq1 = q1.data_ptr() if q1 is not None and q1.numel() else None
+        check(lib.mj_step_q(self.h, p0, p1, pq0, pq1, _stream()))
         out = (C.c_int32 * 2)()
         check(lib.mj_rows_count(self.h, out, _stream()))
         self.n_rows = [out[0], out[1]]
@@ -140,6 +146,13 @@ class TablePool:
         ms = C.c_double(0)
         n = C.c_int64(0)
         check(lib.mj_encode_timing(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def sp_timing(self):
+        """(total ms, launches) of the SP-table kernel since the last call (recorded while encode timing is on)."""
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        check(lib.mj_sp_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def debug_table(self, table):

@@ -72,6 +72,7 @@ struct Arena {
     std::vector<int> live;  // indices of games still running, in swap_remove order (game.rs:298-300)
     std::vector<u8> done;   // per game
     std::vector<int> final_scores;  // 4 per game
+    long guard_hits = 0;            // agari actions overridden by the rule-based guard
     std::vector<Row> rows;
     struct Pending {
         bool can_act = false, quick = false;
@@ -425,6 +426,7 @@ int mjo_arena_poll(void* h) {
 }
 int mjo_arena_n_live(void* h) { return (int)((Arena*)h)->live.size(); }
 long mjo_arena_steps(void* h) { return ((Arena*)h)->steps; }
+long mjo_arena_guard_hits(void* h) { return ((Arena*)h)->guard_hits; }
 long mjo_arena_cycles(void* h) { return ((Arena*)h)->cycles; }
 // rows_out: int32[n_rows*3] (game, seat, is_kan)
 int mjo_arena_rows(void* h, int* rows_out) {
@@ -455,7 +457,10 @@ int mjo_arena_encode(void* h, int row0, int row1, float* obs, u8* masks) {
     });
 }
 // Commit phase (game.rs:291-304): actions[n_rows].  Returns number of games finished in this cycle.
-int mjo_arena_commit(void* h, const int* actions) {
+// q != NULL enables the rule-based agari guard (agent/mortal.rs:319-336) with q = f32 [rows][46] of the batch
+int mjo_arena_commit_q(void* h, const int* actions, const float* q);
+int mjo_arena_commit(void* h, const int* actions) { return mjo_arena_commit_q(h, actions, nullptr); }
+int mjo_arena_commit_q(void* h, const int* actions, const float* q) {
     return guard([&] {
         Arena* a = (Arena*)h;
         int finished = 0;
@@ -479,6 +484,23 @@ int mjo_arena_commit(void* h, const int* actions) {
                 }
                 const PlayerState& st = gm.board->player_states[seat];
                 int action = actions[p.main_row];
+                if (q && action == 43 && !st.rule_based_agari()) {
+                    // q_values[43] = f32::MIN; iter().enumerate().max_by(total_cmp) -> last of the equal maxima
+                    int best = 0;
+                    int32_t best_key = INT32_MIN;
+                    for (int k = 0; k < 46; k++) {
+                        float v = k == 43 ? -3.40282347e+38f : q[(size_t)p.main_row * 46 + k];
+                        int32_t bits;
+                        memcpy(&bits, &v, 4);
+                        bits ^= (int32_t)((uint32_t)(bits >> 31) >> 1);
+                        if (bits >= best_key) {
+                            best_key = bits;
+                            best = k;
+                        }
+                    }
+                    action = best;
+                    a->guard_hits += 1;
+                }
                 int kan_tile = p.kan_row >= 0 ? actions[p.kan_row] : -1;
                 gm.last_reactions[seat] = agent_decode_action(st, (u8)seat, action, kan_tile);
             }

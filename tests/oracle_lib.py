@@ -60,6 +60,9 @@ def lib():
     L.mjo_arena_rows.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_arena_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.mjo_arena_commit.argtypes = [C.c_void_p, C.c_void_p]
+    L.mjo_arena_commit_q.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mjo_arena_guard_hits.restype = C.c_long
+    L.mjo_arena_guard_hits.argtypes = [C.c_void_p]
     L.mjo_arena_result.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.mjo_arena_game_view.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.mjo_arena_player_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -434,9 +437,18 @@ class Arena:
         _check(lib().mjo_arena_encode(self.h, row0, row1, ptr(obs) if want_obs else None, ptr(masks)))
         return obs, masks
 
-    def commit(self, actions):
+    def commit(self, actions, q_values=None):
+        """q_values (f32 [rows, 46]) switches the rule-based agari guard on for every seat (agent/mortal.rs:319-336)."""
         a = np.ascontiguousarray(actions, dtype=np.int32)
-        return _check(lib().mjo_arena_commit(self.h, ptr(a)))
+        if q_values is None:
+            return _check(lib().mjo_arena_commit(self.h, ptr(a)))
+        q = np.ascontiguousarray(q_values, dtype=np.float32)
+        assert q.shape == (len(a), 46)
+        return _check(lib().mjo_arena_commit_q(self.h, ptr(a), ptr(q)))
+
+    @property
+    def guard_hits(self):
+        return lib().mjo_arena_guard_hits(self.h)
 
     @property
     def n_live(self):

@@ -66,9 +66,27 @@ def greedy_actions(masks, rows, cycle, obs_rows3, seed):
     return act
 
 
+def fake_q_values(masks, rows, cycle, seed):
+    """Deterministic stand-in for the engine's q-values: a hash per (row, action) in [-1, 1), -inf where illegal
+    (engine.py masks illegal actions the same way), with deliberate ties to exercise max_by's last-maximum rule."""
+    masks = np.asarray(masks, dtype=bool)
+    n = len(masks)
+    rows = np.asarray(rows, dtype=np.uint64).reshape(n, 3)
+    with np.errstate(over="ignore"):
+        base = (np.uint64(seed) ^ (rows[:, 0] * np.uint64(0xD1B54A32D192ED03)) ^ (rows[:, 1] * np.uint64(0x8CB92BA72F3D8DD7))
+                ^ (np.array([cycle], dtype=np.uint64) * np.uint64(0x94D049BB133111EB)))
+        x = base[:, None] + np.arange(46, dtype=np.uint64)[None, :] * np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    q = ((x >> np.uint64(60)).astype(np.float32) - 8.0) / 8.0  # 16 levels => frequent ties
+    q[~masks] = -np.inf
+    return np.ascontiguousarray(q, dtype=np.float32)
+
+
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
                  policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
-                 policy="random"):
+                 policy="random", guard=False):
     """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch."""
     import torch
 
@@ -78,15 +96,15 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     arena = oracle.Arena(seeds, deal_algo=0, enable_quick_eval=quick_eval, version=version, keep_log=False)
     pool = TablePool(n_tables, version=version, deal_algo=0)
     pool.reset(seeds)
-    pool.configure(0, enable_quick_eval=quick_eval)
-    pool.configure(1, enable_quick_eval=quick_eval)
+    pool.configure(0, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
+    pool.configure(1, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
     C = pool.C
     # v4: rows 889.. (SP block) are produced by a separate kernel; compared only when sp_rows_checked
     n_cmp = C if (version != 4 or sp_rows_checked) else 889
-    actions = None
+    actions = q_dev = None
     stats = dict(cycles=0, rows=0, obs_checked=0)
     for cycle in range(max_cycles):
-        n0, n1 = pool.step(actions, None)
+        n0, n1 = pool.step(actions, None, q_dev, None)
         assert n1 == 0
         rows_o = arena.poll()
         rows_g = pool.rows(0)
@@ -156,7 +174,12 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
             act = greedy_actions(masks_o, rows_o, cycle, obs_g[:, d0:d0 + 3].cpu().numpy(), policy_seed)
         else:
             act = oracle.random_actions(masks_o, rows_o, cycle, seed=policy_seed)
-        arena.commit(act)
+        if guard:
+            q = fake_q_values(masks_o, rows_o, cycle, policy_seed)
+            arena.commit(act, q)
+            q_dev = torch.from_numpy(q).to(pool.device)
+        else:
+            arena.commit(act)
         actions = torch.from_numpy(act).to(pool.device)
         stats["cycles"] += 1
         stats["rows"] += n
@@ -167,7 +190,7 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     scores_o = np.array([arena.result(g)[0] for g in range(n_tables)])
     done_o = np.array([arena.result(g)[1] for g in range(n_tables)])
     stats.update(counters=cnt, done_gpu=int((done_g == 1).sum()), done_oracle=int(done_o.sum()),
-                 oracle_steps=int(arena.steps))
+                 oracle_steps=int(arena.steps), guard_hits=int(arena.guard_hits))
     both = (done_g == 1) & done_o
     assert (scores_g[both] == scores_o[both]).all(), "final scores differ"
     stats["scores_checked"] = int(both.sum())

@@ -39,3 +39,12 @@ def test_lockstep_greedy_policy_v4_sp(oracle):
     st = parity_util.run_lockstep(oracle, 32, version=4, max_cycles=3000, obs_every=4, policy="greedy",
                                   sp_rows_checked=True)
     assert st["scores_checked"] == 32 and st["counters"]["sp_overflow"] == 0
+
+
+def test_lockstep_rule_based_agari_guard(oracle):
+    """enable_rule_based_agari_guard (agent/mortal.rs:319-336 + agent_helper.rs:251-368): both sides get the same
+    synthetic q-values (16 levels => ties, -inf on illegal actions); an agari the rule engine rejects must turn into the
+    same alternative action on both sides.  The greedy policy always answers agari, so all-last 4th-place hands hit it."""
+    st = parity_util.run_lockstep(oracle, 256, version=3, max_cycles=4000, obs_every=16, policy="greedy", guard=True)
+    assert st["scores_checked"] == 256
+    assert st["guard_hits"] > 0
