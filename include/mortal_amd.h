@@ -72,6 +72,11 @@ const uint32_t* mj_rows_dev(MjPool* pool, int agent);
 
 /* Encode agent a's rows: obs_dev [n_rows][C][34] f32, masks_dev [n_rows][46] u8 (bool). */
 int mj_encode(MjPool* pool, int agent, float* obs_dev, uint8_t* masks_dev, void* stream);
+/* Invisible ("oracle") observation of agent a's rows, for engines with is_oracle=True (arena/game.rs:100-101 ->
+ * BoardState::encode_oracle_obs, arena/board.rs:679-782): out_dev [n_rows][mj_oracle_obs_rows(version)][34] f32. */
+int mj_encode_oracle(MjPool* pool, int agent, float* out_dev, void* stream);
+/* consts.rs:32-38 oracle_obs_shape(version).0: 211 for v1, 217 for v2..v4, -1 otherwise. */
+int mj_oracle_obs_rows(int version);
 /* Average duration (ms) of the encode kernel launches timed with HIP events since the last call, and their count. */
 int mj_encode_timing(MjPool* pool, int enable, double* total_ms_out, int64_t* launches_out);
 /* Same for the SP-table kernel (obs v4 rows 889..1011) launched by mj_encode; collected while encode timing is enabled. */

@@ -41,10 +41,8 @@ def _check_engine(engine):
                                   "(mjai-log / akochan agents are out of scope, SURVEY.md §2 rows 2)")
     if not callable(getattr(engine, "react_batch", None)):
         raise TypeError("missing method react_batch")
-    if getattr(engine, "is_oracle"):
-        raise NotImplementedError("is_oracle engines (invisible obs, board.rs:680-782) are not supported yet")
     return dict(name=str(engine.name), version=int(engine.version), quick=bool(engine.enable_quick_eval),
-                guard=bool(getattr(engine, "enable_rule_based_agari_guard")))
+                guard=bool(getattr(engine, "enable_rule_based_agari_guard")), oracle=bool(getattr(engine, "is_oracle")))
 
 
 class BatchRunner:
@@ -68,19 +66,20 @@ class BatchRunner:
                                 enable_rule_based_agari_guard=self.cfg[0]["guard"])
         self.cycles = 0
 
-    def _policy(self, agent, obs, masks):
+    def _policy(self, agent, obs, masks, invisible=None):
         """-> (actions int32 cuda [n], q_values f32 cuda [n,46] or None).  q-values are kept only for a guarded agent."""
         eng = self.engines[agent]
         guard = self.cfg[agent]["guard"]
         if hasattr(eng, "react_batch_device"):
-            out = eng.react_batch_device(obs, masks)
+            out = eng.react_batch_device(obs, masks, invisible) if invisible is not None else eng.react_batch_device(obs, masks)
             act, q = out if isinstance(out, tuple) else (out, None)
             if guard and q is None:
                 raise RuntimeError("enable_rule_based_agari_guard: react_batch_device must return (actions, q_values)")
             q = q.to(device=self.device, dtype=torch.float32).contiguous() if guard else None
             return act.to(device=self.device, dtype=torch.int32).contiguous(), q
         try:
-            actions, q_values, _m, _g = eng.react_batch([_StackedBatch(obs)], [_StackedBatch(masks)], None)
+            inv = [_StackedBatch(invisible)] if invisible is not None else None  # mortal.rs:137-145
+            actions, q_values, _m, _g = eng.react_batch([_StackedBatch(obs)], [_StackedBatch(masks)], inv)
         except Exception as ex:  # same context string as agent/mortal.rs:149
             raise RuntimeError(f"failed to execute `react_batch` on Python engine: {ex}") from ex
         if len(actions) != obs.shape[0]:
@@ -110,7 +109,8 @@ class BatchRunner:
                 if n[a] == 0:
                     continue
                 obs, masks = pool.encode(a)
-                acts[a], qs[a] = self._policy(a, obs, masks)
+                inv = pool.encode_oracle(a) if self.cfg[min(a, len(self.cfg) - 1)]["oracle"] else None
+                acts[a], qs[a] = self._policy(a, obs, masks, inv)
             if self.cycles >= max_cycles:
                 raise MortalAmdError("max_cycles exceeded")
         code, tbl = pool.first_error()

@@ -420,6 +420,31 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     return 0;
 }
 
+int mj_oracle_obs_rows(int version) {  // consts.rs:32-38
+    if (version == 1) return 211;
+    if (version >= 2 && version <= 4) return 217;
+    return -1;
+}
+
+int mj_encode_oracle(MjPool* P, int agent, float* out, void* stream) {
+    if (!P) return fail("null pool");
+    if (!P->rows_valid) return fail("mj_rows_count must be called after mj_step and before mj_encode_oracle");
+    int n = P->last_rows[agent & 1];
+    if (n == 0) return 0;
+    OracleEncParams ep;
+    ep.rows = P->rows[agent & 1];
+    ep.n_rows = n;
+    ep.version = P->version[agent & 1];
+    ep.snap = P->snap;
+    ep.out = out;
+    size_t lds = enc_oracle_lds_bytes(ep.version);
+    hipStream_t s = (hipStream_t)stream;
+    if (ep.version == 1) hipLaunchKernelGGL(mj_k_encode_oracle<true>, dim3(n), dim3(ENC_THREADS), lds, s, ep);
+    else hipLaunchKernelGGL(mj_k_encode_oracle<false>, dim3(n), dim3(ENC_THREADS), lds, s, ep);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int mj_encode_timing(MjPool* P, int enable, double* total_ms, int64_t* launches) {
     if (!P) return fail("null pool");
     for (auto& e : P->events) {

@@ -553,3 +553,105 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         __syncthreads();
     }
 }
+
+// ================================================================ invisible ("oracle") observation, board.rs:679-782
+// One workgroup per decision row; the whole 211|217 x 34 plane stack (<= 29.5 KB) is built in LDS in one pass and
+// streamed out with 16-byte non-temporal stores.  Row map (v2..v4; v1 has a 6-row thermometer instead of 7+1):
+//   per other seat (p+1, p+2, p+3): 4 hand thermometer, 3 aka, 7 shanten one-hot, 1 shanten/6, 1 waits, 1 furiten
+//   then 69 x 2 yama (next draw first), 4 x 2 rinshan, 5 x 2 dora indicators (reveal order), 5 x 2 ura.
+struct OracleEncParams {
+    const uint32_t* rows;
+    int n_rows;
+    int version;
+    const TableOne* snap;
+    float* out;  // [n_rows][rows][34]
+};
+
+template <bool V1>
+__global__ __launch_bounds__(ENC_THREADS) void mj_k_encode_oracle(OracleEncParams P) {
+    constexpr int SEAT_ROWS = V1 ? 15 : 17;
+    constexpr int ROWS = 3 * SEAT_ROWS + 138 + 8 + 10 + 10;
+    constexpr int TILE_F = (ROWS * 34 + 3) & ~3;
+    extern __shared__ float4 smem4[];
+    float* tile = reinterpret_cast<float*>(smem4);
+    TableOne* st = reinterpret_cast<TableOne*>(tile + TILE_F);
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    const uint32_t desc = P.rows[row];
+    const int table = ROW_TABLE(desc), p = ROW_SEAT(desc);
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.snap + table);
+        float4* dst4 = reinterpret_cast<float4*>(st);
+        for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += ENC_THREADS) dst4[i] = src[i];
+        float4* t4 = reinterpret_cast<float4*>(tile);
+        for (int i = tid; i < TILE_F / 4; i += ENC_THREADS) t4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    LaneT<TableOne> L = {st, 0, &c_mj_tables};
+    auto fill = [&](int r, float v) {
+        for (int c = 0; c < 34; c++) tile[r * 34 + c] = v;
+    };
+    auto encode_tile = [&](int r, int t) {
+        tile[r * 34 + deaka(t)] = 1.f;
+        if (is_aka(t)) fill(r + 1, 1.f);
+    };
+    if (tid < 34) {  // hand thermometer + waits, one tile kind per thread
+        for (int k = 0; k < 3; k++) {
+            const int s = (p + 1 + k) & 3, base = k * SEAT_ROWS;
+            const int c = load_hand(L, s).get(tid);
+            for (int i = 0; i < c; i++) tile[(base + i) * 34 + tid] = 1.f;
+            if ((F1(waits, s) >> tid) & 1) tile[(base + SEAT_ROWS - 2) * 34 + tid] = 1.f;
+        }
+    } else if (tid < 64) {
+        if (tid < 37) {  // per-seat scalars
+            const int k = tid - 34, s = (p + 1 + k) & 3, base = k * SEAT_ROWS;
+            const int akas = F1(akas_in_hand, s);
+            for (int i = 0; i < 3; i++)
+                if ((akas >> i) & 1) fill(base + 4 + i, 1.f);
+            int n = F1(shanten, s);
+            n = n < 0 ? 0 : n > 6 ? 6 : n;
+            if (V1) {
+                for (int i = 0; i < n; i++) fill(base + 7 + i, 1.f);
+            } else {
+                fill(base + 7 + n, 1.f);
+                fill(base + 14, (float)n / 6.f);
+            }
+            if (F1(pflags, s) & PF_AT_FURITEN) fill(base + SEAT_ROWS - 1, 1.f);
+        }
+    } else {
+        const int j = tid - 64;
+        const int W0 = 3 * SEAT_ROWS, R0 = W0 + 138, D0 = R0 + 8, U0 = D0 + 10;
+        if (j < 69) {
+            if (j < (int)F(tiles_left) && j < (int)F(yama_n)) encode_tile(W0 + 2 * j, F1(wall, 66 + F(yama_n) - 1 - j));
+        } else if (j < 73) {
+            const int i = j - 69, n = F(rinshan_n);
+            if (i < n) encode_tile(R0 + 2 * i, F1(wall, 52 + n - 1 - i));
+        } else if (j < 78) {
+            const int i = j - 73;
+            encode_tile(D0 + 2 * i, F1(wall, 60 - i));
+        } else if (j < 83) {
+            const int i = j - 78;
+            encode_tile(U0 + 2 * i, F1(wall, 61 + i));
+        }
+    }
+    __syncthreads();
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    float* dst = P.out + (size_t)row * ROWS * 34;
+    constexpr int N = ROWS * 34;  // 7174 / 7378 floats: row stride is 8-byte aligned, so split head / body / tail
+    const int head = (int)(((16 - ((uintptr_t)dst & 15)) & 15) / 4);
+    if (tid < head) dst[tid] = tile[tid];
+    const int n4 = (N - head) / 4;
+    for (int i = tid; i < n4; i += ENC_THREADS) {
+        const float* s4 = tile + head + 4 * i;
+        v4f v = {s4[0], s4[1], s4[2], s4[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst + head + 4 * i));
+    }
+    const int done = head + 4 * n4;
+    if (tid < N - done) dst[done + tid] = tile[done + tid];
+}
+
+static size_t enc_oracle_lds_bytes(int version) {
+    int rows = version == 1 ? 211 : 217;
+    size_t tile = (size_t)((rows * 34 + 3) & ~3) * 4;
+    return tile + ((sizeof(TableOne) + 15) & ~(size_t)15);
+}

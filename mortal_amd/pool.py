@@ -117,6 +117,17 @@ class TablePool:
             check(lib.mj_encode(self.h, agent, obs.data_ptr(), masks.data_ptr(), _stream()))
         return obs[:n], masks[:n]
 
+    def encode_oracle(self, agent, out=None):
+        """Invisible ("oracle") obs of agent's rows (board.rs:679-782): f32 cuda [n, 211|217, 34]."""
+        n = self.n_rows[agent]
+        R = lib.mj_oracle_obs_rows(self.versions[agent])
+        if out is None:
+            out = torch.empty((n, R, 34), dtype=torch.float32, device=self.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= n
+        assert tuple(out.shape[1:]) == (R, 34)
+        check(lib.mj_encode_oracle(self.h, agent, out.data_ptr(), _stream()))
+        return out[:n]
+
     def random_policy(self, agent, masks, seed, cycle, out=None):
         n = self.n_rows[agent]
         if out is None:

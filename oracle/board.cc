@@ -21,6 +21,7 @@ void Board::init_from_seq(const u8 seq[136]) {  // board.rs:111-122
 
 BoardState::BoardState(const Board& b) : board(b) {  // board.rs:125-136
     oya = board.kyoku % 4;
+    dora_indicators_full = board.dora_indicators;
     for (int i = 0; i < 4; i++) player_states[i] = PlayerState((u8)i);
 }
 
@@ -649,6 +650,70 @@ bool Game::commit_end() {  // game.rs:180-197
         scores[top] += kyotaku * 1000;
     }
     return true;
+}
+
+
+// ---------------------------------------------------------------- board.rs:679-782
+void BoardState::encode_oracle_obs(u8 perspective, int version, float* out) const {
+    const int rows = oracle_obs_rows(version);
+    memset(out, 0, sizeof(float) * rows * 34);
+    auto assign = [&](int r, int c, float v) { out[r * 34 + c] = v; };
+    auto fill = [&](int r, float v) {
+        for (int c = 0; c < 34; c++) out[r * 34 + c] = v;
+    };
+    int idx = 0;
+    for (int k = 1; k <= 3; k++) {
+        const PlayerState& st = player_states[(perspective + k) % 4];
+        for (int t = 0; t < 34; t++)
+            for (int c = 0; c < st.tehai[t]; c++) assign(idx + c, t, 1.f);  // assign_rows(idx, tile, count, 1)
+        idx += 4;
+        for (int i = 0; i < 3; i++)
+            if (st.akas_in_hand[i]) fill(idx + i, 1.f);
+        idx += 3;
+        const int n = st.shanten;
+        MJO_ENSURE(n >= 0 && n <= 6, "oracle obs: shanten out of range");
+        if (version == 1) {
+            for (int i = 0; i < n; i++) fill(idx + i, 1.f);
+            idx += 6;
+        } else {
+            fill(idx + n, 1.f);
+            idx += 7;
+            fill(idx, (float)n / 6.f);
+            idx += 1;
+        }
+        for (int t = 0; t < 34; t++)
+            if (st.waits[t]) assign(idx, t, 1.f);
+        idx += 1;
+        if (st.at_furiten) fill(idx, 1.f);
+        idx += 1;
+    }
+    auto encode_tile = [&](int r, u8 tile) {
+        assign(r, deaka(tile), 1.f);
+        if (is_aka(tile)) fill(r + 1, 1.f);
+    };
+    {
+        int taken = 0;
+        for (auto it = board.yama.rbegin(); it != board.yama.rend() && taken < tiles_left; ++it, ++taken) {
+            encode_tile(idx, *it);
+            idx += 2;
+        }
+        MJO_ENSURE(taken == tiles_left, "oracle obs: yama shorter than tiles_left");
+        idx += (69 - tiles_left) * 2;
+    }
+    for (auto it = board.rinshan.rbegin(); it != board.rinshan.rend(); ++it) {
+        encode_tile(idx, *it);
+        idx += 2;
+    }
+    idx += (4 - (int)board.rinshan.size()) * 2;
+    for (auto it = dora_indicators_full.rbegin(); it != dora_indicators_full.rend(); ++it) {
+        encode_tile(idx, *it);
+        idx += 2;
+    }
+    for (u8 t : board.ura_indicators) {
+        encode_tile(idx, t);
+        idx += 2;
+    }
+    MJO_ENSURE(idx == rows, "oracle obs: row count mismatch");
 }
 
 }  // namespace mjo

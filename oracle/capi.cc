@@ -456,6 +456,18 @@ int mjo_arena_encode(void* h, int row0, int row1, float* obs, u8* masks) {
         return 0;
     });
 }
+// Invisible ("oracle") obs of rows [row0,row1) (game.rs:100-101): out = f32 [n][oracle_obs_rows(version)][34]
+int mjo_arena_encode_oracle(void* h, int row0, int row1, int version, float* out) {
+    return guard([&] {
+        Arena* a = (Arena*)h;
+        size_t stride = (size_t)BoardState::oracle_obs_rows(version) * 34;
+        for (int r = row0; r < row1; r++) {
+            const Row& row = a->rows.at(r);
+            a->games[row.game]->board->encode_oracle_obs((u8)row.seat, version, out + (size_t)(r - row0) * stride);
+        }
+        return 0;
+    });
+}
 // Commit phase (game.rs:291-304): actions[n_rows].  Returns number of games finished in this cycle.
 // q != NULL enables the rule-based agari guard (agent/mortal.rs:319-336) with q = f32 [rows][46] of the batch
 int mjo_arena_commit_q(void* h, const int* actions, const float* q);

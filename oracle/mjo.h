@@ -358,8 +358,12 @@ struct BoardState {  // board.rs:52-85
     bool check_four_kan = false;
     std::optional<u8> paos[4];
     std::vector<Event> log;
+    std::vector<u8> dora_indicators_full;          // board.rs:84,127 (copy taken before any indicator is popped)
 
     explicit BoardState(const Board& b);           // board.rs:125-136
+    // invisible ("oracle") observation of seat `perspective`: out = zeroed-and-filled [oracle_obs_rows(version)][34]
+    void encode_oracle_obs(u8 perspective, int version, float* out) const;  // board.rs:679-782
+    static int oracle_obs_rows(int version) { return version == 1 ? 211 : 217; }  // consts.rs:32-38
     Poll poll(std::array<Event, 4> reactions);     // board.rs:141-161
     Poll step(const std::array<Event, 4>& reactions);  // board.rs:511-678
     KyokuResult end() const;                       // board.rs:172-182

@@ -60,6 +60,7 @@ def lib():
     L.mjo_arena_rows.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_arena_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.mjo_arena_commit.argtypes = [C.c_void_p, C.c_void_p]
+    L.mjo_arena_encode_oracle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.mjo_arena_commit_q.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjo_arena_guard_hits.restype = C.c_long
     L.mjo_arena_guard_hits.argtypes = [C.c_void_p]
@@ -436,6 +437,13 @@ class Arena:
             obs = np.empty((n, rows, 34), dtype=np.float32)
         _check(lib().mjo_arena_encode(self.h, row0, row1, ptr(obs) if want_obs else None, ptr(masks)))
         return obs, masks
+
+    def encode_oracle(self, row0, row1, version):
+        """Invisible obs (board.rs:679-782) of rows [row0, row1): f32 [n, 211|217, 34]."""
+        rows = 211 if version == 1 else 217
+        out = np.empty((row1 - row0, rows, 34), dtype=np.float32)
+        _check(lib().mjo_arena_encode_oracle(self.h, row0, row1, version, ptr(out)))
+        return out
 
     def commit(self, actions, q_values=None):
         """q_values (f32 [rows, 46]) switches the rule-based agari guard on for every seat (agent/mortal.rs:319-336)."""

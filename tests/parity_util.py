@@ -86,7 +86,7 @@ def fake_q_values(masks, rows, cycle, seed):
 
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
                  policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
-                 policy="random", guard=False):
+                 policy="random", guard=False, oracle_obs=False):
     """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch."""
     import torch
 
@@ -169,6 +169,18 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
                                                          if k not in ("wall", "kawa")))
                 raise AssertionError("\n".join(lines))
             stats["obs_checked"] += n
+        if oracle_obs and n and cycle % obs_every == 0:
+            inv_g = pool.encode_oracle(0).cpu().numpy()
+            inv_o = arena.encode_oracle(0, n, version)
+            if not (inv_g.view(np.uint32) == inv_o.view(np.uint32)).all():
+                bad = np.argwhere(inv_g.view(np.uint32) != inv_o.view(np.uint32))
+                r = int(bad[0][0])
+                rr = sorted(set(int(x[1]) for x in bad if x[0] == r))
+                lines = [f"cycle {cycle}: invisible obs mismatch at row {r} {rows_o[r]}; differing planes {rr[:40]}"]
+                for q in rr[:8]:
+                    lines.append(f"  plane {q}: oracle {inv_o[r, q].tolist()}\n            gpu    {inv_g[r, q].tolist()}")
+                raise AssertionError("\n".join(lines))
+            stats["oracle_obs_checked"] = stats.get("oracle_obs_checked", 0) + n
         if policy == "greedy":
             d0 = DISCARD_ROW[version]
             act = greedy_actions(masks_o, rows_o, cycle, obs_g[:, d0:d0 + 3].cpu().numpy(), policy_seed)

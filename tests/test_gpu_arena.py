@@ -79,3 +79,36 @@ def test_two_vs_two_runs(oracle):
     a, _ = _engine(3, 3, "a", True)
     b, _ = _engine(3, 4, "b", True)
     assert TwoVsTwo(disable_progress_bar=True).py_vs_py(a, b, (20000, KEY), 2) is None
+
+
+def test_is_oracle_and_guard_engine_contract(oracle):
+    """An engine with is_oracle=True receives `invisible_obs` as a list whose np.stack is the [B, 217, 34] device batch
+    (agent/mortal.rs:137-145); one with enable_rule_based_agari_guard=True has its q-values routed to the step kernel."""
+    import torch
+
+    from libriichi.arena import OneVsThree
+
+    seen = {}
+
+    class Eng:
+        engine_type = "mortal"
+        name = "oracle-guard"
+        is_oracle = True
+        version = 3
+        enable_quick_eval = True
+        enable_rule_based_agari_guard = True
+
+        def react_batch(self, obs, masks, invisible_obs):
+            o = np.stack(obs, axis=0)
+            m = np.stack(masks, axis=0)
+            inv = np.stack(invisible_obs, axis=0)
+            assert isinstance(inv, torch.Tensor) and inv.is_cuda and inv.shape == (o.shape[0], 217, 34)
+            seen["rows"] = seen.get("rows", 0) + int(o.shape[0])
+            # first legal action; q-values favour it, -inf on illegal ones (engine.py masks the same way)
+            q = torch.where(m, torch.linspace(1.0, 0.0, 46, device=m.device).expand_as(m), torch.tensor(-torch.inf, device=m.device))
+            a = q.argmax(dim=1)
+            return a.tolist(), q.tolist(), m.tolist(), [True] * o.shape[0]
+
+    e = Eng()
+    got = OneVsThree(disable_progress_bar=True).py_vs_py(challenger=e, champion=e, seed_start=(10000, KEY), seed_count=1)
+    assert sum(got) == 4 and seen["rows"] > 0

@@ -48,3 +48,13 @@ def test_lockstep_rule_based_agari_guard(oracle):
     st = parity_util.run_lockstep(oracle, 256, version=3, max_cycles=4000, obs_every=16, policy="greedy", guard=True)
     assert st["scores_checked"] == 256
     assert st["guard_hits"] > 0
+
+
+@pytest.mark.parametrize("version", [1, 3])
+def test_lockstep_invisible_obs(oracle, version):
+    """a14: BoardState::encode_oracle_obs (board.rs:679-782) — other seats' hands / shanten / waits / furiten, the live
+    wall, rinshan, dora and ura indicators — bit-exact for every decision row, v1 (211 planes) and v2+ (217 planes).
+    The greedy policy reaches kans (rinshan draws shift the wall window) and furiten."""
+    st = parity_util.run_lockstep(oracle, 128, version=version, max_cycles=1500, obs_every=3,
+                                  compare_obs=False, policy="random" if version == 1 else "greedy", oracle_obs=True)
+    assert st["oracle_obs_checked"] > 20000
