@@ -238,13 +238,24 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
 }
 
 // Per-team LDS scratch of sp_visit_team.
+#define SP_CH 8      // children gathered per batch in the evaluation pass
+#define SP_CCAP 256  // children staged per super-chunk (a required tile has at most 2 x 14)
 struct SpTeam {
-    u64 rowt[34];            // table row of (h + t) in suit(t)
-    u64 rowd[34];            // table row of (h - d) in suit(d)
     u64 keep[34];            // per required tile t: set of shanten-keeping discards of h + t
     int coff[34];            // per required tile t: offset of its first child inside the node's child list
-    float sc[34][2][4];      // level 0: get_score() of every (winning tile, variant), one lane each
     u8 tiles[36];            // required tiles in ascending order
+    union {
+        struct {
+            u64 rowt[34];    // expand: table row of (h + t) in suit(t)
+            u64 rowd[34];    //         table row of (h - d) in suit(d)
+        } ex;
+        float sc[34][2][4];  // level 0: get_score() of every (winning tile, variant), one lane each
+        struct {             // level > 0 evaluation
+            float buf[SP_CH][3][SP_T];          // values of the current batch of children, one turn per lane
+            unsigned short cs[SP_CCAP];         // child slots
+            unsigned short meta[SP_CCAP];       // discard tile | last-of-group << 6 | draw count << 7
+        } ev;
+    } u;
 };
 
 // Visit one 3n+1 state of shanten level L with a TEAM of 32 lanes (half a wavefront).
@@ -290,8 +301,8 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                                      B.kkinds + (yao && hc == 0));
                     is_req = sh - L == -1;
                 }
-                TM->rowt[t] = r;
-                TM->rowd[t] = rd;
+                TM->u.ex.rowt[t] = r;
+                TM->u.ex.rowd[t] = rd;
                 TM->keep[t] = 0;
             }
             const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull;
@@ -315,9 +326,9 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                 if (c == 0) continue;
                 const int st = sh_suit(t), sd = sh_suit(d);
                 const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
-                const u64 row_t = TM->rowt[t];
+                const u64 row_t = TM->u.ex.rowt[t];
                 u64 r0 = B.row[0], r1 = B.row[1], r2 = B.row[2], r3 = B.row[3];
-                const u64 rd = sd == st ? (d == t ? B.row[st] : sh_load(Tb, st, B.key[st] + sh_pow(t) - sh_pow(d))) : TM->rowd[d];
+                const u64 rd = sd == st ? (d == t ? B.row[st] : sh_load(Tb, st, B.key[st] + sh_pow(t) - sh_pow(d))) : TM->u.ex.rowd[d];
                 if (st == 0) r0 = row_t; else if (st == 1) r1 = row_t; else if (st == 2) r2 = row_t; else r3 = row_t;
                 if (sd == 0) r0 = rd; else if (sd == 1) r1 = rd; else if (sd == 2) r2 = rd; else r3 = rd;
                 const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
@@ -393,15 +404,23 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             sp_deal(S1, tile);
             float scv[4];
             if (sp_get_score(Tb, X, S1, tile, scv)) {
-                for (int q = 0; q < 4; q++) TM->sc[t][variant][q] = scv[q];
+                for (int q = 0; q < 4; q++) TM->u.sc[t][variant][q] = scv[q];
                 atomicOr((unsigned long long*)&TM->keep[t], 1ull << variant);
             }
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
     } else {
+        // level > 0: the expansion pass left req / keep / child slots in the node; fetch them in one round trip
         req = node.req;
         child_base = (int)node.child_off;
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int t = ln + 32 * rnd;
+            if (t < 34) TM->keep[t] = node.keep[t];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
     }
 
     // ---- D (EVAL)
@@ -412,116 +431,174 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
     const float* nt = X->not_tsumo[min(sum_required, 123)];
     const float my_m = ln < T ? nt[ln] : 0.f;  // not_tsumo_probs[i] of this lane's turn
     const bool assume_riichi = X->is_menzen && X->prefer_riichi;
-    int cpos = child_base;  // running position inside the node's child list
-    for (int t = 0; t < 34; t++) {
-        if (!((req >> t) & 1)) continue;
-        const int cnt = S.w.get(t);
-        const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-        const u64 keep = L > 0 ? node.keep[t] : 0ull;
-        const int nk = __popcll(keep);
-        // draw entries in the reference's order: plain tile (count-1 if the aka is still in the wall), then the aka
-        for (int variant = 0; variant < 2; variant++) {
-            int tile, count;
-            if (!aka_in_wall) {
-                if (variant == 1) break;
-                tile = t;
-                count = cnt;
-            } else if (variant == 0) {
-                if (cnt < 2) continue;
-                tile = t;
-                count = cnt - 1;
-            } else {
-                tile = akaize(t);
-                count = 1;
-            }
-            float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;  // lane i: folded values at turn i
-            float scores[4] = {0.f, 0.f, 0.f, 0.f};
-            bool is_scores = false;
-            if (L > 0) {
-                // discard_slow (calc.rs:570-637): fold the children in ascending discard order
-                const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;  // akas_in_hand after the draw
-                int max_value = INT_MIN, max_tile = T_UNK;
-                u64 rest = keep;
-                for (int k0 = 0; k0 < nk; k0 += 4) {
-                    // gather up to 4 children first (independent loads in flight together), then fold them in order
-                    float ct[4], cw[4], ce[4];
-                    int cdt[4];
+
+    // accumulate one draw entry (calc.rs:486-548): lane i runs j = i .. T-1; `break`s become predicates (not_tsumo is
+    // monotone).  nx_* = lane i's folded child values at turn i (L > 0) or scores (L == 0).
+    auto accumulate = [&](int count, float nx_t, float nx_w, float nx_e, bool is_scores, const float* scores) {
+        const float* tp = X->tsumo_prob[count - 1];
+        float vt[SP_T], vw[SP_T], ve[SP_T], pr[SP_T];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        cdt[q] = -1;
-                        if (k0 + q < nk) {
-                            const int d = __ffsll((long long)rest) - 1;
-                            rest &= rest - 1;
-                            const int cs = W->pool[min(cpos + k0 + q, SP_POOL - 1)];
-                            if (cs != 0xFFFF) {
-                                const int c = S.h.get(d) + (d == t);
-                                int dt = d;
-                                if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
-                                else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
-                                else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
-                                cdt[q] = dt;
-                                if (ln < T) {
-                                    const SpNode& ch = W->node[cs];
-                                    ct[q] = ch.tenpai[ln];
-                                    cw[q] = ch.win[ln];
-                                    ce[q] = ch.ev[ln];
-                                }
-                            } else {
-                                X->overflow = 1;
-                            }
-                        }
-                    }
+        for (int j = 0; j < SP_T; j++) {
+            // next[j + 1] comes from lane j + 1 (only used when j < T - 1)
+            vt[j] = __shfl(nx_t, (j + 1) & 31, 32);
+            vw[j] = __shfl(nx_w, (j + 1) & 31, 32);
+            ve[j] = __shfl(nx_e, (j + 1) & 31, 32);
+            const float n = nt[j];  // rows are zero-padded beyond T
+            pr[j] = (j < T && j >= ln && ln < T && my_m != 0.f && n != 0.f) ? tp[j] * n / my_m : -1.f;
+        }
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (cdt[q] < 0 || ln >= T) continue;
-                        const int value = (int)ce[q];  // `as i32` (maximize_win_prob = false)
-                        if (value > max_value || (value == max_value && cmp_discard_priority(cdt[q], max_tile) > 0)) {
-                            nx_t = ct[q];
-                            nx_w = cw[q];
-                            nx_e = ce[q];
-                            max_value = value;
-                            max_tile = cdt[q];
-                        }
+        for (int j = 0; j < SP_T; j++) {
+            const float prob = pr[j];
+            if (prob >= 0.f) {  // probabilities are never negative; -1 marks "not part of this lane's sum"
+                if (is_scores) {
+                    int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
+                                   (int)(X->calc_haitei && j == T - 1);
+                    acc_w += prob;
+                    acc_e += prob * scores[han_plus];
+                } else {
+                    if (L == 1) acc_t += prob;
+                    if (j < T - 1) {
+                        if (L > 1) acc_t += prob * vt[j];
+                        acc_w += prob * vw[j];
+                        acc_e += prob * ve[j];
                     }
                 }
-                cpos += nk;
-            } else {
+            }
+        }
+    };
+
+    if (L == 0) {
+        for (int t = 0; t < 34; t++) {
+            if (!((req >> t) & 1)) continue;
+            const int cnt = S.w.get(t);
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            // draw entries in the reference's order: plain tile (count-1 if the aka is still in the wall), then the aka
+            for (int variant = 0; variant < 2; variant++) {
+                int count;
+                if (!aka_in_wall) {
+                    if (variant == 1) break;
+                    count = cnt;
+                } else if (variant == 0) {
+                    if (cnt < 2) continue;
+                    count = cnt - 1;
+                } else {
+                    count = 1;
+                }
                 if (!((TM->keep[t] >> variant) & 1)) continue;  // no yaku with this tile
+                float scores[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) scores[q] = TM->sc[t][variant][q];
-                is_scores = true;
+                for (int q = 0; q < 4; q++) scores[q] = TM->u.sc[t][variant][q];
+                accumulate(count, 0.f, 0.f, 0.f, true, scores);
             }
-            // accumulate (calc.rs:486-548): lane i runs j = i .. T-1; `break`s become predicates (not_tsumo is monotone)
-            const float* tp = X->tsumo_prob[count - 1];
-            float vt[SP_T], vw[SP_T], ve[SP_T], pr[SP_T];
-#pragma unroll
-            for (int j = 0; j < SP_T; j++) {
-                // next[j + 1] comes from lane j + 1 (only used when j < T - 1)
-                vt[j] = __shfl(nx_t, (j + 1) & 31, 32);
-                vw[j] = __shfl(nx_w, (j + 1) & 31, 32);
-                ve[j] = __shfl(nx_e, (j + 1) & 31, 32);
-                const float n = nt[j];  // rows are zero-padded beyond T
-                pr[j] = (j < T && j >= ln && ln < T && my_m != 0.f && n != 0.f) ? tp[j] * n / my_m : -1.f;
+        }
+    } else {
+        // Children are consumed in the reference's order (t ascending, plain before aka draw, discard ascending) but
+        // FETCHED in batches: slots of a whole super-chunk in one coalesced read, then SP_CH children's value arrays
+        // per round trip — instead of two dependent gathers per child.
+        int n_tiles = 0;
+        for (int t = 0; t < 34; t++)
+            if ((req >> t) & 1) {
+                if (ln == 0) TM->tiles[n_tiles] = (u8)t;
+                n_tiles++;
             }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        int ti_next = 0, cpos = child_base;
+        while (ti_next < n_tiles) {
+            // tiles [ti_next, ti_end) whose children fit the staging area
+            int n_ch = 0, ti_end = ti_next;
+            while (ti_end < n_tiles) {
+                const int t = TM->tiles[ti_end];
+                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
+                const int c = nvar * __popcll(TM->keep[t]);
+                if (n_ch + c > SP_CCAP) break;
+                if (ln == 0) TM->coff[t] = n_ch;
+                n_ch += c;
+                ti_end++;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            for (int i = ln; i < n_ch; i += 32) TM->u.ev.cs[i] = W->pool[min(cpos + i, SP_POOL - 1)];
+            // per-child metadata, one lane per draw entry (tile, variant)
+            for (int g = ln; g < 2 * (ti_end - ti_next); g += 32) {
+                const int t = TM->tiles[ti_next + (g >> 1)], variant = g & 1;
+                const int cnt = S.w.get(t);
+                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                int tile, count, vidx;
+                if (!aka_in_wall) { if (variant == 1) continue; tile = t; count = cnt; vidx = 0; }
+                else if (variant == 0) { if (cnt < 2) continue; tile = t; count = cnt - 1; vidx = 0; }
+                else { tile = akaize(t); count = 1; vidx = cnt >= 2 ? 1 : 0; }
+                const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;  // akas_in_hand after the draw
+                u64 rest = TM->keep[t];
+                const int nk = __popcll(rest);
+                int pos = TM->coff[t] + vidx * nk;
+                for (int k = 0; k < nk; k++, pos++) {
+                    const int d = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int c = S.h.get(d) + (d == t);
+                    int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+                    if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
+                    else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
+                    else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
+                    TM->u.ev.meta[pos] = (unsigned short)(dt | ((k == nk - 1) ? 64 : 0) | (count << 7));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // discard_slow (calc.rs:570-637) fold state of the current draw entry
+            float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
+            int max_value = INT_MIN, max_tile = T_UNK;
+            for (int c0 = 0; c0 < n_ch; c0 += SP_CH) {
+                float v[SP_CH][3];
 #pragma unroll
-            for (int j = 0; j < SP_T; j++) {
-                const float prob = pr[j];
-                if (prob >= 0.f) {  // probabilities are never negative; -1 marks "not part of this lane's sum"
-                    if (is_scores) {
-                        int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
-                                       (int)(X->calc_haitei && j == T - 1);
-                        acc_w += prob;
-                        acc_e += prob * scores[han_plus];
-                    } else {
-                        if (L == 1) acc_t += prob;
-                        if (j < T - 1) {
-                            if (L > 1) acc_t += prob * vt[j];
-                            acc_w += prob * vw[j];
-                            acc_e += prob * ve[j];
+                for (int q = 0; q < SP_CH; q++) {
+                    v[q][0] = v[q][1] = v[q][2] = 0.f;
+                    if (c0 + q < n_ch && ln < T) {
+                        const int cs = TM->u.ev.cs[c0 + q];
+                        if (cs != 0xFFFF) {
+                            const SpNode& ch = W->node[cs];
+                            v[q][0] = ch.tenpai[ln];
+                            v[q][1] = ch.win[ln];
+                            v[q][2] = ch.ev[ln];
                         }
                     }
                 }
+                if (ln < SP_T) {
+#pragma unroll
+                    for (int q = 0; q < SP_CH; q++) {
+                        TM->u.ev.buf[q][0][ln] = v[q][0];
+                        TM->u.ev.buf[q][1][ln] = v[q][1];
+                        TM->u.ev.buf[q][2][ln] = v[q][2];
+                    }
+                }
+                const int nq = min(SP_CH, n_ch - c0);
+                for (int q = 0; q < nq; q++) {
+                    const int m = TM->u.ev.meta[c0 + q];
+                    if (TM->u.ev.cs[c0 + q] == 0xFFFF) {
+                        X->overflow = 1;
+                    } else if (ln < T) {
+                        const float ce = TM->u.ev.buf[q][2][ln];
+                        const int value = (int)ce;  // `as i32` (maximize_win_prob = false)
+                        const int dt = m & 63;
+                        if (value > max_value || (value == max_value && cmp_discard_priority(dt, max_tile) > 0)) {
+                            nx_t = TM->u.ev.buf[q][0][ln];
+                            nx_w = TM->u.ev.buf[q][1][ln];
+                            nx_e = ce;
+                            max_value = value;
+                            max_tile = dt;
+                        }
+                    }
+                    if (m & 64) {  // last child of this draw entry
+                        accumulate(m >> 7, nx_t, nx_w, nx_e, false, nullptr);
+                        nx_t = nx_w = nx_e = -3.40282347e+38f;
+                        max_value = INT_MIN;
+                        max_tile = T_UNK;
+                    }
+                }
             }
+            cpos += n_ch;
+            ti_next = ti_end;
         }
     }
     if (ln < SP_T) {

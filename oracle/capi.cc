@@ -86,11 +86,11 @@ struct Arena {
 };
 }  // namespace
 
-namespace mjo { extern long g_sp_stats[8]; }
+namespace mjo { extern long g_sp_stats[16]; }
 
 extern "C" {
 
-void mjo_sp_stats(long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = mjo::g_sp_stats[i]; if (reset) mjo::g_sp_stats[i] = 0; } }
+void mjo_sp_stats(long* out, int reset) { for (int i = 0; i < 16; i++) { out[i] = mjo::g_sp_stats[i]; if (reset) mjo::g_sp_stats[i] = 0; } }
 const char* mjo_last_error() { return g_err.c_str(); }
 int mjo_ev_ints() { return EV_INTS; }
 

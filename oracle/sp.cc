@@ -9,7 +9,7 @@
 
 namespace mjo {
 
-long g_sp_stats[8] = {0,0,0,0,0,0,0,0};  // debug: draw-cache inserts per shanten level [0..3], discard [4..7]
+long g_sp_stats[16] = {};  // debug: draw-cache inserts per shanten level [0..3], discard-cache inserts [4..7], draw calls [8..11], discard calls [12..15]
 
 namespace {
 
@@ -248,6 +248,7 @@ struct Calc {  // calc.rs:64-78
     }
 
     ValuesP draw(int shanten) {  // calc.rs:314-320
+        g_sp_stats[8 + shanten]++;
         if (sup.calc_tegawari && state.n_extra_tsumo == 0) return draw_with_tegawari(shanten);
         return draw_without_tegawari(shanten);
     }
@@ -378,6 +379,7 @@ struct Calc {  // calc.rs:64-78
     }
 
     ValuesP discard(int shanten) {  // calc.rs:563-637
+        g_sp_stats[12 + shanten]++;
         auto it = discard_cache[shanten].find(state);
         if (it != discard_cache[shanten].end()) return it->second;
         auto discard_tiles = get_discard_tiles(state, shanten, sup.tehai_len_div3);
