@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libmortal_amd.so")
+LIB_PATH = os.environ.get("MORTAL_AMD_LIB") or os.path.join(_DIR, "libmortal_amd.so")  # env override: A/B builds
 
 # Every symbol include/mortal_amd.h declares (tests/test_abi.py checks the library exports all of them).
 SYMBOLS = [

@@ -142,6 +142,35 @@ __device__ int sp_insert(SpWork* W, SpCtx* X, const SpState& s, bool& fresh) {
     X->overflow = 1;
     return -1;
 }
+// Two-step insert so that several first probes (one L2 atomic each) can be in flight per lane.
+struct SpIns {
+    u64 k[4], h, old;
+    u32 pos;
+};
+__device__ __forceinline__ void sp_insert_begin(SpWork* W, const SpState& s, SpIns& I) {
+    sp_key(s, I.k);
+    I.h = sp_hash(I.k);
+    I.pos = (u32)(I.h >> 20) & (SP_CAP - 1);
+    I.old = atomicCAS((unsigned long long*)&W->tag[I.pos], 0ull, (unsigned long long)I.h);
+}
+__device__ __forceinline__ int sp_insert_finish(SpWork* W, SpCtx* X, SpIns& I, bool& fresh) {
+    fresh = false;
+    u64 old = I.old;
+    u32 pos = I.pos;
+    for (int probe = 0; probe < SP_CAP; probe++) {
+        if (old == 0ull) {
+            SpNode& n = W->node[pos];
+            n.k0 = I.k[0]; n.k1 = I.k[1]; n.k2 = I.k[2]; n.k3 = I.k[3];
+            fresh = true;
+            return (int)pos;
+        }
+        if (old == I.h) return (int)pos;
+        pos = (pos + 1) & (SP_CAP - 1);
+        old = atomicCAS((unsigned long long*)&W->tag[pos], 0ull, (unsigned long long)I.h);
+    }
+    X->overflow = 1;
+    return -1;
+}
 __device__ int sp_lookup(const SpWork* W, const SpState& s) {
     u64 k[4];
     sp_key(s, k);
@@ -248,6 +277,7 @@ struct SpTeam {
         struct {
             u64 rowt[34];    // expand: table row of (h + t) in suit(t)
             u64 rowd[34];    //         table row of (h - d) in suit(d)
+            unsigned short items[SP_CCAP];  // children of the current super-chunk: t | d << 6 | variant << 12
         } ex;
         float sc[34][2][4];  // level 0: get_score() of every (winning tile, variant), one lane each
         struct {             // level > 0 evaluation
@@ -319,22 +349,41 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
         __threadfence_block();
 
         if (!EVAL) {
-            // ---- B: (required t, d) probes
-            for (int item = ln; item < n_tiles * 34; item += 32) {
-                const int t = TM->tiles[item / 34], d = item % 34;
-                const int c = S.h.get(d) + (d == t);  // count of d after the draw
-                if (c == 0) continue;
-                const int st = sh_suit(t), sd = sh_suit(d);
-                const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
-                const u64 row_t = TM->u.ex.rowt[t];
-                u64 r0 = B.row[0], r1 = B.row[1], r2 = B.row[2], r3 = B.row[3];
-                const u64 rd = sd == st ? (d == t ? B.row[st] : sh_load(Tb, st, B.key[st] + sh_pow(t) - sh_pow(d))) : TM->u.ex.rowd[d];
-                if (st == 0) r0 = row_t; else if (st == 1) r1 = row_t; else if (st == 2) r2 = row_t; else r3 = row_t;
-                if (sd == 0) r0 = rd; else if (sd == 1) r1 = rd; else if (sd == 2) r2 = rd; else r3 = rd;
-                const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
-                const int kpairs = B.kpairs + (yt && hct == 1) - (yd && c == 2), kkinds = B.kkinds + (yt && hct == 0) - (yd && c == 1);
-                if (sh_eval(r0, r1, r2, r3, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0)
-                    atomicOr((unsigned long long*)&TM->keep[t], 1ull << d);
+            // ---- B: (required t, d) probes, four items per lane and round so that their gathers overlap
+            const int n_items = n_tiles * 34;
+            for (int base = 0; base < n_items; base += 128) {
+                u64 rdv[4];
+                int tt[4], dd[4];
+                bool valid[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int item = base + q * 32 + ln;
+                    valid[q] = item < n_items;
+                    const int t = TM->tiles[min(item, n_items - 1) / 34], d = item % 34;
+                    tt[q] = t;
+                    dd[q] = d;
+                    valid[q] = valid[q] && (S.h.get(d) + (d == t)) > 0;
+                    const int st = sh_suit(t);
+                    rdv[q] = 0;
+                    if (valid[q] && sh_suit(d) == st && d != t) rdv[q] = sh_load(Tb, st, B.key[st] + sh_pow(t) - sh_pow(d));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (!valid[q]) continue;
+                    const int t = tt[q], d = dd[q];
+                    const int c = S.h.get(d) + (d == t);  // count of d after the draw
+                    const int st = sh_suit(t), sd = sh_suit(d);
+                    const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
+                    const u64 row_t = TM->u.ex.rowt[t];
+                    u64 r0 = B.row[0], r1 = B.row[1], r2 = B.row[2], r3 = B.row[3];
+                    const u64 rd = sd == st ? (d == t ? B.row[st] : rdv[q]) : TM->u.ex.rowd[d];
+                    if (st == 0) r0 = row_t; else if (st == 1) r1 = row_t; else if (st == 2) r2 = row_t; else r3 = row_t;
+                    if (sd == 0) r0 = rd; else if (sd == 1) r1 = rd; else if (sd == 2) r2 = rd; else r3 = rd;
+                    const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
+                    const int kpairs = B.kpairs + (yt && hct == 1) - (yd && c == 2), kkinds = B.kkinds + (yt && hct == 0) - (yd && c == 1);
+                    if (sh_eval(r0, r1, r2, r3, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0)
+                        atomicOr((unsigned long long*)&TM->keep[t], 1ull << d);
+                }
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
@@ -344,7 +393,6 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                 const int t = TM->tiles[ti];
                 const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
                 const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
-                if (ln == 0) TM->coff[t] = total;
                 total += nvar * __popcll(TM->keep[t]);
             }
             if (ln == 0) {
@@ -357,36 +405,80 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             if (ln < 2) {
                 for (int t = ln; t < 34; t += 2) node.keep[t] = TM->keep[t];
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            // ---- C: children
-            for (int item = ln; item < n_tiles * 68; item += 32) {
-                const int t = TM->tiles[item / 68], variant = (item / 34) & 1, d = item % 34;
-                const u64 kp = TM->keep[t];
-                if (!((kp >> d) & 1)) continue;
-                const int cnt = S.w.get(t);
-                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-                int tile, vidx;  // vidx: index of this variant among the tile's existing draw entries
-                if (!aka_in_wall) { if (variant == 1) continue; tile = t; vidx = 0; }
-                else if (variant == 0) { if (cnt < 2) continue; tile = t; vidx = 0; }
-                else { tile = akaize(t); vidx = cnt >= 2 ? 1 : 0; }
-                SpState S2 = S;
-                sp_deal(S2, tile);
-                const int c = S2.h.get(d);
-                int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
-                if (d == T_5M && (S2.akas & 1) && c == 1) dt = T_5MR;
-                else if (d == T_5P && (S2.akas & 2) && c == 1) dt = T_5PR;
-                else if (d == T_5S && (S2.akas & 4) && c == 1) dt = T_5SR;
-                sp_discard(S2, dt);
-                bool fresh;
-                const int cs = sp_insert(W, X, S2, fresh);
-                if (fresh && cs >= 0) {
-                    int idx = atomicAdd(&X->n_list, 1);
-                    if (idx < SP_CAP) W->list[idx] = (u32)cs;
-                    else X->overflow = 1;
+            // ---- C: children, in super-chunks of at most SP_CCAP.  The (t, variant, d) triples are first compacted
+            // into an LDS list (one lane per draw entry), then every lane inserts children i, i+32 with both first
+            // hash probes in flight.
+            int ti_next = 0, cpos = child_base;
+            while (ti_next < n_tiles) {
+                int n_ch = 0, ti_end = ti_next;
+                while (ti_end < n_tiles) {
+                    const int t = TM->tiles[ti_end];
+                    const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                    const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
+                    const int c = nvar * __popcll(TM->keep[t]);
+                    if (n_ch + c > SP_CCAP) break;
+                    if (ln == 0) TM->coff[t] = n_ch;
+                    n_ch += c;
+                    ti_end++;
                 }
-                const int pos = child_base + TM->coff[t] + vidx * __popcll(kp) + __popcll(kp & ((1ull << d) - 1));
-                if (pos < SP_POOL) W->pool[pos] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                for (int g = ln; g < 2 * (ti_end - ti_next); g += 32) {
+                    const int t = TM->tiles[ti_next + (g >> 1)], variant = g & 1;
+                    const int cnt = S.w.get(t);
+                    const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                    int vidx;  // index of this variant among the tile's existing draw entries
+                    if (!aka_in_wall) { if (variant == 1) continue; vidx = 0; }
+                    else if (variant == 0) { if (cnt < 2) continue; vidx = 0; }
+                    else vidx = cnt >= 2 ? 1 : 0;
+                    u64 rest = TM->keep[t];
+                    const int nk = __popcll(rest);
+                    int pos = TM->coff[t] + vidx * nk;
+                    for (int k = 0; k < nk; k++, pos++) {
+                        const int d = __ffsll((long long)rest) - 1;
+                        rest &= rest - 1;
+                        TM->u.ex.items[pos] = (unsigned short)(t | (d << 6) | (variant << 12));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                auto child_state = [&](int i) {
+                    const int it = TM->u.ex.items[i];
+                    const int t = it & 63, d = (it >> 6) & 63, variant = it >> 12;
+                    const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                    const int tile = (aka_in_wall && variant == 1) ? akaize(t) : t;
+                    SpState S2 = S;
+                    sp_deal(S2, tile);
+                    const int c = S2.h.get(d);
+                    int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+                    if (d == T_5M && (S2.akas & 1) && c == 1) dt = T_5MR;
+                    else if (d == T_5P && (S2.akas & 2) && c == 1) dt = T_5PR;
+                    else if (d == T_5S && (S2.akas & 4) && c == 1) dt = T_5SR;
+                    sp_discard(S2, dt);
+                    return S2;
+                };
+                auto child_done = [&](int i, SpIns& I) {
+                    bool fresh;
+                    const int cs = sp_insert_finish(W, X, I, fresh);
+                    if (fresh && cs >= 0) {
+                        int idx = atomicAdd(&X->n_list, 1);
+                        if (idx < SP_CAP) W->list[idx] = (u32)cs;
+                        else X->overflow = 1;
+                    }
+                    if (cpos + i < SP_POOL) W->pool[cpos + i] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
+                };
+                for (int i = ln; i < n_ch; i += 64) {
+                    const bool two = i + 32 < n_ch;
+                    SpIns Ia, Ib;
+                    sp_insert_begin(W, child_state(i), Ia);
+                    if (two) sp_insert_begin(W, child_state(i + 32), Ib);
+                    child_done(i, Ia);
+                    if (two) child_done(i + 32, Ib);
+                }
+                cpos += n_ch;
+                ti_next = ti_end;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
             }
             return;
         }
