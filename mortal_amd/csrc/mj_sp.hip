@@ -528,32 +528,28 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
     // monotone).  nx_* = lane i's folded child values at turn i (L > 0) or scores (L == 0).
     auto accumulate = [&](int count, float nx_t, float nx_w, float nx_e, bool is_scores, const float* scores) {
         const float* tp = X->tsumo_prob[count - 1];
-        float vt[SP_T], vw[SP_T], ve[SP_T], pr[SP_T];
-#pragma unroll
-        for (int j = 0; j < SP_T; j++) {
+        const bool lane_on = ln < T && my_m != 0.f;
+        // rolled on purpose: the kernel is latency-bound and occupancy-limited by registers, not by ALU issue
+#pragma unroll 1
+        for (int j = 0; j < T; j++) {
             // next[j + 1] comes from lane j + 1 (only used when j < T - 1)
-            vt[j] = __shfl(nx_t, (j + 1) & 31, 32);
-            vw[j] = __shfl(nx_w, (j + 1) & 31, 32);
-            ve[j] = __shfl(nx_e, (j + 1) & 31, 32);
-            const float n = nt[j];  // rows are zero-padded beyond T
-            pr[j] = (j < T && j >= ln && ln < T && my_m != 0.f && n != 0.f) ? tp[j] * n / my_m : -1.f;
-        }
-#pragma unroll
-        for (int j = 0; j < SP_T; j++) {
-            const float prob = pr[j];
-            if (prob >= 0.f) {  // probabilities are never negative; -1 marks "not part of this lane's sum"
-                if (is_scores) {
-                    int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
-                                   (int)(X->calc_haitei && j == T - 1);
-                    acc_w += prob;
-                    acc_e += prob * scores[han_plus];
-                } else {
-                    if (L == 1) acc_t += prob;
-                    if (j < T - 1) {
-                        if (L > 1) acc_t += prob * vt[j];
-                        acc_w += prob * vw[j];
-                        acc_e += prob * ve[j];
-                    }
+            const float vt = __shfl(nx_t, (j + 1) & 31, 32);
+            const float vw = __shfl(nx_w, (j + 1) & 31, 32);
+            const float ve = __shfl(nx_e, (j + 1) & 31, 32);
+            const float n = nt[j];
+            if (!(lane_on && j >= ln && n != 0.f)) continue;
+            const float prob = tp[j] * n / my_m;
+            if (is_scores) {
+                int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
+                               (int)(X->calc_haitei && j == T - 1);
+                acc_w += prob;
+                acc_e += prob * scores[han_plus];
+            } else {
+                if (L == 1) acc_t += prob;
+                if (j < T - 1) {
+                    if (L > 1) acc_t += prob * vt;
+                    acc_w += prob * vw;
+                    acc_e += prob * ve;
                 }
             }
         }
@@ -724,7 +720,7 @@ MJD int f32_total_cmp(float a, float b) {
     return (x > y) - (x < y);
 }
 
-__global__ __launch_bounds__(SP_THREADS, 3) void mj_k_sp(SpParams P) {
+__global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ TableOne st;
     __shared__ int s_row;
