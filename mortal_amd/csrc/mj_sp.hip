@@ -24,6 +24,8 @@
 #define SP_MAX_CAND 14
 
 #define SP_POOL (SP_CAP * 32)   // child-slot pool entries per workgroup
+#define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
+#define SP_L0_MAX 17            // winning draw entries per tenpai state (13 waits + 3 aka variants; 272-byte node area)
 struct SpNode {                // one 3n+1 state
     u64 k0, k1, k2, k3;        // hand.mp | hand.sz + akas_in_hand<<48 | wall.mp | wall.sz + akas_in_wall<<48
     float tenpai[SP_T], win[SP_T], ev[SP_T];
@@ -36,6 +38,7 @@ struct SpWork {                // per-workgroup scratch in HBM (persistent workg
     SpNode node[SP_CAP];
     u32 list[SP_CAP];          // slots grouped by level: level L occupies [lvl_begin[L], lvl_end[L])
     unsigned short pool[SP_POOL];
+    u32 items[SP_ITEMS];       // level 0: (state, winning tile, variant) work items of the dense scoring pass
 };
 
 struct SpParams {
@@ -111,6 +114,7 @@ struct SpCtx {  // per-decision constants (LDS)
     int lvl_begin[5], lvl_end[5];
     int n_list;
     int n_pool;
+    int n_items;
     int overflow;
     unsigned long long* prof;  // optional phase timers (MJ_SP_PROF)
     // candidates
@@ -279,7 +283,7 @@ struct SpTeam {
             u64 rowd[34];    //         table row of (h - d) in suit(d)
             unsigned short items[SP_CCAP];  // children of the current super-chunk: t | d << 6 | variant << 12
         } ex;
-        float sc[34][2][4];  // level 0: get_score() of every (winning tile, variant), one lane each
+        float sc[SP_L0_MAX][4];  // level 0: get_score() of every draw entry (filled by sp_l0_score through the node)
         struct {             // level > 0 evaluation
             float buf[SP_CH][3][SP_T];          // values of the current batch of children, one turn per lane
             unsigned short cs[SP_CCAP];         // child slots
@@ -287,6 +291,78 @@ struct SpTeam {
         } ev;
     } u;
 };
+
+// ---- Level 0 (tenpai states) is evaluated in three passes so that the expensive, divergent scoring of the winning
+// draws (get_score: agari decomposition + yaku + fu) runs with every lane busy instead of ~3 lanes per 32-lane team:
+//   probe : team per state — which draws win (34 shanten probes)        -> node.req, one work item per draw entry
+//   score : THREAD per item, dense across the workgroup                  -> 4 scores per item in the node (keep[] area)
+//   sum   : team per state — sp_visit_team<true>(L = 0) accumulates the scores in the reference's order
+__device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, int slot) {
+    const int ln = threadIdx.x & 31;
+    const int sh32 = threadIdx.x & 32;
+    SpNode& node = W->node[slot];
+    const SpState S = sp_state_of(node);
+    const int ld3 = X->len_div3;
+    const ShBase B = sh_base(Tb, S.h);
+    u64 req = 0;
+#pragma unroll
+    for (int rnd = 0; rnd < 2; rnd++) {
+        const int t = ln + 32 * rnd;
+        bool is_req = false;
+        if (t < 34 && S.w.get(t) > 0) {
+            const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
+            const u64 r = sh_load(Tb, st, B.key[st] + sh_pow(t));
+            const int sh = sh_eval(st == 0 ? r : B.row[0], st == 1 ? r : B.row[1], st == 2 ? r : B.row[2], st == 3 ? r : B.row[3],
+                                   ld3, B.pairs + (hc == 1), B.kinds + (hc == 0), B.kpairs + (yao && hc == 1),
+                                   B.kkinds + (yao && hc == 0));
+            is_req = sh == -1;
+        }
+        const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull;
+        req |= bal << (32 * rnd);
+    }
+    req &= (1ull << 34) - 1;
+    // draw entries in the reference's order: plain tile (if a non-red copy is left), then the red five
+    int cnt = 0;
+    u32 mine = 0;
+    for (u64 rest = req; rest; rest &= rest - 1) {
+        const int t = __ffsll((long long)rest) - 1;
+        const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+        if (!aka_in_wall || S.w.get(t) >= 2) {
+            if (ln == cnt) mine = (u32)t << 19;
+            cnt++;
+        }
+        if (aka_in_wall) {
+            if (ln == cnt) mine = ((u32)t << 19) | (1u << 25);
+            cnt++;
+        }
+    }
+    if (cnt > SP_L0_MAX) { X->overflow = 1; cnt = SP_L0_MAX; }
+    int base = 0;
+    if (ln == 0) {
+        base = atomicAdd(&X->n_items, cnt);
+        node.req = req;
+        node.child_off = 0;  // bit i: draw entry i has a yaku (set by sp_l0_score)
+    }
+    base = __shfl(base, 0, 32);
+    if (ln < cnt) {
+        if (base + ln < SP_ITEMS) W->items[base + ln] = (u32)slot | ((u32)ln << 14) | mine;
+        else X->overflow = 1;
+    }
+}
+__device__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
+    const int slot = item & 0x3FFF, idx = (item >> 14) & 31, t = (item >> 19) & 63, variant = (item >> 25) & 1;
+    SpNode& node = W->node[slot];
+    SpState S1 = sp_state_of(node);
+    const int tile = variant ? akaize(t) : t;
+    sp_deal(S1, tile);
+    float scv[4];
+    if (sp_get_score(Tb, X, S1, tile, scv)) {
+        float2* dst = reinterpret_cast<float2*>(node.keep) + 2 * idx;  // node.keep is 8-byte aligned
+        dst[0] = make_float2(scv[0], scv[1]);
+        dst[1] = make_float2(scv[2], scv[3]);
+        atomicOr(&node.child_off, 1u << idx);
+    }
+}
 
 // Visit one 3n+1 state of shanten level L with a TEAM of 32 lanes (half a wavefront).
 //   EVAL == false (L >= 1): find the required draws and shanten-keeping discards, insert every child state (level
@@ -313,7 +389,8 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
     u64 req = 0;
     int child_base = 0;
 
-    if (!EVAL || L == 0) {
+    u32 l0_yaku = 0;  // level 0: bit i = draw entry i has a yaku
+    if (!EVAL) {
         // ---- A
         const ShBase B = sh_base(Tb, S.h);
 #pragma unroll
@@ -482,27 +559,7 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             }
             return;
         }
-        // level 0 (tenpai): score every winning draw (calc.rs:640-758), one lane per (tile, variant); keep[t] bit v
-        // records that variant v of tile t has a yaku
-        for (int item = ln; item < n_tiles * 2; item += 32) {
-            const int t = TM->tiles[item >> 1], variant = item & 1;
-            const int cnt = S.w.get(t);
-            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-            int tile;
-            if (!aka_in_wall) { if (variant == 1) continue; tile = t; }
-            else if (variant == 0) { if (cnt < 2) continue; tile = t; }
-            else tile = akaize(t);
-            SpState S1 = S;
-            sp_deal(S1, tile);
-            float scv[4];
-            if (sp_get_score(Tb, X, S1, tile, scv)) {
-                for (int q = 0; q < 4; q++) TM->u.sc[t][variant][q] = scv[q];
-                atomicOr((unsigned long long*)&TM->keep[t], 1ull << variant);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-    } else {
+    } else if (L > 0) {
         // level > 0: the expansion pass left req / keep / child slots in the node; fetch them in one round trip
         req = node.req;
         child_base = (int)node.child_off;
@@ -511,6 +568,15 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             const int t = ln + 32 * rnd;
             if (t < 34) TM->keep[t] = node.keep[t];
         }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    } else {
+        // level 0: sp_l0_probe left the winning draws in node.req, sp_l0_score the scores of every draw entry
+        req = node.req;
+        l0_yaku = __hip_atomic_load(&node.child_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // set by L2 atomics
+        const float* src = reinterpret_cast<const float*>(node.keep);
+        float* dst = &TM->u.sc[0][0];
+        for (int i = ln; i < SP_L0_MAX * 4; i += 32) dst[i] = src[i];
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
     }
@@ -556,11 +622,11 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
     };
 
     if (L == 0) {
-        for (int t = 0; t < 34; t++) {
-            if (!((req >> t) & 1)) continue;
+        int idx = 0;  // draw entry index (same enumeration as sp_l0_probe)
+        for (u64 rest = req; rest; rest &= rest - 1) {
+            const int t = __ffsll((long long)rest) - 1;
             const int cnt = S.w.get(t);
             const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-            // draw entries in the reference's order: plain tile (count-1 if the aka is still in the wall), then the aka
             for (int variant = 0; variant < 2; variant++) {
                 int count;
                 if (!aka_in_wall) {
@@ -572,10 +638,11 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                 } else {
                     count = 1;
                 }
-                if (!((TM->keep[t] >> variant) & 1)) continue;  // no yaku with this tile
+                const int e = idx++;
+                if (e >= SP_L0_MAX || !((l0_yaku >> e) & 1)) continue;  // no yaku with this tile
                 float scores[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) scores[q] = TM->u.sc[t][variant][q];
+                for (int q = 0; q < 4; q++) scores[q] = TM->u.sc[e][q];
                 accumulate(count, 0.f, 0.f, 0.f, true, scores);
             }
         }
@@ -953,6 +1020,15 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             // evaluate bottom-up
             for (int lv = 0; lv <= cur_shanten; lv++) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
+                if (lv == 0) {
+                    if (tid == 0) X.n_items = 0;
+                    __syncthreads();
+                    for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_l0_probe(c_mj_tables, W, &X, (int)W->list[i]);
+                    __syncthreads();
+                    const int n_items = min(X.n_items, SP_ITEMS);
+                    for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
+                    __syncthreads();
+                }
                 for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<true>(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 __syncthreads();
                 if (lv == 0) t_3 = wall_clock64();
