@@ -27,6 +27,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 KEY = 0xD5DFAA4CEF265CD7
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_WRITE_CEILING_GBS = 4870.0  # torch fill_/zero_ of the same 9.2 GB on this GPU (tools/hbm_write_peak.py, profiles/)
 STATE_READ_BYTES = 1500  # per-decision state read
 
 
@@ -220,6 +221,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_write_ceiling": achieved / HBM_WRITE_CEILING_GBS,
+                "measured_write_ceiling": HBM_WRITE_CEILING_GBS,
                 "traffic": traffic,
                 "traffic_unit": "B/launch",
                 "traffic_source": traffic_src,
