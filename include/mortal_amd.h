@@ -53,6 +53,13 @@ int mj_pool_reset(MjPool* pool, const uint64_t* nonces, const uint64_t* keys, co
 /* Per-agent engine attributes (agent/mortal.rs:53-74): obs version (0 = keep), quick-eval, agari guard. */
 int mj_pool_configure(MjPool* pool, int agent, int version, int enable_quick_eval,
                       int enable_rule_based_agari_guard);
+/* Per-table mjai event log (arena/board.rs:189-197 add_log -> arena/result.rs:32-51 dump_json_log), off by default.
+ * words_per_table u64 words are reserved per table (a hanchan needs <= ~250 words per kyoku); a table that overflows
+ * ends with error MJ_ERR_LOG_OVERFLOW (7).  Word format: mortal_amd/csrc/mj_state.h LG_*; decoded by mortal_amd/mjai_log.py. */
+int mj_pool_enable_log(MjPool* pool, uint32_t words_per_table);
+int mj_log_lengths(MjPool* pool, uint32_t* len_out /* [n_tables] host */, void* stream);
+int mj_log_read(MjPool* pool, int table0, int n, uint64_t* words_out /* [n][words_per_table] host */, void* stream);
+
 /* Steady-state mode for throughput runs: finished tables restart with nonce += stride. 0 disables. */
 int mj_pool_set_refill(MjPool* pool, uint64_t nonce_stride);
 

@@ -2,8 +2,8 @@
 the MI355X table pool (mortal_amd).  Put the repository root on PYTHONPATH and the reference's drivers
 (`mortal/one_vs_three.py`, `mortal/player.py`) import this package unchanged.
 
-Implemented this round: `libriichi.consts`, `libriichi.arena` (OneVsThree/TwoVsTwo `py_vs_py`).
-"Next" rows, present as stubs that raise NotImplementedError on use: `libriichi.stat`,
+Implemented: `libriichi.consts`, `libriichi.arena` (OneVsThree/TwoVsTwo `py_vs_py`, incl. `log_dir` mjai dumps),
+`libriichi.stat.Stat`.  "Next" rows, present as stubs that raise NotImplementedError on use:
 `libriichi.dataset`, `libriichi.mjai`, `libriichi.state`.
 """
 import importlib as _il

@@ -1,5 +1,5 @@
-"""libriichi.stat — a "next" row of the hot-path scope table; not built this round."""
+"""libriichi.stat (reference libriichi/src/stat.rs): `Stat.from_dir(dir, player_name, disable_progress_bar=False)`,
+`Stat.from_log`, 44 counters, derived-rate getters, `total_pt` / `avg_pt` — see mortal_amd/stat.py."""
+from mortal_amd.stat import Stat  # noqa: F401
 
-
-def __getattr__(name):
-    raise NotImplementedError(f"libriichi.stat.{name} is not implemented yet (SURVEY.md §8(f))")
+__all__ = ["Stat"]

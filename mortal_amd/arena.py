@@ -12,6 +12,8 @@ We pass `[proxy]` whose `__array_function__` answers `np.stack` with the pre-sta
 engine consumes the encoded batch in place.  Engines that define `react_batch_device(obs, masks)` (our extension,
 returns a device int tensor of actions) skip the `.tolist()` round trip as well.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -48,7 +50,7 @@ def _check_engine(engine):
 class BatchRunner:
     """Drives N tables to completion with up to two engines (agent 0 / agent 1)."""
 
-    def __init__(self, engines, seeds, agent_of_seat, device=None, deal_algo=0):
+    def __init__(self, engines, seeds, agent_of_seat, device=None, deal_algo=0, keep_log=False):
         self.engines = engines
         self.cfg = [_check_engine(e) for e in engines]
         dev = device
@@ -58,6 +60,10 @@ class BatchRunner:
         self.device = torch.device(dev)
         n = len(seeds)
         self.pool = TablePool(n, version=self.cfg[0]["version"], deal_algo=deal_algo, device=str(self.device))
+        if keep_log:
+            self.pool.enable_log()
+        self.seeds = list(seeds)
+        self.agent_of_seat = np.asarray(agent_of_seat, dtype=np.uint8)
         self.pool.reset(seeds, game_ids=np.arange(n), agent_of_seat=agent_of_seat, n_games_total=n)
         for a, c in enumerate(self.cfg):
             self.pool.configure(a, enable_quick_eval=c["quick"], version=c["version"], enable_rule_based_agari_guard=c["guard"])
@@ -121,6 +127,22 @@ class BatchRunner:
             raise MortalAmdError("some games did not finish")
         return scores
 
+    def dump_logs(self, log_dir, splits):
+        """Write one mjai `.json.gz` per game (result.rs:32-51, one_vs_three.rs:195-225); `splits` = files per seed."""
+        from . import mjai_log
+
+        os.makedirs(log_dir, exist_ok=True)
+        names_of_agent = [c["name"] for c in self.cfg]
+        if len(names_of_agent) == 1:
+            names_of_agent = names_of_agent * 2
+        paths = []
+        for g, words in enumerate(self.pool.read_logs()):
+            names = [names_of_agent[(int(self.agent_of_seat[g]) >> s) & 1] for s in range(4)]  # game.rs:186
+            events = mjai_log.decode_events(words)
+            name = f"{self.seeds[g][0]}_{self.seeds[g][1]}_{'abcd'[g % splits]}.json.gz"
+            paths.append(mjai_log.write_game_log_as(os.path.join(log_dir, name), names, self.seeds[g], events))
+        return paths
+
     def close(self):
         self.pool.close()
 
@@ -143,15 +165,15 @@ class OneVsThree:
 
     def py_vs_py(self, challenger, champion, seed_start, seed_count):
         """Returns the rank histogram [1st, 2nd, 3rd, 4th] of the challenger over seed_count*4 hanchan."""
-        if self.log_dir is not None:
-            raise NotImplementedError("log_dir (mjai .json.gz dumps, result.rs:32-51) is a 'next' row (SURVEY §8(f).1)")
         n = int(seed_count) * 4
         seeds = [(int(seed_start[0]) + g // 4, int(seed_start[1])) for g in range(n)]  # one_vs_three.rs:140-142
         # challenger (agent 0) sits at seat g % 4, the champion (agent 1) on the other three (one_vs_three.rs:144-191)
         aos = np.array([0xF & ~(1 << (g % 4)) for g in range(n)], dtype=np.uint8)
-        runner = BatchRunner([challenger, champion], seeds, aos)
+        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None)
         try:
             scores = runner.run()
+            if self.log_dir is not None:
+                runner.dump_logs(self.log_dir, 4)
         finally:
             runner.close()
         rankings = [0, 0, 0, 0]
@@ -174,15 +196,15 @@ class TwoVsTwo:
         self.log_dir = log_dir
 
     def py_vs_py(self, challenger, champion, seed_start, seed_count):
-        if self.log_dir is not None:
-            raise NotImplementedError("log_dir is a 'next' row (SURVEY §8(f).1)")
         n = int(seed_count) * 2
         seeds = [(int(seed_start[0]) + g // 2, int(seed_start[1])) for g in range(n)]  # two_vs_two.rs:138-140
         # split A: challenger at seats 0,2; split B: 1,3 (two_vs_two.rs:142-172)
         aos = np.array([0b1010 if g % 2 == 0 else 0b0101 for g in range(n)], dtype=np.uint8)
-        runner = BatchRunner([challenger, champion], seeds, aos)
+        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None)
         try:
             runner.run()
+            if self.log_dir is not None:
+                runner.dump_logs(self.log_dir, 2)
         finally:
             runner.close()
         return None

@@ -77,6 +77,9 @@ std::vector<MjGatherEnt> build_gather() {
 
 struct MjPool {
     int n_tables = 0, n_blocks = 0, deal_algo = 0, max_rows = 0;
+    uint64_t* log = nullptr;   // optional event log [n_tables][log_cap]
+    uint32_t* log_len = nullptr;
+    uint32_t log_cap = 0;
     int version[2] = {4, 4};  // obs version per agent (engine.version, agent/mortal.rs:57)
     TableBlock* blocks = nullptr;
     uint32_t* rows[2] = {nullptr, nullptr};
@@ -223,6 +226,8 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->sp_work);
     hipFree(P->sp_queue);
     hipFree(P->sp_err);
+    hipFree(P->log);
+    hipFree(P->log_len);
     if (P->n_rows_host) hipHostFree(P->n_rows_host);
     hipFree(P->counters);
     hipFree(P->final_scores);
@@ -261,8 +266,34 @@ int mj_pool_reset(MjPool* P, const uint64_t* nonces, const uint64_t* keys, const
     HIP_OK(hipMalloc(&P->final_done, (size_t)P->n_games_total));
     HIP_OK(hipMemset(P->final_scores, 0, (size_t)P->n_games_total * 4 * sizeof(int)));
     HIP_OK(hipMemset(P->final_done, 0, (size_t)P->n_games_total));
+    if (P->log_len) HIP_OK(hipMemset(P->log_len, 0, (size_t)P->n_tables * sizeof(uint32_t)));
     P->cycles = 0;
     P->rows_valid = false;
+    return 0;
+}
+
+int mj_pool_enable_log(MjPool* P, uint32_t words_per_table) {
+    if (!P) return fail("null pool");
+    if (P->log) { hipFree(P->log); hipFree(P->log_len); P->log = nullptr; P->log_len = nullptr; }
+    P->log_cap = words_per_table;
+    if (words_per_table == 0) return 0;
+    HIP_OK(hipMalloc(&P->log, (size_t)P->n_tables * words_per_table * sizeof(uint64_t)));
+    HIP_OK(hipMalloc(&P->log_len, (size_t)P->n_tables * sizeof(uint32_t)));
+    HIP_OK(hipMemset(P->log_len, 0, (size_t)P->n_tables * sizeof(uint32_t)));
+    return 0;
+}
+int mj_log_lengths(MjPool* P, uint32_t* len_out, void* stream) {
+    if (!P || !P->log) return fail("event log is not enabled");
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    HIP_OK(hipMemcpy(len_out, P->log_len, (size_t)P->n_tables * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+int mj_log_read(MjPool* P, int table0, int n, uint64_t* words_out, void* stream) {
+    if (!P || !P->log) return fail("event log is not enabled");
+    if (table0 < 0 || n < 0 || table0 + n > P->n_tables) return fail("table range out of bounds");
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    HIP_OK(hipMemcpy(words_out, P->log + (size_t)table0 * P->log_cap, (size_t)n * P->log_cap * sizeof(uint64_t),
+                     hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -298,6 +329,9 @@ int mj_step_q(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, 
     sp.actions[1] = a1;
     sp.q_values[0] = q0;
     sp.q_values[1] = q1;
+    sp.log = P->log;
+    sp.log_len = P->log_len;
+    sp.log_cap = P->log_cap;
     sp.deal_algo = P->deal_algo;
     for (int a = 0; a < 2; a++) {
         sp.enable_quick_eval[a] = P->enable_quick_eval[a];

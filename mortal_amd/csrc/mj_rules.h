@@ -20,6 +20,9 @@ struct LaneT {  // a table viewed through lane `l` of a block (pool block in HBM
     BlockT* B;
     int l;
     const MjTablesDev* T;
+    uint64_t* log = nullptr;   // this table's event log (NULL = logging off), see mj_state.h LG_*
+    uint32_t* log_len = nullptr;
+    uint32_t log_cap = 0;
 };
 typedef LaneT<TableBlock> Lane;
 #define F(f) (L.B->f[L.l])
@@ -27,6 +30,18 @@ typedef LaneT<TableBlock> Lane;
 #define F2(f, i, j) (L.B->f[i][j][L.l])
 #define F3(f, i, j, k) (L.B->f[i][j][k][L.l])
 #define BIT(t) (1ull << (t))
+
+template <class LN> MJD void log_push(const LN& L, uint64_t w) {
+    if (!L.log) return;
+    const uint32_t n = *L.log_len;
+    if (n < L.log_cap) L.log[n] = w;
+    else L.B->err[L.l] = L.B->err[L.l] ? L.B->err[L.l] : (uint8_t)MJ_ERR_LOG_OVERFLOW;
+    *L.log_len = n + 1;
+}
+template <class LN> MJD void log_push_i32x4(const LN& L, const int v[4]) {
+    log_push(L, (uint64_t)(uint32_t)v[0] | ((uint64_t)(uint32_t)v[1] << 32));
+    log_push(L, (uint64_t)(uint32_t)v[2] | ((uint64_t)(uint32_t)v[3] << 32));
+}
 
 template <class LN> MJD Hand load_hand(const LN& L, int s) {
     Hand h;
@@ -603,6 +618,22 @@ template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
     F(yama_n) = 69;
     F(tiles_left) = 69;
     F(flags) |= TF_HAIPAI_DONE;
+    if (L.log) {  // StartKyoku + the oya's first Tsumo (board.rs:206-239)
+        log_push(L, LG_WORD(LG_START_KYOKU, 0, 0, marker, kyoku, 0, 0, 0, 0) | ((uint64_t)honba << LG_HONBA_SHIFT) |
+                        ((uint64_t)F(kyotaku) << LG_KYOTAKU_SHIFT));
+        int sc[4];
+        for (int i = 0; i < 4; i++) sc[i] = F1(scores, i);
+        log_push_i32x4(L, sc);
+        for (int w = 0; w < 7; w++) {
+            uint64_t v = 0;
+            for (int k = 0; k < 8; k++) {
+                const int i = w * 8 + k;
+                if (i < 52) v |= (uint64_t)F1(wall, i) << (8 * k);
+            }
+            log_push(L, v);
+        }
+        log_push(L, LG_WORD(LG_TSUMO, oya, 0, tile, 0, 0, 0, 0, 0));
+    }
     ev_tsumo(L, oya, tile);
 }
 

@@ -49,7 +49,7 @@ enum {
 // error codes (sticky per table; mj_pool_errors reports the first)
 enum {
     MJ_OK = 0, MJ_ERR_ILLEGAL_ACTION = 1, MJ_ERR_KAWA_OVERFLOW = 2, MJ_ERR_WALL = 3, MJ_ERR_INTERNAL = 4,
-    MJ_ERR_NOT_HORA = 5, MJ_ERR_FOUR_WIND = 6,
+    MJ_ERR_NOT_HORA = 5, MJ_ERR_FOUR_WIND = 6, MJ_ERR_LOG_OVERFLOW = 7,
 };
 
 // kawa entry (u64):  bit0 valid(Some) | 1..6 tile(0..36) | 7 is_dora | 8 is_tedashi | 9 is_riichi
@@ -179,3 +179,19 @@ struct MjTablesDev {
     const uint32_t* agari_divs;  // n x 5: n_div, div[4]
     uint32_t n_agari;
 };
+// ---- optional per-table mjai event log (arena/board.rs:189-197 add_log; result.rs:32-51 dump_json_log).
+// One u64 header word per event, followed by payload words for start_kyoku (2 score words, 7 haipai words = 52 tiles,
+// 8 per word, seat-major), hora (2 delta words, 1 ura word = 6 bits per indicator) and ryukyoku (2 delta words).
+enum MjLogType : uint32_t {
+    LG_START_KYOKU = 1, LG_TSUMO, LG_DAHAI, LG_CHI, LG_PON, LG_DAIMINKAN, LG_KAKAN, LG_ANKAN, LG_DORA, LG_REACH,
+    LG_REACH_ACCEPTED, LG_HORA, LG_RYUKYOKU, LG_END_KYOKU,
+};
+#define LG_WORD(type, actor, target, pai, c0, c1, c2, c3, tsumogiri)                                                   \
+    ((uint64_t)(type) | ((uint64_t)(actor) << 4) | ((uint64_t)(target) << 6) | ((uint64_t)((pai) & 63) << 8) |         \
+     ((uint64_t)((c0) & 63) << 14) | ((uint64_t)((c1) & 63) << 20) | ((uint64_t)((c2) & 63) << 26) |                   \
+     ((uint64_t)((c3) & 63) << 32) | ((uint64_t)((tsumogiri) & 1) << 38))
+#define LG_NURA_SHIFT 39   /* hora: number of ura indicators (0..5) */
+#define LG_HONBA_SHIFT 44  /* start_kyoku: honba (8 bits); kyoku (0..11) travels in the c0 field, dora marker in pai */
+#define LG_KYOTAKU_SHIFT 52
+
+

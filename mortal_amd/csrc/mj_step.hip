@@ -23,6 +23,9 @@ struct StepParams {
     MjTablesDev tables;
     const int* actions[2];     // per agent, indexed by row id of the previous cycle (NULL on the first cycle)
     const float* q_values[2];  // per agent [rows][46] or NULL (needed only by the agari guard)
+    uint64_t* log;             // [n_tables][log_cap] event words or NULL (logging off)
+    uint32_t* log_len;         // [n_tables]
+    uint32_t log_cap;
     int deal_algo;
     int enable_quick_eval[2];
     int enable_agari_guard[2];
@@ -167,12 +170,20 @@ template <class LN> MJDN Reaction decode_action(const LN& L, int s, int action, 
 }
 
 // ---------------------------------------------------------------- board (arena/board.rs)
-template <class LN> MJD void abortive_ryukyoku(const LN& L) { F(flags) |= TF_HAS_ABORTIVE; }  // board.rs:502-509
+template <class LN> MJD void abortive_ryukyoku(const LN& L) {  // board.rs:502-509
+    F(flags) |= TF_HAS_ABORTIVE;
+    if (L.log) {
+        const int z[4] = {0, 0, 0, 0};
+        log_push(L, LG_WORD(LG_RYUKYOKU, 0, 0, 0, 0, 0, 0, 0, 0));
+        log_push_i32x4(L, z);
+    }
+}
 
 template <class LN> MJD void check_riichi_accepted(const LN& L) {  // board.rs:342-351
     int a = F(riichi_to_be_accepted);
     if (a != MJ_NONE) {
         F(riichi_to_be_accepted) = MJ_NONE;
+        log_push(L, LG_WORD(LG_REACH_ACCEPTED, a, 0, 0, 0, 0, 0, 0, 0));
         ev_reach_accepted(L, a);
     }
 }
@@ -181,6 +192,7 @@ template <class LN> MJD void add_new_dora(const LN& L) {  // board.rs:353-364
     if (n == 0) { set_err(L, MJ_ERR_WALL); return; }
     n -= 1;
     F(dora_n) = (u8)n;
+    log_push(L, LG_WORD(LG_DORA, 0, 0, F1(wall, 56 + n), 0, 0, 0, 0, 0));
     ev_dora(L, F1(wall, 56 + n));
 }
 
@@ -211,6 +223,21 @@ template <class LN> MJDN void exhaustive_ryukyoku(const LN& L) {  // board.rs:24
     }
     for (int k = 0; k < 4; k++) F1(kyoku_deltas, k) += deltas[k];
     F(flags) = fl;
+    if (L.log) {
+        log_push(L, LG_WORD(LG_RYUKYOKU, 0, 0, 0, 0, 0, 0, 0, 0));
+        log_push_i32x4(L, deltas);
+    }
+}
+
+// Hora{actor, target, deltas, ura_markers}: the ura indicators are listed only for a winner in riichi (board.rs:418-426)
+template <class LN> MJD void log_hora(const LN& L, int actor, int target, const int d[4], int n_ura) {
+    if (!L.log) return;
+    const int n = accepted(L, actor) ? n_ura : 0;
+    log_push(L, LG_WORD(LG_HORA, actor, target, 0, 0, 0, 0, 0, 0) | ((uint64_t)n << LG_NURA_SHIFT));
+    log_push_i32x4(L, d);
+    uint64_t u = 0;
+    for (int i = 0; i < n; i++) u |= (uint64_t)F1(wall, 61 + i) << (6 * i);
+    log_push(L, u);
 }
 
 template <class LN> MJDN void handle_hora(const LN& L, int single_actor, int single_target, const Reaction rx[4]) {  // board.rs:366-471
@@ -247,6 +274,7 @@ template <class LN> MJDN void handle_hora(const LN& L, int single_actor, int sin
             kyotaku_point = 0;
             honba_left = 0;
             for (int i = 0; i < 4; i++) F1(kyoku_deltas, i) += d[i];
+            log_hora(L, actor, single_target, d, n_ura);
         }
         return;
     }
@@ -263,6 +291,7 @@ template <class LN> MJDN void handle_hora(const LN& L, int single_actor, int sin
     }
     d[single_actor] = tsumo_total(p, single_actor == oya) + kyotaku_point + honba_left * 300;
     for (int i = 0; i < 4; i++) F1(kyoku_deltas, i) += d[i];
+    log_hora(L, single_actor, single_target, d, n_ura);
 }
 
 // One BoardState::step (board.rs:511-678).  Returns true when the kyoku has ended.
@@ -324,6 +353,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
             fl &= ~TF_NEW_DORA_AT_TSUMO;
             F(flags) = fl;
             if (dora_now) add_new_dora(L);
+            log_push(L, LG_WORD(LG_TSUMO, F(tsumo_actor), 0, tile, 0, 0, 0, 0, 0));
             ev_tsumo(L, F(tsumo_actor), tile);
             break;
         }
@@ -332,6 +362,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
                 F(flags) = fl & ~TF_NEW_DORA_AT_DISCARD;
                 add_new_dora(L);
             }
+            log_push(L, LG_WORD(LG_DAHAI, ev.actor, 0, ev.pai, 0, 0, 0, 0, ev.tsumogiri));
             ev_dahai(L, ev.actor, ev.pai, ev.tsumogiri);
             const int next_actor = (ev.actor + 1) & 3;
             F(tsumo_actor) = (u8)next_actor;
@@ -372,6 +403,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
         case RX_CHI:
         case RX_PON:
             check_riichi_accepted(L);
+            log_push(L, LG_WORD(ev.type == RX_PON ? LG_PON : LG_CHI, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, 0, 0, 0));
             ev_chi_pon(L, ev.type == RX_PON, ev.actor, ev.target, ev.pai, ev.c0, ev.c1);
             break;
         case RX_ANKAN:
@@ -379,6 +411,8 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
                 F(flags) = fl & ~TF_NEW_DORA_AT_DISCARD;
                 add_new_dora(L);
             }
+            // consumed = [akaize(t), t, t, t] (agent/mortal.rs:505-520)
+            log_push(L, LG_WORD(LG_ANKAN, ev.actor, 0, 0, akaize(ev.pai), ev.pai, ev.pai, ev.pai, 0));
             ev_ankan(L, ev.actor, ev.pai);
             add_new_dora(L);
             F(tsumo_actor) = ev.actor;
@@ -389,13 +423,21 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
         case RX_KAKAN:
             if (fl & TF_NEW_DORA_AT_DISCARD) F(flags) = fl | TF_NEW_DORA_AT_TSUMO;
             check_riichi_accepted(L);
-            if (ev.type == RX_DAIMINKAN) ev_daiminkan(L, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, ev.c2);
-            else ev_kakan(L, ev.actor, ev.pai);
+            if (ev.type == RX_DAIMINKAN) {
+                log_push(L, LG_WORD(LG_DAIMINKAN, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, ev.c2, 0, 0));
+                ev_daiminkan(L, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, ev.c2);
+            } else {
+                // pai = the added tile; consumed = the pon it extends: red five first unless it is the added tile
+                const int t = deaka(ev.pai);
+                log_push(L, LG_WORD(LG_KAKAN, ev.actor, 0, ev.pai, is_aka(ev.pai) ? t : akaize(t), t, t, 0, 0));
+                ev_kakan(L, ev.actor, ev.pai);
+            }
             F(flags) |= TF_NEW_DORA_AT_DISCARD | TF_DEAL_FROM_RINSHAN;
             F(tsumo_actor) = ev.actor;
             F(kans) += 1;
             break;
         case RX_REACH:
+            log_push(L, LG_WORD(LG_REACH, ev.actor, 0, 0, 0, 0, 0, 0, 0));
             ev_reach(L, ev.actor);
             F(riichi_to_be_accepted) = ev.actor;
             break;
@@ -454,6 +496,7 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
             continue;
         }
         // ---- Poll::End (board.rs:149-157, game.rs:114-174)
+        log_push(L, LG_WORD(LG_END_KYOKU, 0, 0, 0, 0, 0, 0, 0, 0));
         fl = F(flags);
         for (int i = 0; i < 4; i++) F1(scores, i) += F1(kyoku_deltas, i);
         if (fl & TF_HAS_ABORTIVE) fl |= TF_CAN_RENCHAN;
@@ -493,6 +536,11 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
 __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
     const int table = blockIdx.x * 64 + threadIdx.x;
     Lane L = {P.blocks + blockIdx.x, (int)threadIdx.x, &c_mj_tables};
+    if (P.log && table < P.n_tables) {
+        L.log = P.log + (size_t)table * P.log_cap;
+        L.log_len = P.log_len + table;
+        L.log_cap = P.log_cap;
+    }
     u32 fl = F(flags);
     const bool active = table < P.n_tables && !(fl & TF_INACTIVE);
     bool live_after = false;
@@ -624,6 +672,7 @@ __global__ __launch_bounds__(64) void mj_k_refill(StepParams P) {
     if (table >= P.n_tables || (fl & TF_INACTIVE) || !(fl & TF_DONE)) return;
     F(seed_nonce) += P.refill_stride;
     F(game_id) += (u32)P.n_tables;
+    if (P.log_len) P.log_len[table] = 0;
     F(flags) = 0;
     F(kyoku) = 0;
     F(honba) = 0;

@@ -1,0 +1,113 @@
+"""Device event log -> mjai JSON lines (+ .json.gz dump).
+
+The step kernel appends one u64 header word (+ payload words) per event to a per-table log
+(mortal_amd/csrc/mj_state.h LG_*).  This module turns those words into the reference's serialisation:
+`Event` of mjai/event.rs:14-121 (serde: tag "type", snake_case, declaration field order, compact separators) and
+`GameResult::dump_json_log` (arena/result.rs:32-51): a start_game line with names and seed, every event of every kyoku,
+an end_game line.  File naming and gzip follow arena/one_vs_three.rs:195-225.
+"""
+import gzip
+import json
+import os
+
+TILE_NAMES = ([f"{n}{s}" for s in "mps" for n in range(1, 10)] + ["E", "S", "W", "N", "P", "F", "C", "5mr", "5pr", "5sr", "?"])
+
+(LG_START_KYOKU, LG_TSUMO, LG_DAHAI, LG_CHI, LG_PON, LG_DAIMINKAN, LG_KAKAN, LG_ANKAN, LG_DORA, LG_REACH,
+ LG_REACH_ACCEPTED, LG_HORA, LG_RYUKYOKU, LG_END_KYOKU) = range(1, 15)
+_NURA_SHIFT, _HONBA_SHIFT, _KYOTAKU_SHIFT = 39, 44, 52
+
+
+def _i32x4(w0, w1):
+    out = []
+    for w in (w0, w1):
+        for sh in (0, 32):
+            v = (w >> sh) & 0xFFFFFFFF
+            out.append(v - (1 << 32) if v & 0x80000000 else v)
+    return out
+
+
+def decode_events(words):
+    """u64 words of one table -> list of mjai event dicts (keys in the reference's serialisation order)."""
+    evs = []
+    i, n = 0, len(words)
+    tn = TILE_NAMES
+    while i < n:
+        w = int(words[i])
+        i += 1
+        t = w & 15
+        actor, target = (w >> 4) & 3, (w >> 6) & 3
+        pai = (w >> 8) & 63
+        c = [(w >> (14 + 6 * k)) & 63 for k in range(4)]
+        if t == LG_START_KYOKU:
+            kyoku = c[0]
+            scores = _i32x4(int(words[i]), int(words[i + 1]))
+            tiles = []
+            for k in range(7):
+                v = int(words[i + 2 + k])
+                tiles += [(v >> (8 * b)) & 0xFF for b in range(8)]
+            i += 9
+            evs.append({"type": "start_kyoku", "bakaze": tn[27 + kyoku // 4], "dora_marker": tn[pai], "kyoku": kyoku % 4 + 1,
+                        "honba": (w >> _HONBA_SHIFT) & 0xFF, "kyotaku": (w >> _KYOTAKU_SHIFT) & 0xFF, "oya": kyoku % 4,
+                        "scores": scores, "tehais": [[tn[x] for x in tiles[s * 13:(s + 1) * 13]] for s in range(4)]})
+        elif t == LG_TSUMO:
+            evs.append({"type": "tsumo", "actor": actor, "pai": tn[pai]})
+        elif t == LG_DAHAI:
+            evs.append({"type": "dahai", "actor": actor, "pai": tn[pai], "tsumogiri": bool((w >> 38) & 1)})
+        elif t in (LG_CHI, LG_PON):
+            evs.append({"type": "chi" if t == LG_CHI else "pon", "actor": actor, "target": target, "pai": tn[pai],
+                        "consumed": [tn[c[0]], tn[c[1]]]})
+        elif t == LG_DAIMINKAN:
+            evs.append({"type": "daiminkan", "actor": actor, "target": target, "pai": tn[pai],
+                        "consumed": [tn[c[0]], tn[c[1]], tn[c[2]]]})
+        elif t == LG_KAKAN:
+            evs.append({"type": "kakan", "actor": actor, "pai": tn[pai], "consumed": [tn[c[0]], tn[c[1]], tn[c[2]]]})
+        elif t == LG_ANKAN:
+            evs.append({"type": "ankan", "actor": actor, "consumed": [tn[x] for x in c]})
+        elif t == LG_DORA:
+            evs.append({"type": "dora", "dora_marker": tn[pai]})
+        elif t == LG_REACH:
+            evs.append({"type": "reach", "actor": actor})
+        elif t == LG_REACH_ACCEPTED:
+            evs.append({"type": "reach_accepted", "actor": actor})
+        elif t == LG_HORA:
+            deltas = _i32x4(int(words[i]), int(words[i + 1]))
+            u = int(words[i + 2])
+            i += 3
+            n_ura = (w >> _NURA_SHIFT) & 7
+            evs.append({"type": "hora", "actor": actor, "target": target, "deltas": deltas,
+                        "ura_markers": [tn[(u >> (6 * k)) & 63] for k in range(n_ura)]})
+        elif t == LG_RYUKYOKU:
+            deltas = _i32x4(int(words[i]), int(words[i + 1]))
+            i += 2
+            evs.append({"type": "ryukyoku", "deltas": deltas})
+        elif t == LG_END_KYOKU:
+            evs.append({"type": "end_kyoku"})
+        else:
+            raise ValueError(f"corrupt event log word {w:#x} at {i - 1}")
+    return evs
+
+
+def _dumps(ev):
+    return json.dumps(ev, separators=(",", ":"), ensure_ascii=False)
+
+
+def dump_json_log(names, seed, events):
+    """arena/result.rs:32-51."""
+    lines = [_dumps({"type": "start_game", "names": list(names), "seed": [int(seed[0]), int(seed[1])]})]
+    lines += [_dumps(e) for e in events]
+    lines.append(_dumps({"type": "end_game"}))
+    return "\n".join(lines) + "\n"
+
+
+def write_game_log_as(path, names, seed, events):
+    """One `{seed}_{key}_{split}.json.gz` per game (one_vs_three.rs:213-222); gzip level 9 = Compression::best()."""
+    with gzip.GzipFile(path, "wb", compresslevel=9, mtime=0) as f:
+        f.write(dump_json_log(names, seed, events).encode())
+    return path
+
+
+def read_game_log(path):
+    """-> list of event dicts of one `.json` / `.json.gz` log file."""
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rt") as f:
+        return [json.loads(l) for l in f if l.strip()]

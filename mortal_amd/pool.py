@@ -72,6 +72,26 @@ class TablePool:
         if version:
             self.versions[agent] = version
 
+    def enable_log(self, words_per_table=16384):
+        """Turn the per-table mjai event log on (call before reset/step).  16384 words cover ~60 kyoku."""
+        check(lib.mj_pool_enable_log(self.h, int(words_per_table)))
+        self.log_cap = int(words_per_table)
+
+    def read_logs(self, chunk=1024):
+        """-> list (one per table) of uint64 arrays holding the event words logged so far."""
+        n = self.n_tables
+        lens = np.zeros(n, dtype=np.uint32)
+        check(lib.mj_log_lengths(self.h, lens.ctypes.data, _stream()))
+        if (lens > self.log_cap).any():
+            raise MortalAmdError(f"event log overflow on table {int(np.argmax(lens > self.log_cap))}")
+        out = []
+        for t0 in range(0, n, chunk):
+            k = min(chunk, n - t0)
+            buf = np.empty((k, self.log_cap), dtype=np.uint64)
+            check(lib.mj_log_read(self.h, t0, k, buf.ctypes.data, _stream()))
+            out += [buf[i, :lens[t0 + i]].copy() for i in range(k)]
+        return out
+
     def set_refill(self, nonce_stride):
         check(lib.mj_pool_set_refill(self.h, nonce_stride))
 

@@ -86,15 +86,17 @@ def fake_q_values(masks, rows, cycle, seed):
 
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
                  policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
-                 policy="random", guard=False, oracle_obs=False):
+                 policy="random", guard=False, oracle_obs=False, compare_logs=False):
     """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch."""
     import torch
 
     from mortal_amd.pool import TablePool
 
     seeds = seeds or default_seeds(n_tables)
-    arena = oracle.Arena(seeds, deal_algo=0, enable_quick_eval=quick_eval, version=version, keep_log=False)
+    arena = oracle.Arena(seeds, deal_algo=0, enable_quick_eval=quick_eval, version=version, keep_log=compare_logs)
     pool = TablePool(n_tables, version=version, deal_algo=0)
+    if compare_logs:
+        pool.enable_log()
     pool.reset(seeds)
     pool.configure(0, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
     pool.configure(1, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
@@ -206,6 +208,24 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     both = (done_g == 1) & done_o
     assert (scores_g[both] == scores_o[both]).all(), "final scores differ"
     stats["scores_checked"] = int(both.sum())
+    if compare_logs:
+        import json
+
+        from mortal_amd import mjai_log
+
+        n_ev = 0
+        for g, words in enumerate(pool.read_logs()):
+            got = mjai_log.decode_events(words)
+            want = arena.log(g)
+            dump = lambda e: json.dumps(e, separators=(",", ":"))
+            if [dump(e) for e in got] != [dump(e) for e in want]:
+                k = 0
+                while k < min(len(got), len(want)) and dump(got[k]) == dump(want[k]):
+                    k += 1
+                raise AssertionError(f"game {g}: event {k} of {len(want)} differs:\n oracle {want[k] if k < len(want) else None}\n"
+                                     f" gpu    {got[k] if k < len(got) else None}")
+            n_ev += len(got)
+        stats["log_events_checked"] = n_ev
     if verbose:
         print("lockstep", stats)
     pool.close()

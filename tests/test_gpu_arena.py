@@ -112,3 +112,23 @@ def test_is_oracle_and_guard_engine_contract(oracle):
     e = Eng()
     got = OneVsThree(disable_progress_bar=True).py_vs_py(challenger=e, champion=e, seed_start=(10000, KEY), seed_count=1)
     assert sum(got) == 4 and seen["rows"] > 0
+
+
+def test_log_dir_and_stat(oracle, tmp_path):
+    """player.py's flow (mortal/player.py:60-73): OneVsThree(log_dir=...).py_vs_py(...) then Stat.from_dir(dir, name):
+    the rank histogram of the challenger from the logs equals py_vs_py's return value."""
+    from libriichi.arena import OneVsThree
+    from libriichi.stat import Stat
+
+    chal, _ = _engine(3, 1, "challenger", True)
+    cham, _ = _engine(3, 2, "champion", True)
+    d = str(tmp_path / "logs")
+    got = OneVsThree(disable_progress_bar=True, log_dir=d).py_vs_py(challenger=chal, champion=cham, seed_start=(10000, KEY), seed_count=2)
+    import os
+
+    files = sorted(os.listdir(d))
+    assert files == sorted(f"{10000 + i}_{KEY}_{s}.json.gz" for i in range(2) for s in "abcd")
+    st = Stat.from_dir(d, "challenger", True)
+    assert st.game == 8 and [st.rank_1, st.rank_2, st.rank_3, st.rank_4] == got
+    ch = Stat.from_dir(d, "champion", True)
+    assert ch.game == 24 and st.point + ch.point == 0

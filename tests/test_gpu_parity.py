@@ -58,3 +58,15 @@ def test_lockstep_invisible_obs(oracle, version):
     st = parity_util.run_lockstep(oracle, 128, version=version, max_cycles=1500, obs_every=3,
                                   compare_obs=False, policy="random" if version == 1 else "greedy", oracle_obs=True)
     assert st["oracle_obs_checked"] > 20000
+
+
+def test_lockstep_event_logs(oracle):
+    """the device event log, decoded to mjai JSON, equals the oracle's game log (the reference's
+    BoardState log, pinned by the golden game) event for event — start_kyoku haipai, draws, calls with aka-aware consumed
+    tiles, kan doras, riichi acceptance, hora deltas + ura markers, ryukyoku deltas, end_kyoku."""
+    st = parity_util.run_lockstep(oracle, 128, version=3, max_cycles=4000, compare_obs=False, policy="greedy",
+                                  compare_logs=True)
+    assert st["scores_checked"] == 128 and st["log_events_checked"] > 100000
+    st = parity_util.run_lockstep(oracle, 64, version=3, max_cycles=4000, compare_obs=False, policy="random",
+                                  compare_logs=True, seeds=parity_util.default_seeds(64, 777))
+    assert st["scores_checked"] == 64

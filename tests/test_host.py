@@ -40,8 +40,9 @@ def test_libriichi_surface():
     assert hasattr(env, "py_vs_py") and hasattr(TwoVsTwo(), "py_vs_py")
     with pytest.raises(TypeError):
         OneVsThree(True)  # keyword-only like the pyo3 signature (one_vs_three.rs:27)
+    assert hasattr(libriichi.stat.Stat, "from_dir") and hasattr(libriichi.stat.Stat, "avg_pt")
     with pytest.raises(NotImplementedError):
-        libriichi.stat.Stat
+        libriichi.dataset.GameplayLoader
 
 
 def test_stack_proxy_is_zero_copy():

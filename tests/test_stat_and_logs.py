@@ -1,0 +1,86 @@
+"""Host side of SURVEY §8(f).1: `libriichi.stat.Stat` and the mjai log writer, on the reference's example game
+(tests/golden/example_game.jsonl = log-viewer/index.example.html:10-264, metadata stripped)."""
+import gzip
+import json
+import math
+import os
+
+import numpy as np
+
+from libriichi.stat import Stat
+from mortal_amd import mjai_log
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "example_game.jsonl")
+
+
+def test_stat_from_log_example_game():
+    log = open(GOLDEN).read()
+    # seat 1 ("mortal"): pon in E1, chi + ron 5200 in E2, chasing riichi + ron 20000 (incl. its own stick) as dealer in E3
+    s = Stat.from_log(log, 1)
+    assert (s.game, s.round, s.oya) == (1, 3, 1)
+    assert (s.rank_1, s.rank_2, s.rank_3, s.rank_4, s.tobi) == (1, 0, 0, 0, 0)
+    assert s.point == 25000 + 5200 + 20000 - 1000 - 25000
+    assert (s.agari, s.agari_as_oya, s.agari_point_ko, s.agari_point_oya) == (2, 1, 5200, 19000)
+    assert (s.fuuro, s.fuuro_num, s.fuuro_agari, s.fuuro_agari_point, s.fuuro_point) == (2, 2, 1, 5200, 5200)
+    assert (s.riichi, s.riichi_as_oya, s.chasing_riichi, s.riichi_agari, s.riichi_agari_point) == (1, 1, 1, 1, 19000)
+    assert s.avg_rank == 1.0 and s.total_pt([90, 45, 0, -135]) == 90 and s.avg_pt([90, 45, 0, -135]) == 90.0
+    assert math.isnan(s.avg_point_per_dama_agari) and math.isnan(s.houjuu_to_oya_rate)  # 0/0 like Rust's f64
+    # seat 2 dealt into all three wins and went below zero
+    t = Stat.from_log(log, 2)
+    assert (t.houjuu, t.houjuu_to_oya, t.houjuu_point_to_oya, t.houjuu_point_to_ko) == (3, 2, -25700, -4200)
+    assert (t.tobi, t.rank_4, t.point) == (1, 1, -30900)
+    assert (t.riichi, t.riichi_houjuu, t.fuuro_houjuu, t.riichi_got_chased) == (1, 1, 1, 1)
+    # whole table: every round is won by someone, points sum to zero, ranks form a permutation
+    allp = [Stat.from_log(log, p) for p in range(4)]
+    assert sum(x.point for x in allp) == 0
+    assert sum(x.agari for x in allp) == 3 and sum(x.houjuu for x in allp) == 3
+    assert sorted(x.avg_rank for x in allp) == [1.0, 2.0, 3.0, 4.0]
+    tot = sum(allp, Stat())
+    assert tot.game == 4 and tot.round == 12
+    text = str(s)
+    assert "Avg winning Δscore as dealer     19000.000000" in text and "Avg dama winning Δscore          NaN" in text
+
+
+def test_stat_from_dir_and_log_writer(tmp_path):
+    lines = [json.loads(l) for l in open(GOLDEN)]
+    names, seed, events = lines[0]["names"], lines[0]["seed"], lines[1:-1]
+    # the writer reproduces the reference's serialisation byte for byte (field order, separators, trailing newline)
+    assert mjai_log.dump_json_log(names, seed, events) == open(GOLDEN).read()
+    p = mjai_log.write_game_log_as(str(tmp_path / f"{seed[0]}_{seed[1]}_a.json.gz"), names, seed, events)
+    assert gzip.open(p, "rt").read() == open(GOLDEN).read()
+    (tmp_path / "sub").mkdir()
+    (tmp_path / "sub" / "plain.json").write_text(open(GOLDEN).read())
+    s = Stat.from_dir(str(tmp_path), "mortal", disable_progress_bar=True)
+    assert s.game == 2 and s.rank_1 == 2 and s.point == 2 * 24200  # the gz and the plain copy, seat 1 each
+    b = Stat.from_dir(str(tmp_path), "baseline", True)
+    assert b.game == 6 and b.point == -2 * 24200
+    assert Stat.from_dir(str(tmp_path), "nobody", True).game == 0
+
+
+def test_decode_events_word_format():
+    """Header/payload layout of mortal_amd/csrc/mj_state.h LG_* (the GPU test compares real device logs with the oracle)."""
+    def word(t, actor=0, target=0, pai=0, c=(0, 0, 0, 0), tsumogiri=0):
+        return t | actor << 4 | target << 6 | pai << 8 | c[0] << 14 | c[1] << 20 | c[2] << 26 | c[3] << 32 | tsumogiri << 38
+
+    def i32x2(a, b):
+        return (a & 0xFFFFFFFF) | ((b & 0xFFFFFFFF) << 32)
+
+    tiles = [i % 37 for i in range(52)]
+    hai = [sum((tiles[w * 8 + k] if w * 8 + k < 52 else 0) << (8 * k) for k in range(8)) for w in range(7)]
+    words = [word(1, pai=29, c=(5, 0, 0, 0)) | 2 << 44 | 3 << 52, i32x2(25000, 24000), i32x2(-100, 51100), *hai,
+             word(2, actor=1, pai=34), word(3, actor=1, pai=34, tsumogiri=1), word(4, 2, 1, 4, (34, 5, 0, 0)),
+             word(8, actor=3, c=(35, 13, 13, 13)), word(9, pai=31), word(7, actor=0, pai=36, c=(22, 22, 22, 0)),
+             word(12, 2, 0) | 2 << 39, i32x2(8000, -8000), i32x2(0, 0), 7 | 8 << 6,
+             word(13), i32x2(1500, -1500), i32x2(1500, -1500), word(14)]
+    ev = mjai_log.decode_events(np.array(words, dtype=np.uint64))
+    assert ev[0] == {"type": "start_kyoku", "bakaze": "S", "dora_marker": "W", "kyoku": 2, "honba": 2, "kyotaku": 3,
+                     "oya": 1, "scores": [25000, 24000, -100, 51100],
+                     "tehais": [[mjai_log.TILE_NAMES[t] for t in tiles[s * 13:(s + 1) * 13]] for s in range(4)]}
+    assert ev[1:] == [
+        {"type": "tsumo", "actor": 1, "pai": "5mr"}, {"type": "dahai", "actor": 1, "pai": "5mr", "tsumogiri": True},
+        {"type": "chi", "actor": 2, "target": 1, "pai": "5m", "consumed": ["5mr", "6m"]},
+        {"type": "ankan", "actor": 3, "consumed": ["5pr", "5p", "5p", "5p"]}, {"type": "dora", "dora_marker": "P"},
+        {"type": "kakan", "actor": 0, "pai": "5sr", "consumed": ["5s", "5s", "5s"]},
+        {"type": "hora", "actor": 2, "target": 0, "deltas": [8000, -8000, 0, 0], "ura_markers": ["8m", "9m"]},
+        {"type": "ryukyoku", "deltas": [1500, -1500, 1500, -1500]}, {"type": "end_kyoku"}]
+    assert list(ev[0].keys()) == ["type", "bakaze", "dora_marker", "kyoku", "honba", "kyotaku", "oya", "scores", "tehais"]
