@@ -236,7 +236,7 @@ def main():
             "kernel_ms_per_step": {"mj_k_encode": enc_ms / args.steps, "mj_k_sp": sp_ms / args.steps,
                                    "everything_else": (dt * 1e3 - enc_ms - sp_ms) / args.steps},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
             line["cpu_baseline"] = cpu_baseline(args.version, args.cpu_budget, args.cpu_tables)
         print(json.dumps(line))
     pool.close()
