@@ -222,6 +222,39 @@ MJD int sh_eval(u64 rm, u64 rp, u64 rs, u64 rz, int len_div3, int pairs, int kin
     return s;
 }
 
+// Min-plus merges of the per-suit rows are commutative and associative (a row = cheapest tile distance for j mentsu
+// without / with the pair; sh_add_suhai is the convolution over (mentsu count, pair flag)), and every merged entry is
+// bounded by the corresponding entry of either operand (row[0] == 0), so merged vectors still fit 10 nibbles.  Hence
+// the shanten of a hand that differs from a base hand in ONE suit is  final(merge of the three untouched rows, new row)
+// and in TWO suits  final(merge(merge of the two untouched rows, new row a), new row b):  the expensive full merges are
+// shared by all probes of a state and a probe costs one `sh_final` (~35 ops) instead of two full merges + final (~330).
+MJD u64 sh_merge(u64 a, u64 b, int m) {
+    int v[10];
+    sh_unpack(a, v);
+    sh_add_suhai(v, b, m);
+    u64 r = 0;
+#pragma unroll
+    for (int j = 0; j < 10; j++) r |= (u64)(v[j] & 15) << (4 * j);
+    return r;
+}
+MJD int sh_final(u64 a, u64 b, int m) {  // entry 5+m of merge(a, b): m mentsu + the pair
+    int v[10];
+    sh_unpack(a, v);
+    return sh_add_jihai_final(v, b, m);
+}
+MJD int sh_pair_idx(int a, int b) {  // unordered suit pair -> 0..5 : 01 02 03 12 13 23
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return lo == 0 ? hi - 1 : lo == 1 ? hi + 1 : 5;
+}
+// normal-form shanten from the final entry + chitoi / kokushi (shanten.rs:139-150)
+MJD int sh_finish(int fin, int len_div3, int pairs, int kinds, int kpairs, int kkinds) {
+    int s = fin - 1;
+    if (s <= 0 || len_div3 < 4) return s;
+    s = min(s, 7 - pairs + (kinds >= 7 ? 0 : 7 - kinds) - 1);
+    if (s > 0) s = min(s, 14 - kkinds - (kpairs > 0) - 1);
+    return s;
+}
+
 // ---------------------------------------------------------------- points (point.rs:13-112)
 // The reference's match table equals the textbook formula on its whole domain (its own test,
 // point.rs:121-153, asserts exactly that), so the device uses the closed form.

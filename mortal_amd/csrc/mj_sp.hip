@@ -275,6 +275,8 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
 #define SP_CCAP 256  // children staged per super-chunk (a required tile has at most 2 x 14)
 struct SpTeam {
     u64 keep[34];            // per required tile t: set of shanten-keeping discards of h + t
+    u64 r2[6];               // merges of two base rows (suit pairs 01 02 03 12 13 23), see mj_algo.h sh_merge
+    u64 r3[4];               // per suit s: merge of the three OTHER base rows
     int coff[34];            // per required tile t: offset of its first child inside the node's child list
     u8 tiles[36];            // required tiles in ascending order
     union {
@@ -282,6 +284,7 @@ struct SpTeam {
             u64 rowt[34];    // expand: table row of (h + t) in suit(t)
             u64 rowd[34];    //         table row of (h - d) in suit(d)
             unsigned short items[SP_CCAP];  // children of the current super-chunk: t | d << 6 | variant << 12
+            u64 U[34][3];    // per required tile t and k-th other suit: merge(two untouched suits, row of h + t)
         } ex;
         float sc[SP_L0_MAX][4];  // level 0: get_score() of every draw entry (filled by sp_l0_score through the node)
         struct {             // level > 0 evaluation
@@ -292,18 +295,36 @@ struct SpTeam {
     } u;
 };
 
+// Partial merges of a state's four base rows, shared by all of its probes (lanes 0..5, then 0..3 of the team).
+__device__ __forceinline__ void sp_partial_merges(SpTeam* TM, const ShBase& B, int ld3, int ln) {
+    if (ln < 6) {
+        const int a = ln < 3 ? 0 : ln < 5 ? 1 : 2, b = ln < 3 ? ln + 1 : ln < 5 ? ln - 1 : 3;
+        TM->r2[ln] = sh_merge(B.row[a], B.row[b], ld3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (ln < 4) {
+        // others of suit 0: (1,2)+3, of 1: (0,2)+3, of 2: (0,1)+3, of 3: (0,1)+2
+        const u64 pr = ln == 0 ? TM->r2[3] : ln == 1 ? TM->r2[1] : TM->r2[0];
+        TM->r3[ln] = sh_merge(pr, B.row[ln == 3 ? 2 : 3], ld3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+}
+
 // ---- Level 0 (tenpai states) is evaluated in three passes so that the expensive, divergent scoring of the winning
 // draws (get_score: agari decomposition + yaku + fu) runs with every lane busy instead of ~3 lanes per 32-lane team:
 //   probe : team per state — which draws win (34 shanten probes)        -> node.req, one work item per draw entry
 //   score : THREAD per item, dense across the workgroup                  -> 4 scores per item in the node (keep[] area)
 //   sum   : team per state — sp_visit_team<true>(L = 0) accumulates the scores in the reference's order
-__device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, int slot) {
+__device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot) {
     const int ln = threadIdx.x & 31;
     const int sh32 = threadIdx.x & 32;
     SpNode& node = W->node[slot];
     const SpState S = sp_state_of(node);
     const int ld3 = X->len_div3;
     const ShBase B = sh_base(Tb, S.h);
+    sp_partial_merges(TM, B, ld3, ln);
     u64 req = 0;
 #pragma unroll
     for (int rnd = 0; rnd < 2; rnd++) {
@@ -312,9 +333,8 @@ __device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, int slot
         if (t < 34 && S.w.get(t) > 0) {
             const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
             const u64 r = sh_load(Tb, st, B.key[st] + sh_pow(t));
-            const int sh = sh_eval(st == 0 ? r : B.row[0], st == 1 ? r : B.row[1], st == 2 ? r : B.row[2], st == 3 ? r : B.row[3],
-                                   ld3, B.pairs + (hc == 1), B.kinds + (hc == 0), B.kpairs + (yao && hc == 1),
-                                   B.kkinds + (yao && hc == 0));
+            const int sh = sh_finish(sh_final(TM->r3[st], r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
+                                     B.kpairs + (yao && hc == 1), B.kkinds + (yao && hc == 0));
             is_req = sh == -1;
         }
         const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull;
@@ -393,6 +413,7 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
     if (!EVAL) {
         // ---- A
         const ShBase B = sh_base(Tb, S.h);
+        sp_partial_merges(TM, B, ld3, ln);
 #pragma unroll
         for (int rnd = 0; rnd < 2; rnd++) {
             const int t = ln + 32 * rnd;
@@ -403,9 +424,8 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                 if (!EVAL && hc > 0) rd = sh_load(Tb, st, B.key[st] - sh_pow(t));
                 if (S.w.get(t) > 0) {
                     r = sh_load(Tb, st, B.key[st] + sh_pow(t));
-                    int sh = sh_eval(st == 0 ? r : B.row[0], st == 1 ? r : B.row[1], st == 2 ? r : B.row[2], st == 3 ? r : B.row[3],
-                                     ld3, B.pairs + (hc == 1), B.kinds + (hc == 0), B.kpairs + (yao && hc == 1),
-                                     B.kkinds + (yao && hc == 0));
+                    int sh = sh_finish(sh_final(TM->r3[st], r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
+                                       B.kpairs + (yao && hc == 1), B.kkinds + (yao && hc == 0));
                     is_req = sh - L == -1;
                 }
                 TM->u.ex.rowt[t] = r;
@@ -426,17 +446,31 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
         __threadfence_block();
 
         if (!EVAL) {
-            // ---- B: (required t, d) probes, four items per lane and round so that their gathers overlap
+            // ---- B1: per required tile t and each of the three other suits: U = merge(two untouched suits, row of h+t)
+            for (int item = ln; item < n_tiles * 3; item += 32) {
+                const int ti = item / 3, k = item % 3, t = TM->tiles[ti];
+                const int st = sh_suit(t), sd = k + (k >= st);  // k-th suit != st
+                int x = -1, y = -1;  // the two suits other than st and sd
+                for (int q = 0; q < 4; q++)
+                    if (q != st && q != sd) { if (x < 0) x = q; else y = q; }
+                TM->u.ex.U[ti][k] = sh_merge(TM->r2[sh_pair_idx(x, y)], TM->u.ex.rowt[t], ld3);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // ---- B2: (required t, d) probes, four items per lane and round so that their gathers overlap:
+            // same suit -> final(r3[suit], gathered row of h+t-d); other suit -> final(U[t][suit d], row of h-d)
             const int n_items = n_tiles * 34;
             for (int base = 0; base < n_items; base += 128) {
                 u64 rdv[4];
-                int tt[4], dd[4];
+                int tt[4], dd[4], tii[4];
                 bool valid[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int item = base + q * 32 + ln;
                     valid[q] = item < n_items;
-                    const int t = TM->tiles[min(item, n_items - 1) / 34], d = item % 34;
+                    const int ti = min(item, n_items - 1) / 34;
+                    const int t = TM->tiles[ti], d = item % 34;
+                    tii[q] = ti;
                     tt[q] = t;
                     dd[q] = d;
                     valid[q] = valid[q] && (S.h.get(d) + (d == t)) > 0;
@@ -451,14 +485,12 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                     const int c = S.h.get(d) + (d == t);  // count of d after the draw
                     const int st = sh_suit(t), sd = sh_suit(d);
                     const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
-                    const u64 row_t = TM->u.ex.rowt[t];
-                    u64 r0 = B.row[0], r1 = B.row[1], r2 = B.row[2], r3 = B.row[3];
-                    const u64 rd = sd == st ? (d == t ? B.row[st] : rdv[q]) : TM->u.ex.rowd[d];
-                    if (st == 0) r0 = row_t; else if (st == 1) r1 = row_t; else if (st == 2) r2 = row_t; else r3 = row_t;
-                    if (sd == 0) r0 = rd; else if (sd == 1) r1 = rd; else if (sd == 2) r2 = rd; else r3 = rd;
+                    int fin;
+                    if (sd == st) fin = sh_final(TM->r3[st], d == t ? B.row[st] : rdv[q], ld3);
+                    else fin = sh_final(TM->u.ex.U[tii[q]][sd - (sd > st)], TM->u.ex.rowd[d], ld3);
                     const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
                     const int kpairs = B.kpairs + (yt && hct == 1) - (yd && c == 2), kkinds = B.kkinds + (yt && hct == 0) - (yd && c == 1);
-                    if (sh_eval(r0, r1, r2, r3, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0)
+                    if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0)
                         atomicOr((unsigned long long*)&TM->keep[t], 1ull << d);
                 }
             }
@@ -1023,7 +1055,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
-                    for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_l0_probe(c_mj_tables, W, &X, (int)W->list[i]);
+                    for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_l0_probe(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i]);
                     __syncthreads();
                     const int n_items = min(X.n_items, SP_ITEMS);
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
