@@ -57,16 +57,34 @@ def _cpu_worker(version, budget_s, n_tables, wid):
     return dict(steps=steps, cycles=cycles, rows=rows_total, arenas=batches, dt=time.perf_counter() - t0)
 
 
+def _usable_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (containers)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = min(cores, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(version, budget_s=12.0, n_tables=16):
     """Oracle arena (CPU restatement) on a bounded sample of the same workload: one worker PROCESS per host core, each
     running independent arenas (tables are independent, like the reference's rayon loop over games,
     arena/game.rs:286-296).  value = sum over workers of steps_i / dt_i (all workers run concurrently)."""
     import subprocess
 
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = _usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), "--version", str(version),
                                "--cpu-budget", str(budget_s), "--cpu-tables", str(n_tables)],

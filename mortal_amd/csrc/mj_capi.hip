@@ -557,19 +557,25 @@ int mj_results(MjPool* P, int32_t* scores, uint8_t* done, void* stream) {
     return 0;
 }
 
+__global__ void mj_k_first_error(const TableBlock* blocks, int n_tables, unsigned long long* out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tables) return;
+    const unsigned e = blocks[t >> 6].err[t & 63];
+    if (e) atomicMin(out, ((unsigned long long)t << 8) | e);
+}
 int mj_pool_first_error(MjPool* P, int* table_out, void* stream) {
     if (!P) return fail("null pool");
-    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-    std::vector<uint8_t> err(MJ_LANES);
-    for (int b = 0; b < P->n_blocks; b++) {
-        HIP_OK(hipMemcpy(err.data(), P->blocks[b].err, MJ_LANES, hipMemcpyDeviceToHost));
-        for (int l = 0; l < MJ_LANES; l++)
-            if (err[l]) {
-                if (table_out) *table_out = b * MJ_LANES + l;
-                return err[l];
-            }
-    }
-    return 0;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* slot = P->counters + 7;  // spare counter word
+    HIP_OK(hipMemsetAsync(slot, 0xFF, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(mj_k_first_error, dim3((P->n_tables + 255) / 256), dim3(256), 0, s, P->blocks, P->n_tables, slot);
+    HIP_OK(hipGetLastError());
+    unsigned long long v = 0;
+    HIP_OK(hipMemcpyAsync(&v, slot, sizeof v, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (v == ~0ull) return 0;
+    if (table_out) *table_out = (int)(v >> 8);
+    return (int)(v & 0xFF);
 }
 
 int mj_debug_table(MjPool* P, int table, void* out, size_t out_size, void* stream) {
