@@ -72,6 +72,18 @@ int mj_step(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_de
 int mj_step_q(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_dev1, const float* q_dev0,
               const float* q_dev1, void* stream);
 
+/* ---- Log replay for the dataset loader (dataset/gameplay.rs:239-443 Gameplay::load_events_by_player).
+ * One game log per table, as packed event words (LG_* format, the same words mj_log_read returns; host encoder:
+ * mortal_amd/mjai_log.py encode_events).  script = all logs concatenated, off[n_logs + 1] = word offsets, tracked[t] bit s =
+ * samples wanted for seat s of log t.  mj_replay_step applies events until some tracked seat has a sample, then
+ * mj_rows_count / mj_encode(agent 0) / mj_encode_oracle deliver obs + masks exactly as in the arena, and mj_replay_meta the
+ * per-row int32[8] = {label, log, seat, kyoku index, turn, shanten, is kan-select row, event index}.
+ * counters()[1] = logs fully replayed. */
+int mj_replay_load(MjPool* pool, const uint64_t* script_host, const uint32_t* off_host, const uint8_t* tracked_host,
+                   int n_logs, int always_include_kan_select);
+int mj_replay_step(MjPool* pool, void* stream);
+int mj_replay_meta(MjPool* pool, int32_t* meta_dev, void* stream);
+
 /* Number of policy rows per agent produced by the last mj_step (synchronises `stream`). */
 int mj_rows_count(MjPool* pool, int32_t n_rows_out[2], void* stream);
 /* Device array of row descriptors of agent a: table | seat << 28 | is_kan_select << 31. */

@@ -1,5 +1,4 @@
-"""libriichi.dataset — a "next" row of the hot-path scope table; not built this round."""
+"""libriichi.dataset (reference libriichi/src/dataset/): `GameplayLoader`, `Gameplay`, `Grp` — see mortal_amd/dataset.py."""
+from mortal_amd.dataset import GameplayLoader, Gameplay, Grp  # noqa: F401
 
-
-def __getattr__(name):
-    raise NotImplementedError(f"libriichi.dataset.{name} is not implemented yet (SURVEY.md §8(f))")
+__all__ = ["GameplayLoader", "Gameplay", "Grp"]

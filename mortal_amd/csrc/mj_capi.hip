@@ -11,6 +11,7 @@
 
 #include "../../include/mortal_amd.h"
 #include "mj_step.hip"
+#include "mj_replay.hip"
 #include "mj_encode.hip"
 #include "mj_sp.hip"
 
@@ -77,6 +78,12 @@ std::vector<MjGatherEnt> build_gather() {
 
 struct MjPool {
     int n_tables = 0, n_blocks = 0, deal_algo = 0, max_rows = 0;
+    // log replay (dataset loader)
+    uint64_t* rp_script = nullptr;
+    uint32_t *rp_off = nullptr, *rp_cursor = nullptr, *rp_ev_index = nullptr;
+    uint8_t *rp_kyoku = nullptr, *rp_tracked = nullptr;
+    int32_t *rp_label = nullptr, *rp_kan_label = nullptr;
+    int rp_always_kan = 1;
     uint64_t* log = nullptr;   // optional event log [n_tables][log_cap]
     uint32_t* log_len = nullptr;
     uint32_t log_cap = 0;
@@ -228,6 +235,8 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->sp_err);
     hipFree(P->log);
     hipFree(P->log_len);
+    hipFree(P->rp_script); hipFree(P->rp_off); hipFree(P->rp_cursor); hipFree(P->rp_ev_index);
+    hipFree(P->rp_kyoku); hipFree(P->rp_tracked); hipFree(P->rp_label); hipFree(P->rp_kan_label);
     if (P->n_rows_host) hipHostFree(P->n_rows_host);
     hipFree(P->counters);
     hipFree(P->final_scores);
@@ -313,6 +322,7 @@ int mj_pool_set_refill(MjPool* P, uint64_t stride) {
     return 0;
 }
 
+static int launch_rows(MjPool* P, hipStream_t s);
 int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
     return mj_step_q(P, a0, a1, nullptr, nullptr, stream);
 }
@@ -347,6 +357,9 @@ int mj_step_q(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, 
     sp.block_rows = P->block_rows;
     if (sp.refill) hipLaunchKernelGGL(mj_k_refill, dim3(P->n_blocks), dim3(64), 0, s, sp);
     hipLaunchKernelGGL(mj_k_step, dim3(P->n_blocks), dim3(64), 0, s, sp);
+    return launch_rows(P, s);
+}
+static int launch_rows(MjPool* P, hipStream_t s) {
     RowsParams rp;
     rp.blocks = P->blocks;
     rp.n_blocks = P->n_blocks;
@@ -363,6 +376,70 @@ int mj_step_q(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, 
     HIP_OK(hipGetLastError());
     P->cycles += 1;
     P->rows_valid = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------- log replay (dataset/gameplay.rs)
+int mj_replay_load(MjPool* P, const uint64_t* script, const uint32_t* off, const uint8_t* tracked, int n_logs,
+                   int always_include_kan_select) {
+    if (!P) return fail("null pool");
+    if (n_logs != P->n_tables) return fail("mj_replay_load: one log per table (create the pool with n_tables = n_logs)");
+    const size_t n_words = off[n_logs];
+    hipFree(P->rp_script); hipFree(P->rp_off); hipFree(P->rp_cursor); hipFree(P->rp_ev_index);
+    hipFree(P->rp_kyoku); hipFree(P->rp_tracked); hipFree(P->rp_label); hipFree(P->rp_kan_label);
+    HIP_OK(hipMalloc(&P->rp_script, (n_words + 1) * sizeof(uint64_t)));
+    HIP_OK(hipMalloc(&P->rp_off, (size_t)(n_logs + 1) * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&P->rp_cursor, (size_t)n_logs * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&P->rp_ev_index, (size_t)n_logs * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&P->rp_kyoku, (size_t)n_logs));
+    HIP_OK(hipMalloc(&P->rp_tracked, (size_t)n_logs));
+    HIP_OK(hipMalloc(&P->rp_label, (size_t)n_logs * 4 * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&P->rp_kan_label, (size_t)n_logs * 4 * sizeof(int32_t)));
+    HIP_OK(hipMemcpy(P->rp_script, script, n_words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(P->rp_off, off, (size_t)(n_logs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(P->rp_tracked, tracked, (size_t)n_logs, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(P->rp_cursor, 0, (size_t)n_logs * sizeof(uint32_t)));
+    HIP_OK(hipMemset(P->rp_ev_index, 0, (size_t)n_logs * sizeof(uint32_t)));
+    HIP_OK(hipMemset(P->rp_kyoku, 0, (size_t)n_logs));
+    P->rp_always_kan = always_include_kan_select;
+    // fresh tables (all seats agent 0); padding lanes of the last block inactive
+    std::vector<TableBlock> host(P->n_blocks);
+    memset(host.data(), 0, host.size() * sizeof(TableBlock));
+    for (int t = P->n_tables; t < P->n_blocks * MJ_LANES; t++) host[t >> 6].flags[t & 63] = TF_INACTIVE | TF_DONE | TF_ENDED;
+    HIP_OK(hipMemcpy(P->blocks, host.data(), host.size() * sizeof(TableBlock), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(P->counters, 0, 8 * sizeof(unsigned long long)));
+    P->cycles = 0;
+    P->rows_valid = false;
+    return 0;
+}
+int mj_replay_step(MjPool* P, void* stream) {
+    if (!P || !P->rp_script) return fail("mj_replay_load first");
+    ReplayParams rp;
+    rp.blocks = P->blocks;
+    rp.n_tables = P->n_tables;
+    rp.script = P->rp_script;
+    rp.script_off = P->rp_off;
+    rp.cursor = P->rp_cursor;
+    rp.ev_index = P->rp_ev_index;
+    rp.kyoku_idx = P->rp_kyoku;
+    rp.tracked = P->rp_tracked;
+    rp.always_include_kan_select = P->rp_always_kan;
+    rp.block_rows = P->block_rows;
+    rp.label = P->rp_label;
+    rp.kan_label = P->rp_kan_label;
+    rp.counters = P->counters;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mj_k_replay, dim3(P->n_blocks), dim3(64), 0, s, rp);
+    return launch_rows(P, s);
+}
+int mj_replay_meta(MjPool* P, int32_t* meta_dev, void* stream) {
+    if (!P || !P->rp_script) return fail("mj_replay_load first");
+    if (!P->rows_valid) return fail("mj_rows_count must be called after mj_replay_step");
+    const int n = P->last_rows[0];
+    if (n == 0) return 0;
+    ReplayMetaParams mp = {P->blocks, P->rows[0], n, P->rp_label, P->rp_kan_label, P->rp_kyoku, P->rp_ev_index, meta_dev};
+    hipLaunchKernelGGL(mj_k_replay_meta, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mp);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 

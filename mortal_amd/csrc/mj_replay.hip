@@ -1,0 +1,237 @@
+// Log replay for the dataset loader (reference: dataset/gameplay.rs:239-443 Gameplay::load_events_by_player).
+//
+// A table replays one mjai game log: its events arrive as the same packed words the arena's event log uses
+// (mj_state.h LG_*), the step kernel's PlayerState handlers (mj_rules.h ev_*) are applied one event at a time — all four
+// seats at once, public state once per table — and after every event the tracked seats that can act get a training
+// sample: a policy row (obs + mask through the normal snapshot / encode kernels) plus the label the log implies
+// (gameplay.rs:296-409: the next event, with the reach_accepted / dora skip and the hora look-ahead).
+#include <hip/hip_runtime.h>
+
+#include "mj_rules.h"
+
+struct ReplayParams {
+    TableBlock* blocks;
+    int n_tables;
+    const uint64_t* script;      // all logs' event words, concatenated
+    const uint32_t* script_off;  // [n_tables + 1] word offsets
+    uint32_t* cursor;            // [n_tables] next word (relative)
+    uint32_t* ev_index;          // [n_tables] events applied so far
+    uint8_t* kyoku_idx;          // [n_tables] kyoku counter of the loader (gameplay.rs:279)
+    const uint8_t* tracked;      // [n_tables] bit s: samples wanted for seat s
+    int always_include_kan_select;
+    int* block_rows;             // [n_blocks][2] row counts for mj_k_scan / mj_k_assign
+    int32_t* label;              // [n_tables][4] label of the pending main row (valid when main_row >= 0)
+    int32_t* kan_label;          // [n_tables][4] label (tile id) of the pending kan-select row
+    unsigned long long* counters;  // [0] events applied, [1] finished logs
+};
+
+struct RpEvent {
+    int type, actor, target, pai, c[4], tsumogiri, len;
+};
+MJD int rp_len(uint64_t w) {
+    const int t = (int)(w & 15);
+    return t == LG_START_KYOKU ? 10 : t == LG_HORA ? 4 : t == LG_RYUKYOKU ? 3 : 1;
+}
+MJD RpEvent rp_decode(uint64_t w) {
+    RpEvent e;
+    e.type = (int)(w & 15);
+    e.actor = (int)((w >> 4) & 3);
+    e.target = (int)((w >> 6) & 3);
+    e.pai = (int)((w >> 8) & 63);
+    for (int k = 0; k < 4; k++) e.c[k] = (int)((w >> (14 + 6 * k)) & 63);
+    e.tsumogiri = (int)((w >> 38) & 1);
+    e.len = rp_len(w);
+    return e;
+}
+
+// label of seat p after the current event (gameplay.rs:296-409); -1 = no sample.  nxt[0..2] = the three events after
+// the current one (type 0 past the end of the log = end_game).
+template <class LN> MJDN int rp_label(const LN& L, int p, const RpEvent nxt[3], int always_kan, int& kan_select) {
+    kan_select = -1;
+    const u32 cans = F1(cans, p);
+    const RpEvent& next = (nxt[0].type == LG_REACH_ACCEPTED || nxt[0].type == LG_DORA) ? nxt[1] : nxt[0];
+    switch (next.type) {
+        case LG_DAHAI: return next.pai;
+        case LG_REACH: return 37;
+        case LG_CHI:
+            if (next.actor == p) {  // ChiType::new (chi_type.rs): position of the called tile among the three
+                const int a = deaka(next.c[0]), b = deaka(next.c[1]), t = deaka(next.pai);
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                return t < lo ? 38 : t < hi ? 39 : 40;
+            }
+            break;
+        case LG_PON:
+            if (next.actor == p) return 41;
+            break;
+        case LG_DAIMINKAN:
+            if (next.actor == p) {
+                if (always_kan) kan_select = deaka(next.pai);
+                return 42;
+            }
+            break;
+        case LG_KAKAN:
+            if (always_kan || __popcll(F1(kakan_cand, p)) > 1) kan_select = deaka(next.pai);
+            return 42;
+        case LG_ANKAN:
+            if (always_kan || __popcll(F1(ankan_cand, p)) > 1) kan_select = deaka(next.c[0]);
+            return 42;
+        case LG_RYUKYOKU:
+            if (cans & CAN_RYUKYOKU) return 44;
+            break;
+        default: break;
+    }
+    const bool has_any_ron = nxt[0].type == LG_HORA;
+    if (has_any_ron) {
+        for (int k = 0; k < 3; k++) {
+            if (nxt[k].type == LG_END_KYOKU) break;
+            if (nxt[k].type == LG_HORA && nxt[k].actor == p) return 43;
+        }
+    }
+    const bool can_chi = (cans & (CAN_CHI_LOW | CAN_CHI_MID | CAN_CHI_HIGH)) != 0;
+    if ((can_chi && next.type == LG_TSUMO) || ((cans & (CAN_PON | CAN_DAIMINKAN | CAN_RON_AGARI)) && !has_any_ron)) return 45;
+    return -1;
+}
+
+// Apply events until at least one tracked seat has a sample (or the log ends).  One lane per table.
+__global__ __launch_bounds__(64) void mj_k_replay(ReplayParams P) {
+    const int table = blockIdx.x * 64 + threadIdx.x;
+    Lane L = {P.blocks + blockIdx.x, (int)threadIdx.x, &c_mj_tables};
+    int nr = 0;
+    if (table < P.n_tables) {
+        const uint64_t* sc = P.script + P.script_off[table];
+        const uint32_t n_words = P.script_off[table + 1] - P.script_off[table];
+        uint32_t cur = P.cursor[table];
+        for (int s = 0; s < 4; s++) {
+            F1(main_row, s) = -1;
+            F1(kan_row, s) = -1;
+        }
+        const int tracked = P.tracked[table];
+        // the loader's windows(4) never makes the last two log events (.., hora|ryukyoku, end_kyoku) "current"
+        // (gameplay.rs:258-262): stop as soon as fewer than three events remain
+        while (cur < n_words && F(err) == MJ_OK) {
+            // look ahead: current + three following events
+            uint32_t pos = cur;
+            const RpEvent ev = rp_decode(sc[pos]);
+            pos += ev.len;
+            RpEvent nxt[3];
+            int n_after = 0;
+            for (int k = 0; k < 3; k++) {
+                if (pos < n_words) {
+                    nxt[k] = rp_decode(sc[pos]);
+                    pos += nxt[k].len;
+                    n_after++;
+                } else {
+                    nxt[k].type = 0;
+                    nxt[k].actor = nxt[k].target = nxt[k].pai = 0;
+                    nxt[k].len = 1;
+                }
+            }
+            if (n_after < 2) {  // this event and what follows are never a window start
+                cur = n_words;
+                break;
+            }
+            // ---- apply (PlayerState::update for all four seats)
+            switch (ev.type) {
+                case LG_START_KYOKU: {
+                    const uint64_t w = sc[cur];
+                    F(kyoku) = (u8)ev.c[0];
+                    F(honba) = (u8)((w >> LG_HONBA_SHIFT) & 0xFF);
+                    F(kyotaku) = (u8)((w >> LG_KYOTAKU_SHIFT) & 0xFF);
+                    const uint64_t s0 = sc[cur + 1], s1 = sc[cur + 2];
+                    F1(scores, 0) = (int)(uint32_t)s0;
+                    F1(scores, 1) = (int)(uint32_t)(s0 >> 32);
+                    F1(scores, 2) = (int)(uint32_t)s1;
+                    F1(scores, 3) = (int)(uint32_t)(s1 >> 32);
+                    for (int i = 0; i < 136; i++) F1(wall, i) = T_UNK;
+                    for (int k = 0; k < 7; k++) {
+                        const uint64_t v = sc[cur + 3 + k];
+                        for (int b = 0; b < 8; b++) {
+                            const int i = k * 8 + b;
+                            if (i < 52) F1(wall, i) = (u8)((v >> (8 * b)) & 0xFF);
+                        }
+                    }
+                    F1(wall, 60) = (u8)ev.pai;
+                    kyoku_init(L);
+                    F(flags) |= TF_HAIPAI_DONE;
+                    break;
+                }
+                case LG_TSUMO:
+                    F(tiles_left) -= 1;
+                    ev_tsumo(L, ev.actor, ev.pai);
+                    break;
+                case LG_DAHAI: ev_dahai(L, ev.actor, ev.pai, ev.tsumogiri != 0); break;
+                case LG_CHI: ev_chi_pon(L, false, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1]); break;
+                case LG_PON: ev_chi_pon(L, true, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1]); break;
+                case LG_DAIMINKAN: ev_daiminkan(L, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1], ev.c[2]); break;
+                case LG_KAKAN: ev_kakan(L, ev.actor, ev.pai); break;
+                case LG_ANKAN: ev_ankan(L, ev.actor, deaka(ev.c[0])); break;
+                case LG_DORA: ev_dora(L, ev.pai); break;
+                case LG_REACH: ev_reach(L, ev.actor); break;
+                case LG_REACH_ACCEPTED: ev_reach_accepted(L, ev.actor); break;
+                case LG_HORA: ev_prologue(L, ev.actor); break;
+                case LG_RYUKYOKU:
+                case LG_END_KYOKU: ev_prologue(L, -1); break;
+                default: set_err(L, MJ_ERR_INTERNAL); break;
+            }
+            if (ev.type == LG_END_KYOKU) P.kyoku_idx[table] += 1;
+            cur += ev.len;
+            P.ev_index[table] += 1;
+            // ---- samples
+            for (int p = 0; p < 4; p++) {
+                if (!((tracked >> p) & 1) || !(F1(cans, p) & CAN_ACT)) continue;
+                int kan_select;
+                const int label = rp_label(L, p, nxt, P.always_include_kan_select, kan_select);
+                if (label < 0) continue;
+                P.label[table * 4 + p] = label;
+                F1(main_row, p) = nr++;
+                if (kan_select >= 0) {
+                    P.kan_label[table * 4 + p] = kan_select;
+                    F1(kan_row, p) = nr++;
+                }
+            }
+            if (nr) break;
+        }
+        P.cursor[table] = cur;
+        if (cur >= n_words && !(F(flags) & TF_DONE)) {
+            F(flags) |= TF_DONE;
+            atomicAdd(&P.counters[1], 1ull);
+        }
+    }
+    F1(n_rows, 0) = (u8)nr;
+    F1(n_rows, 1) = 0;
+    int rows0 = nr;
+    for (int off = 32; off > 0; off >>= 1) rows0 += __shfl_down(rows0, off);
+    if (threadIdx.x == 0) {
+        P.block_rows[2 * blockIdx.x] = rows0;
+        P.block_rows[2 * blockIdx.x + 1] = 0;
+    }
+}
+
+// Per-row sample metadata after mj_k_assign: label, log id, seat, kyoku index, turn, shanten, kan flag, event index.
+struct ReplayMetaParams {
+    const TableBlock* blocks;
+    const uint32_t* rows;
+    int n_rows;
+    const int32_t* label;
+    const int32_t* kan_label;
+    const uint8_t* kyoku_idx;
+    const uint32_t* ev_index;
+    int32_t* out;  // [n_rows][8]
+};
+__global__ void mj_k_replay_meta(ReplayMetaParams P) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.n_rows) return;
+    const uint32_t d = P.rows[r];
+    const int t = ROW_TABLE(d), s = ROW_SEAT(d), kan = ROW_KAN(d);
+    const TableBlock* B = P.blocks + (t >> 6);
+    const int l = t & 63;
+    int32_t* o = P.out + (size_t)r * 8;
+    o[0] = kan ? P.kan_label[t * 4 + s] : P.label[t * 4 + s];
+    o[1] = t;
+    o[2] = s;
+    o[3] = P.kyoku_idx[t];
+    o[4] = B->at_turn[s][l];
+    o[5] = B->shanten[s][l];
+    o[6] = kan;
+    o[7] = (int32_t)P.ev_index[t];
+}

@@ -540,9 +540,9 @@ template <class LN> MJD void ev_reach_accepted(const LN& L, int actor) {  // upd
 }
 
 // ---------------------------------------------------------------- kyoku start (board.rs:99-136,206-239; update.rs:125-217)
-template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
-    const int kyoku = F(kyoku), honba = F(honba);
-    deal_wall(&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
+// kyoku_init: everything a StartKyoku event does to the table, given wall[0..52) (haipai) and wall[60] (first dora
+// indicator); shared by the arena (deal from the seed) and the log replay (tiles from the logged event).
+template <class LN> MJDN void kyoku_init(const LN& L) {
     F(yama_n) = 70;
     F(rinshan_n) = 4;
     F(dora_n) = 5;
@@ -612,6 +612,12 @@ template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
         update_shanten(L, s);
         update_waits_and_furiten(L, s);
     }
+}
+template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
+    const int kyoku = F(kyoku), honba = F(honba);
+    deal_wall(&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
+    kyoku_init(L);
+    const int marker = F1(wall, 56 + 4);
     // first tsumo of the oya
     const int oya = kyoku & 3;
     int tile = F1(wall, 66 + 69);

@@ -1,0 +1,291 @@
+"""libriichi.dataset: `Grp` (dataset/grp.rs) and `GameplayLoader` / `Gameplay` (dataset/gameplay.rs) on the MI355X pool.
+
+`Grp` is a host-side reduction of the event stream.  `GameplayLoader` replays whole batches of logs on the device:
+one table per log, every seat's PlayerState advanced by the step kernel's event handlers (`mj_k_replay`), and every
+decision of a wanted seat encoded by the arena's obs/mask kernels — obs, mask, label and bookkeeping are the
+reference's (gameplay.rs:239-443), produced for all logs of a batch at once instead of one rayon task per player.
+
+Not supported yet: `oracle=True` with `trust_seed=False` semantics of dataset/invisible.rs (the unseen-tile
+reconstruction); `oracle=True` raises NotImplementedError.
+"""
+import gzip
+import json
+
+import numpy as np
+import torch
+
+from . import mjai_log
+from .pool import ACTION_SPACE, OBS_ROWS, TablePool
+
+GRP_SIZE = 7
+
+
+def _read_gz(path):
+    with gzip.open(path, "rt") as f:
+        return f.read()
+
+
+def _parse(raw_log):
+    try:
+        return [json.loads(l) for l in raw_log.splitlines() if l.strip()]
+    except json.JSONDecodeError as ex:
+        raise ValueError(f"failed to parse log: {ex}") from ex
+
+
+class Grp:
+    """dataset/grp.rs:20-165: per-kyoku [grand_kyoku, honba, kyotaku, scores/10000 x4] (f64), final ranks and scores."""
+
+    def __init__(self, feature=None, rank_by_player=(0, 0, 0, 0), final_scores=(0, 0, 0, 0)):
+        self.feature = np.zeros((0, GRP_SIZE), dtype=np.float64) if feature is None else feature
+        self.rank_by_player = list(rank_by_player)
+        self.final_scores = list(final_scores)
+
+    @staticmethod
+    def load_events(events):
+        game_info = []
+        rank_by_player = None
+        final_deltas = [0, 0, 0, 0]
+        final_scores = [0, 0, 0, 0]
+        for ev in reversed(events):
+            t = ev["type"]
+            if t in ("hora", "ryukyoku"):
+                if rank_by_player is None:
+                    ds = ev.get("deltas")
+                    if ds is None:
+                        raise ValueError("invalid log: field `deltas` is required for Hora and Ryukyoku of AL")
+                    final_deltas = [a + b for a, b in zip(final_deltas, ds)]
+            elif t == "reach_accepted":
+                if rank_by_player is None:
+                    final_deltas[ev["actor"]] -= 1000
+            elif t == "start_kyoku":
+                if rank_by_player is None:
+                    final_scores = [a + b for a, b in zip(ev["scores"], final_deltas)]
+                    order = sorted(range(4), key=lambda i: -final_scores[i])  # Rankings::new (stable)
+                    total = sum(final_scores)
+                    if total < 100_000:  # assume the sum of scores to be 100k
+                        final_scores[order[0]] += 100_000 - total
+                    rank_by_player = [0] * 4
+                    for r, pid in enumerate(order):
+                        rank_by_player[pid] = r
+                kyoku = ev["kyoku"]
+                grand = {"E": kyoku - 1, "S": 3 + kyoku}.get(ev["bakaze"], 7 + kyoku)
+                game_info.insert(0, [float(grand), float(ev["honba"]), float(ev["kyotaku"])]
+                                 + [s / 10000.0 for s in ev["scores"]])
+        if rank_by_player is None:
+            raise ValueError("invalid log: no Hora or Ryukyoku after a StartKyoku")
+        return Grp(np.array(game_info, dtype=np.float64).reshape(len(game_info), GRP_SIZE), rank_by_player, final_scores)
+
+    @staticmethod
+    def load_log(raw_log):
+        return Grp.load_events(_parse(raw_log))
+
+    @staticmethod
+    def load_gz_log_files(gzip_filenames):
+        out = []
+        for f in gzip_filenames:
+            try:
+                out.append(Grp.load_log(_read_gz(f)))
+            except Exception as ex:
+                raise RuntimeError(f"error when reading {f}: {ex}") from ex
+        return out
+
+    def __len__(self):
+        return self.feature.shape[0]
+
+    def take_feature(self):
+        f, self.feature = self.feature, np.zeros((0, GRP_SIZE), dtype=np.float64)
+        return f
+
+    def take_rank_by_player(self):
+        return list(self.rank_by_player)
+
+    def take_final_scores(self):
+        return list(self.final_scores)
+
+
+class Gameplay:
+    """One player's samples of one game (gameplay.rs:46-64).  The `take_*` methods hand the per-move lists over like
+    the reference's; the same data stays available as stacked device tensors (`obs_dev`, `masks_dev`) for consumers
+    that batch on the GPU anyway (mortal/dataloader.py stacks them right after)."""
+
+    def __init__(self, player_id, player_name, grp):
+        self.player_id = player_id
+        self.player_name = player_name
+        self.grp = grp
+        self.obs_dev = None
+        self.masks_dev = None
+        self.invisible_obs = []
+        self.actions = []
+        self.at_kyoku = []
+        self.dones = []
+        self.apply_gamma = []
+        self.at_turns = []
+        self.shantens = []
+
+    def _take_list(self, name):
+        v = getattr(self, name)
+        setattr(self, name, [])
+        return v
+
+    def take_obs(self):
+        t, self.obs_dev = self.obs_dev, None
+        return [] if t is None else list(t.cpu().numpy())
+
+    def take_masks(self):
+        t, self.masks_dev = self.masks_dev, None
+        return [] if t is None else list(t.cpu().numpy())
+
+    def take_invisible_obs(self):
+        return self._take_list("invisible_obs")
+
+    def take_actions(self):
+        return self._take_list("actions")
+
+    def take_at_kyoku(self):
+        return self._take_list("at_kyoku")
+
+    def take_dones(self):
+        return self._take_list("dones")
+
+    def take_apply_gamma(self):
+        return self._take_list("apply_gamma")
+
+    def take_at_turns(self):
+        return self._take_list("at_turns")
+
+    def take_shantens(self):
+        return self._take_list("shantens")
+
+    def take_grp(self):
+        g, self.grp = self.grp, Grp()
+        return g
+
+    def take_player_id(self):
+        return self.player_id
+
+
+class GameplayLoader:
+    """dataset/gameplay.rs:21-165."""
+
+    def __init__(self, version, *, oracle=True, player_names=None, excludes=None, trust_seed=False,
+                 always_include_kan_select=True, augmented=False, device="cuda:0"):
+        if version not in OBS_ROWS:
+            raise ValueError(f"unsupported obs version {version}")
+        self.version = version
+        self.oracle = bool(oracle)
+        self.player_names = list(player_names or [])
+        self.excludes = list(excludes or [])
+        self.trust_seed = bool(trust_seed)
+        self.always_include_kan_select = bool(always_include_kan_select)
+        self.augmented = bool(augmented)
+        self.device = device
+        if self.oracle:
+            raise NotImplementedError("GameplayLoader(oracle=True): the unseen-tile reconstruction of "
+                                      "dataset/invisible.rs is not built yet; pass oracle=False")
+
+    def __repr__(self):
+        return (f"GameplayLoader {{ version: {self.version}, oracle: {self.oracle}, player_names: {self.player_names}, "
+                f"excludes: {self.excludes}, trust_seed: {self.trust_seed}, "
+                f"always_include_kan_select: {self.always_include_kan_select}, augmented: {self.augmented} }}")
+
+    # ---- the reference's entry points
+    def load_log(self, raw_log):
+        return self.load_logs([raw_log])[0]
+
+    def load_gz_log_files(self, gzip_filenames):
+        raws = []
+        for f in gzip_filenames:
+            try:
+                raws.append(_read_gz(f))
+            except Exception as ex:
+                raise RuntimeError(f"error when reading {f}: {ex}") from ex
+        return self.load_logs(raws)
+
+    def _wanted(self, names):
+        ps, ex = set(self.player_names), set(self.excludes)
+        out = []
+        for i, name in enumerate(names):
+            if ps:
+                keep = name in ps
+            elif ex:
+                keep = name not in ex
+            else:
+                keep = True
+            if keep:
+                out.append(i)
+        return out
+
+    def load_logs(self, raw_logs):
+        """Batch entry point: list of raw log texts -> list (per log) of lists of Gameplay (one per wanted player)."""
+        games = []
+        for raw in raw_logs:
+            events = _parse(raw)
+            if not events or events[0].get("type") != "start_game":
+                raise ValueError("empty or invalid game log")
+            names = events[0].get("names", ["", "", "", ""])
+            wanted = self._wanted(names)
+            games.append(dict(events=events, names=names, wanted=wanted, grp=Grp.load_events(events)))
+        n = len(games)
+        if n == 0:
+            return []
+        scripts = [mjai_log.encode_events(g["events"], augmented=self.augmented) for g in games]
+        tracked = [sum(1 << p for p in g["wanted"]) for g in games]
+        total_events = sum(len(g["events"]) for g in games)
+        pool = TablePool(n, version=self.version, device=self.device, max_rows=8 * n + 64)
+        try:
+            pool.replay_load(scripts, tracked, self.always_include_kan_select)
+            obs_parts, mask_parts, meta_parts = [], [], []
+            for _ in range(total_events + 8):
+                k = pool.replay_step()
+                if k == 0:
+                    if pool.counters()["games"] >= n:
+                        break
+                    continue
+                obs, masks = pool.encode(0)
+                obs_parts.append(obs)
+                mask_parts.append(masks)
+                meta_parts.append(pool.replay_meta())
+            else:
+                raise RuntimeError("log replay did not terminate")
+            code, tbl = pool.first_error()
+            if code:
+                raise ValueError(f"log {tbl}: the event stream is not a legal game (error code {code})")
+        finally:
+            pool.close()
+        C = OBS_ROWS[self.version]
+        if obs_parts:
+            obs = torch.cat(obs_parts)
+            masks = torch.cat(mask_parts)
+            meta = torch.cat(meta_parts).cpu().numpy()
+        else:
+            obs = torch.empty((0, C, 34), dtype=torch.float32, device=self.device)
+            masks = torch.empty((0, ACTION_SPACE), dtype=torch.bool, device=self.device)
+            meta = np.zeros((0, 8), dtype=np.int32)
+        # order the samples of every (log, seat) like the reference: by event, the kan-select entry after its main entry
+        order = np.lexsort((meta[:, 6], meta[:, 7], meta[:, 2], meta[:, 1])) if len(meta) else np.zeros(0, dtype=np.int64)
+        meta = meta[order]
+        idx_dev = torch.as_tensor(order, device=obs.device, dtype=torch.long)
+        obs, masks = obs[idx_dev], masks[idx_dev]
+        out = []
+        pos = 0
+        for t, g in enumerate(games):
+            per_log = []
+            for p in g["wanted"]:
+                lo = pos
+                while pos < len(meta) and meta[pos, 1] == t and meta[pos, 2] == p:
+                    pos += 1
+                m = meta[lo:pos]
+                gp = Gameplay(p, g["names"][p], Grp(g["grp"].feature.copy(), g["grp"].rank_by_player, g["grp"].final_scores))
+                gp.obs_dev = obs[lo:pos]
+                gp.masks_dev = masks[lo:pos]
+                gp.actions = [int(x) for x in m[:, 0]]
+                gp.at_kyoku = [int(x) for x in m[:, 3]]
+                gp.at_turns = [int(x) for x in m[:, 4]]
+                gp.shantens = [int(x) for x in m[:, 5]]
+                gp.apply_gamma = [bool(x <= 37) for x in m[:, 0]]  # only discard and kan will discount (gameplay.rs:423)
+                ak = gp.at_kyoku
+                gp.dones = [ak[i + 1] > ak[i] for i in range(len(ak) - 1)] + [True]  # gameplay.rs:264-265
+                per_log.append(gp)
+            out.append(per_log)
+        assert pos == len(meta)
+        return out

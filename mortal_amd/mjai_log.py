@@ -87,6 +87,82 @@ def decode_events(words):
     return evs
 
 
+TILE_ID = {n: i for i, n in enumerate(TILE_NAMES)}
+
+
+def augment_tile_id(t):
+    """Tile::augment (tile.rs:154-167): swap manzu and pinzu, keep the red flag."""
+    if t >= 37:
+        return t
+    aka = t >= 34
+    d = (4, 13, 22)[t - 34] if aka else t
+    d = d + 9 if d < 9 else d - 9 if d < 18 else d
+    return {4: 34, 13: 35, 22: 36}[d] if aka else d
+
+
+def encode_events(events, augmented=False):
+    """mjai event dicts (start_game / end_game skipped) -> uint64 words in the LG_* format (inverse of decode_events)."""
+    import numpy as np
+
+    tid = (lambda name: augment_tile_id(TILE_ID[name])) if augmented else (lambda name: TILE_ID[name])
+
+    def word(t, actor=0, target=0, pai=0, c=(), tsumogiri=0):
+        w = t | (actor << 4) | (target << 6) | ((pai & 63) << 8) | (int(bool(tsumogiri)) << 38)
+        for k, x in enumerate(c):
+            w |= (x & 63) << (14 + 6 * k)
+        return w
+
+    def i32x2(a, b):
+        return (a & 0xFFFFFFFF) | ((b & 0xFFFFFFFF) << 32)
+
+    out = []
+    for e in events:
+        t = e["type"]
+        if t in ("start_game", "end_game", "none"):
+            continue
+        if t == "start_kyoku":
+            kyoku = (TILE_ID[e["bakaze"]] - 27) * 4 + e["kyoku"] - 1
+            out.append(word(LG_START_KYOKU, pai=tid(e["dora_marker"]), c=(kyoku,)) | (e["honba"] << _HONBA_SHIFT)
+                       | (e["kyotaku"] << _KYOTAKU_SHIFT))
+            sc = e["scores"]
+            out += [i32x2(sc[0], sc[1]), i32x2(sc[2], sc[3])]
+            tiles = [tid(x) for hand in e["tehais"] for x in hand]
+            if len(tiles) != 52:
+                raise ValueError("start_kyoku needs 4 x 13 tiles")
+            for k in range(7):
+                out.append(sum((tiles[k * 8 + b] if k * 8 + b < 52 else 0) << (8 * b) for b in range(8)))
+        elif t == "tsumo":
+            out.append(word(LG_TSUMO, e["actor"], pai=tid(e["pai"])))
+        elif t == "dahai":
+            out.append(word(LG_DAHAI, e["actor"], pai=tid(e["pai"]), tsumogiri=e["tsumogiri"]))
+        elif t in ("chi", "pon", "daiminkan"):
+            code = {"chi": LG_CHI, "pon": LG_PON, "daiminkan": LG_DAIMINKAN}[t]
+            out.append(word(code, e["actor"], e["target"], tid(e["pai"]), [tid(x) for x in e["consumed"]]))
+        elif t == "kakan":
+            out.append(word(LG_KAKAN, e["actor"], pai=tid(e["pai"]), c=[tid(x) for x in e["consumed"]]))
+        elif t == "ankan":
+            out.append(word(LG_ANKAN, e["actor"], c=[tid(x) for x in e["consumed"]]))
+        elif t == "dora":
+            out.append(word(LG_DORA, pai=tid(e["dora_marker"])))
+        elif t == "reach":
+            out.append(word(LG_REACH, e["actor"]))
+        elif t == "reach_accepted":
+            out.append(word(LG_REACH_ACCEPTED, e["actor"]))
+        elif t == "hora":
+            ura = [tid(x) for x in (e.get("ura_markers") or [])]
+            d = e.get("deltas") or [0, 0, 0, 0]
+            out.append(word(LG_HORA, e["actor"], e["target"]) | (len(ura) << _NURA_SHIFT))
+            out += [i32x2(d[0], d[1]), i32x2(d[2], d[3]), sum(u << (6 * k) for k, u in enumerate(ura))]
+        elif t == "ryukyoku":
+            d = e.get("deltas") or [0, 0, 0, 0]
+            out += [word(LG_RYUKYOKU), i32x2(d[0], d[1]), i32x2(d[2], d[3])]
+        elif t == "end_kyoku":
+            out.append(word(LG_END_KYOKU))
+        else:
+            raise ValueError(f"unknown event type {t!r}")
+    return np.array(out, dtype=np.uint64)
+
+
 def _dumps(ev):
     return json.dumps(ev, separators=(",", ":"), ensure_ascii=False)
 

@@ -92,6 +92,32 @@ class TablePool:
             out += [buf[i, :lens[t0 + i]].copy() for i in range(k)]
         return out
 
+    # ---- log replay (dataset loader)
+    def replay_load(self, scripts, tracked, always_include_kan_select=True):
+        """scripts: one uint64 word array per table (mjai_log.encode_events); tracked: 4-bit seat mask per table."""
+        assert len(scripts) == self.n_tables
+        off = np.zeros(len(scripts) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(x) for x in scripts])
+        script = np.ascontiguousarray(np.concatenate(scripts) if len(scripts) else np.zeros(0), dtype=np.uint64)
+        tr = np.ascontiguousarray(tracked, dtype=np.uint8)
+        check(lib.mj_replay_load(self.h, script.ctypes.data, off.ctypes.data, tr.ctypes.data, len(scripts),
+                                 int(always_include_kan_select)))
+
+    def replay_step(self):
+        check(lib.mj_replay_step(self.h, _stream()))
+        out = (C.c_int32 * 2)()
+        check(lib.mj_rows_count(self.h, out, _stream()))
+        self.n_rows = [out[0], out[1]]
+        return out[0]
+
+    def replay_meta(self):
+        """int32 cuda [n, 8] = label, log, seat, kyoku index, turn, shanten, is-kan-row, event index."""
+        n = self.n_rows[0]
+        meta = torch.empty((n, 8), dtype=torch.int32, device=self.device)
+        if n:
+            check(lib.mj_replay_meta(self.h, meta.data_ptr(), _stream()))
+        return meta
+
     def set_refill(self, nonce_stride):
         check(lib.mj_pool_set_refill(self.h, nonce_stride))
 

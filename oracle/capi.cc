@@ -248,6 +248,8 @@ int mjo_ps_snapshot(void* h, int* o) {
     o[234] = s->real_time_shanten();
     o[235] = s->can_w_riichi; o[236] = s->at_ippatsu; o[237] = s->at_rinshan;
     for (int i = 0; i < 4; i++) o[238 + i] = s->scores[i];
+    o[242] = (int)s->ankan_candidates.size();
+    o[243] = (int)s->kakan_candidates.size();
     return 0;
 }
 // kawa of relative seat `rel` in the pool's u64 entry format (mortal_amd/csrc/mj_state.h KW_*); returns length
