@@ -84,6 +84,15 @@ int mj_replay_load(MjPool* pool, const uint64_t* script_host, const uint32_t* of
 int mj_replay_step(MjPool* pool, void* stream);
 int mj_replay_meta(MjPool* pool, int32_t* meta_dev, void* stream);
 
+/* ---- Single-table access behind libriichi.state.PlayerState (state/player_state.rs:142-167, tests / debugging):
+ * apply one event (LG_* words, "?" tiles = 37 allowed for hidden hands), make (table, seat) the only policy row so that
+ * mj_rows_count + mj_encode return its obs/mask (state/obs_repr.rs:776-791 encode_obs), and a few queries:
+ * what = 0 agari_points(args: is_ron, n_ura, ura[5]) -> ok, ron, tsumo_ko, tsumo_oya | 1 rule_based_agari |
+ *        2 real_time_shanten | 3 doras_owned[4] | 4 add_dora_indicator(args[0]) | 5 set scores(args[0..3]). */
+int mj_table_apply_event(MjPool* pool, int table, const uint64_t* words_host, int n_words, void* stream);
+int mj_table_mark_row(MjPool* pool, int table, int seat, int at_kan_select, void* stream);
+int mj_table_query(MjPool* pool, int table, int seat, int what, const int32_t* args8_host, int32_t* out8_host, void* stream);
+
 /* Number of policy rows per agent produced by the last mj_step (synchronises `stream`). */
 int mj_rows_count(MjPool* pool, int32_t n_rows_out[2], void* stream);
 /* Device array of row descriptors of agent a: table | seat << 28 | is_kan_select << 31. */

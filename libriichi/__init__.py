@@ -3,8 +3,8 @@ the MI355X table pool (mortal_amd).  Put the repository root on PYTHONPATH and t
 (`mortal/one_vs_three.py`, `mortal/player.py`) import this package unchanged.
 
 Implemented: `libriichi.consts`, `libriichi.arena` (OneVsThree/TwoVsTwo `py_vs_py`, incl. `log_dir` mjai dumps),
-`libriichi.stat.Stat`, `libriichi.dataset` (GameplayLoader with oracle=False, Gameplay, Grp).  "Next" rows (SURVEY.md
-§8(f)), present as stubs that raise NotImplementedError on use: `libriichi.mjai`, `libriichi.state`.
+`libriichi.stat.Stat`, `libriichi.dataset` (GameplayLoader with oracle=False, Gameplay, Grp), `libriichi.state.PlayerState`
+(update / encode_obs / getters).  Present as a stub that raises NotImplementedError on use: `libriichi.mjai`.
 """
 import importlib as _il
 import sys as _sys

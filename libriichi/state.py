@@ -1,5 +1,5 @@
-"""libriichi.state — a "next" row of the hot-path scope table; not built this round."""
+"""libriichi.state (reference libriichi/src/state/): `PlayerState(player_id)` with `update(json) -> ActionCandidate`,
+`encode_obs(version, at_kan_select)`, getters, `brief_info()` — on the device path, see mortal_amd/state.py."""
+from mortal_amd.state import ActionCandidate, PlayerState  # noqa: F401
 
-
-def __getattr__(name):
-    raise NotImplementedError(f"libriichi.state.{name} is not implemented yet (SURVEY.md §8(f))")
+__all__ = ["PlayerState", "ActionCandidate"]

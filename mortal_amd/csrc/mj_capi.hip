@@ -443,6 +443,42 @@ int mj_replay_meta(MjPool* P, int32_t* meta_dev, void* stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------- single-table access (libriichi.state.PlayerState)
+int mj_table_apply_event(MjPool* P, int table, const uint64_t* words, int n_words, void* stream) {
+    if (!P || table < 0 || table >= P->n_tables) return fail("bad table");
+    if (n_words < 1 || n_words > 16) return fail("bad event");
+    hipStream_t s = (hipStream_t)stream;
+    uint64_t* dev = nullptr;
+    HIP_OK(hipMalloc(&dev, 16 * sizeof(uint64_t)));
+    HIP_OK(hipMemcpyAsync(dev, words, (size_t)n_words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(mj_k_apply_event, dim3(1), dim3(1), 0, s, P->blocks, table, dev);
+    HIP_OK(hipStreamSynchronize(s));
+    hipFree(dev);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+int mj_table_mark_row(MjPool* P, int table, int seat, int at_kan_select, void* stream) {
+    if (!P || table < 0 || table >= P->n_tables || seat < 0 || seat > 3) return fail("bad table / seat");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mj_k_mark_row, dim3(P->n_blocks), dim3(64), 0, s, P->blocks, P->n_tables, table, seat, at_kan_select,
+                       P->block_rows);
+    return launch_rows(P, s);
+}
+int mj_table_query(MjPool* P, int table, int seat, int what, const int32_t* args8, int32_t* out8, void* stream) {
+    if (!P || table < 0 || table >= P->n_tables || seat < 0 || seat > 3) return fail("bad table / seat");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* dev = nullptr;
+    HIP_OK(hipMalloc(&dev, 16 * sizeof(int32_t)));
+    HIP_OK(hipMemsetAsync(dev, 0, 16 * sizeof(int32_t), s));
+    if (args8) HIP_OK(hipMemcpyAsync(dev, args8, 8 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(mj_k_query, dim3(1), dim3(1), 0, s, P->blocks, table, seat, what, dev, dev + 8);
+    HIP_OK(hipMemcpyAsync(out8, dev + 8, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    hipFree(dev);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int mj_rows_count(MjPool* P, int32_t out[2], void* stream) {
     if (!P) return fail("null pool");
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));

@@ -44,6 +44,50 @@ MJD RpEvent rp_decode(uint64_t w) {
     return e;
 }
 
+// PlayerState::update (state/update.rs:41-122) of all four seats for one event; `w` points at its header word.
+template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uint64_t* w) {
+    switch (ev.type) {
+        case LG_START_KYOKU: {
+            F(kyoku) = (u8)ev.c[0];
+            F(honba) = (u8)((w[0] >> LG_HONBA_SHIFT) & 0xFF);
+            F(kyotaku) = (u8)((w[0] >> LG_KYOTAKU_SHIFT) & 0xFF);
+            F1(scores, 0) = (int)(uint32_t)w[1];
+            F1(scores, 1) = (int)(uint32_t)(w[1] >> 32);
+            F1(scores, 2) = (int)(uint32_t)w[2];
+            F1(scores, 3) = (int)(uint32_t)(w[2] >> 32);
+            for (int i = 0; i < 136; i++) F1(wall, i) = T_UNK;
+            for (int k = 0; k < 7; k++) {
+                const uint64_t v = w[3 + k];
+                for (int b = 0; b < 8; b++) {
+                    const int i = k * 8 + b;
+                    if (i < 52) F1(wall, i) = (u8)((v >> (8 * b)) & 0xFF);
+                }
+            }
+            F1(wall, 60) = (u8)ev.pai;
+            kyoku_init(L);
+            F(flags) |= TF_HAIPAI_DONE;
+            break;
+        }
+        case LG_TSUMO:
+            F(tiles_left) -= 1;
+            ev_tsumo(L, ev.actor, ev.pai);
+            break;
+        case LG_DAHAI: ev_dahai(L, ev.actor, ev.pai, ev.tsumogiri != 0); break;
+        case LG_CHI: ev_chi_pon(L, false, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1]); break;
+        case LG_PON: ev_chi_pon(L, true, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1]); break;
+        case LG_DAIMINKAN: ev_daiminkan(L, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1], ev.c[2]); break;
+        case LG_KAKAN: ev_kakan(L, ev.actor, ev.pai); break;
+        case LG_ANKAN: ev_ankan(L, ev.actor, deaka(ev.c[0])); break;
+        case LG_DORA: ev_dora(L, ev.pai); break;
+        case LG_REACH: ev_reach(L, ev.actor); break;
+        case LG_REACH_ACCEPTED: ev_reach_accepted(L, ev.actor); break;
+        case LG_HORA: ev_prologue(L, ev.actor); break;
+        case LG_RYUKYOKU:
+        case LG_END_KYOKU: ev_prologue(L, -1); break;
+        default: set_err(L, MJ_ERR_INTERNAL); break;
+    }
+}
+
 // label of seat p after the current event (gameplay.rs:296-409); -1 = no sample.  nxt[0..2] = the three events after
 // the current one (type 0 past the end of the log = end_game).
 template <class LN> MJDN int rp_label(const LN& L, int p, const RpEvent nxt[3], int always_kan, int& kan_select) {
@@ -130,49 +174,7 @@ __global__ __launch_bounds__(64) void mj_k_replay(ReplayParams P) {
                 cur = n_words;
                 break;
             }
-            // ---- apply (PlayerState::update for all four seats)
-            switch (ev.type) {
-                case LG_START_KYOKU: {
-                    const uint64_t w = sc[cur];
-                    F(kyoku) = (u8)ev.c[0];
-                    F(honba) = (u8)((w >> LG_HONBA_SHIFT) & 0xFF);
-                    F(kyotaku) = (u8)((w >> LG_KYOTAKU_SHIFT) & 0xFF);
-                    const uint64_t s0 = sc[cur + 1], s1 = sc[cur + 2];
-                    F1(scores, 0) = (int)(uint32_t)s0;
-                    F1(scores, 1) = (int)(uint32_t)(s0 >> 32);
-                    F1(scores, 2) = (int)(uint32_t)s1;
-                    F1(scores, 3) = (int)(uint32_t)(s1 >> 32);
-                    for (int i = 0; i < 136; i++) F1(wall, i) = T_UNK;
-                    for (int k = 0; k < 7; k++) {
-                        const uint64_t v = sc[cur + 3 + k];
-                        for (int b = 0; b < 8; b++) {
-                            const int i = k * 8 + b;
-                            if (i < 52) F1(wall, i) = (u8)((v >> (8 * b)) & 0xFF);
-                        }
-                    }
-                    F1(wall, 60) = (u8)ev.pai;
-                    kyoku_init(L);
-                    F(flags) |= TF_HAIPAI_DONE;
-                    break;
-                }
-                case LG_TSUMO:
-                    F(tiles_left) -= 1;
-                    ev_tsumo(L, ev.actor, ev.pai);
-                    break;
-                case LG_DAHAI: ev_dahai(L, ev.actor, ev.pai, ev.tsumogiri != 0); break;
-                case LG_CHI: ev_chi_pon(L, false, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1]); break;
-                case LG_PON: ev_chi_pon(L, true, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1]); break;
-                case LG_DAIMINKAN: ev_daiminkan(L, ev.actor, ev.target, ev.pai, ev.c[0], ev.c[1], ev.c[2]); break;
-                case LG_KAKAN: ev_kakan(L, ev.actor, ev.pai); break;
-                case LG_ANKAN: ev_ankan(L, ev.actor, deaka(ev.c[0])); break;
-                case LG_DORA: ev_dora(L, ev.pai); break;
-                case LG_REACH: ev_reach(L, ev.actor); break;
-                case LG_REACH_ACCEPTED: ev_reach_accepted(L, ev.actor); break;
-                case LG_HORA: ev_prologue(L, ev.actor); break;
-                case LG_RYUKYOKU:
-                case LG_END_KYOKU: ev_prologue(L, -1); break;
-                default: set_err(L, MJ_ERR_INTERNAL); break;
-            }
+            rp_apply(L, ev, sc + cur);
             if (ev.type == LG_END_KYOKU) P.kyoku_idx[table] += 1;
             cur += ev.len;
             P.ev_index[table] += 1;
@@ -234,4 +236,112 @@ __global__ void mj_k_replay_meta(ReplayMetaParams P) {
     o[5] = B->shanten[s][l];
     o[6] = kan;
     o[7] = (int32_t)P.ev_index[t];
+}
+
+
+// ================================================================ single-table access for libriichi.state.PlayerState
+// (state/player_state.rs:142-167 pyo3 surface: update / encode_obs / getters; used by tests and debugging)
+__global__ void mj_k_apply_event(TableBlock* blocks, int table, const uint64_t* words) {
+    Lane L = {blocks + (table >> 6), table & 63, &c_mj_tables};
+    const RpEvent ev = rp_decode(words[0]);
+    rp_apply(L, ev, words);
+}
+// mark one (table, seat) as the only policy row so that the normal snapshot / encode kernels produce its obs + mask
+__global__ __launch_bounds__(64) void mj_k_mark_row(TableBlock* blocks, int n_tables, int table, int seat, int kan, int* block_rows) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    TableBlock* B = blocks + blockIdx.x;
+    const int l = threadIdx.x;
+    for (int s = 0; s < 4; s++) {
+        B->main_row[s][l] = -1;
+        B->kan_row[s][l] = -1;
+    }
+    const bool me = t == table && t < n_tables;
+    if (me) {
+        if (kan) B->kan_row[seat][l] = 0;
+        else B->main_row[seat][l] = 0;
+    }
+    B->n_rows[0][l] = me ? 1 : 0;
+    B->n_rows[1][l] = 0;
+    if (l == 0) {
+        block_rows[2 * blockIdx.x] = (table >> 6) == (int)blockIdx.x ? 1 : 0;
+        block_rows[2 * blockIdx.x + 1] = 0;
+    }
+}
+// queries / pokes: out int32[8]
+enum { MJ_Q_AGARI_POINTS = 0, MJ_Q_RULE_BASED_AGARI = 1, MJ_Q_REAL_TIME_SHANTEN = 2, MJ_Q_DORAS_OWNED = 3,
+       MJ_Q_ADD_DORA = 4, MJ_Q_SET_SCORES = 5 };
+__global__ void mj_k_query(TableBlock* blocks, int table, int seat, int what, const int32_t* args, int32_t* out) {
+    Lane L = {blocks + (table >> 6), table & 63, &c_mj_tables};
+    const int p = seat;
+    switch (what) {
+        case MJ_Q_AGARI_POINTS: {  // args: is_ron, n_ura, ura[5]  (agent_helper.rs:377-462)
+            u8 ura[5];
+            for (int i = 0; i < 5; i++) ura[i] = (u8)args[2 + i];
+            Point pt = {0, 0, 0};
+            const u32 cans = F1(cans, p);
+            const bool is_ron = args[0] != 0;
+            bool ok = is_ron ? (cans & CAN_RON_AGARI) != 0 : (cans & CAN_TSUMO_AGARI) != 0;
+            if (ok) ok = seat_agari_points(L, p, is_ron, args[1], pt, ura);
+            out[0] = ok;
+            out[1] = pt.ron;
+            out[2] = pt.tsumo_ko;
+            out[3] = pt.tsumo_oya;
+            break;
+        }
+        case MJ_Q_RULE_BASED_AGARI: out[0] = rule_based_agari(L, p); break;
+        case MJ_Q_REAL_TIME_SHANTEN: {  // agent_helper.rs:467-503
+            const u32 cans = F1(cans, p);
+            const int sh = F1(shanten, p);
+            int r;
+            if (!(cans & CAN_DISCARD)) r = sh;
+            else if (sh > 0) r = F1(has_next_shanten, p) ? sh - 1 : sh;
+            else if (F1(last_self_tsumo, p) != MJ_NONE) r = ((F1(waits, p) >> deaka(F1(last_self_tsumo, p))) & 1) ? -1 : 0;
+            else r = calc_all(c_mj_tables, load_hand(L, p), F1(len_div3, p));
+            out[0] = r;
+            break;
+        }
+        case MJ_Q_DORAS_OWNED: {  // doras_owned[rel] (update.rs:780-808 recount): hand (own seat only) + melds + akas
+            for (int rel = 0; rel < 4; rel++) {
+                const int s = (p + rel) & 3;
+                int n = 0;
+                const int nd = F(n_dora_ind);
+                const Hand h = load_hand(L, s);
+                for (int i = 0; i < nd; i++) {
+                    const int d = tile_next(F1(dora_ind, i));
+                    if (rel == 0) n += h.get(d);
+                    for (int k = 0; k < F1(fuuro_n, s); k++)
+                        for (int j = 0; j < 4; j++) {
+                            const int t = F3(fuuro, s, k, j);
+                            if (t != MJ_NONE && deaka(t) == d) n++;
+                        }
+                    for (int k = 0; k < F1(ankan_n, s); k++)
+                        if (F2(ankan, s, k) == d) n += 4;
+                }
+                if (rel == 0) n += __popc(F1(akas_in_hand, s));
+                for (int k = 0; k < F1(fuuro_n, s); k++)
+                    for (int j = 0; j < 4; j++) {
+                        const int t = F3(fuuro, s, k, j);
+                        if (t != MJ_NONE && is_aka(t)) n++;
+                    }
+                for (int k = 0; k < F1(ankan_n, s); k++) {
+                    const int t = F2(ankan, s, k);
+                    if (t == T_5M || t == T_5P || t == T_5S) n++;
+                }
+                out[rel] = n;
+            }
+            break;
+        }
+        case MJ_Q_ADD_DORA: {  // add_dora_indicator without the event prologue (update.rs:780-808)
+            const int n = F(n_dora_ind);
+            if (n < 5) {
+                F1(dora_ind, n) = (u8)args[0];
+                F(n_dora_ind) = (u8)(n + 1);
+                pub_witness(L, args[0]);
+            }
+            break;
+        }
+        case MJ_Q_SET_SCORES:
+            for (int i = 0; i < 4; i++) F1(scores, i) = args[i];
+            break;
+    }
 }

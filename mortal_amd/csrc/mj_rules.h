@@ -172,13 +172,16 @@ template <class LN> MJD void pad_kawa_for_pon_or_daiminkan(const LN& L, int acto
     }
 }
 template <class LN> MJD void hand_remove(const LN& L, int s, Hand& h, int tile) {  // move_tile Discard/FuuroConsume (update.rs:733-775)
-    h.dec(deaka(tile));
+    // the count guard only matters for seats whose hand is hidden (single-perspective replays: "?" tiles); a legal
+    // event never removes a tile the seat does not hold
+    if (h.get(deaka(tile)) > 0) h.dec(deaka(tile));
     if (is_aka(tile)) F1(akas_in_hand, s) &= ~(1 << (tile - T_5MR));
 }
 
 // ---------------------------------------------------------------- events
 template <class LN> MJDN void ev_tsumo(const LN& L, int actor, int pai) {  // update.rs:219-309
     ev_prologue(L, actor);
+    if (pai >= T_UNK) return;  // another seat's hidden draw ("?"): nothing to track (update.rs:226-229)
     int tiles_left = F(tiles_left);  // already decremented by the board
     const int s = actor;
     F1(at_turn, s) += 1;
@@ -604,6 +607,7 @@ template <class LN> MJDN void kyoku_init(const LN& L) {
         u8 akas = 0;
         for (int i = 0; i < 13; i++) {
             int t = F1(wall, s * 13 + i);
+            if (t >= T_UNK) continue;  // hidden hand of a single-perspective log
             h.inc(deaka(t));
             if (is_aka(t)) akas |= 1 << (t - T_5MR);
         }

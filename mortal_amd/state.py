@@ -1,0 +1,181 @@
+"""libriichi.state.PlayerState (state/player_state.rs:142-167, pyo3 surface) on the device path.
+
+One table of a TablePool plays the role of the reference's per-player state machine: `update(event)` applies an mjai
+event through the same HIP event handlers the arena uses (`mj_table_apply_event` -> mj_rules.h ev_*), `encode_obs` runs the
+arena's snapshot + encode kernels for this seat, the getters read the table record back.  Meant for tests and debugging
+— the reference's own scenario tests (state/test.rs) run against it in tests/test_gpu_state.py.
+
+Hidden information is written the reference's way: other seats' haipai and draws are "?" tiles.
+"""
+import json
+
+import numpy as np
+
+from . import mjai_log
+from ._lib import MortalAmdError, check, lib
+from .pool import TablePool, _stream
+
+_CAN_BITS = ["can_discard", "can_chi_low", "can_chi_mid", "can_chi_high", "can_pon", "can_daiminkan", "can_kakan",
+             "can_ankan", "can_riichi", "can_tsumo_agari", "can_ron_agari", "can_ryukyoku"]
+Q_AGARI_POINTS, Q_RULE_BASED_AGARI, Q_REAL_TIME_SHANTEN, Q_DORAS_OWNED, Q_ADD_DORA, Q_SET_SCORES = range(6)
+
+
+class ActionCandidate:
+    """state/action.rs:13-89."""
+
+    def __init__(self, bits=0, target_actor=0):
+        for i, name in enumerate(_CAN_BITS):
+            setattr(self, name, bool((bits >> i) & 1))
+        self.target_actor = int(target_actor)
+
+    can_chi = property(lambda s: s.can_chi_low or s.can_chi_mid or s.can_chi_high)
+    can_kan = property(lambda s: s.can_daiminkan or s.can_kakan or s.can_ankan)
+    can_agari = property(lambda s: s.can_tsumo_agari or s.can_ron_agari)
+    can_pass = property(lambda s: s.can_chi or s.can_pon or s.can_daiminkan or s.can_ron_agari)
+    can_act = property(lambda s: s.can_discard or s.can_chi or s.can_pon or s.can_kan or s.can_riichi or s.can_agari
+                       or s.can_ryukyoku)
+
+    def __repr__(self):
+        on = [n for n in _CAN_BITS if getattr(self, n)]
+        return f"ActionCandidate({', '.join(on)}; target_actor={self.target_actor})"
+
+
+class PlayerState:
+    def __init__(self, player_id, device="cuda:0"):
+        if not 0 <= int(player_id) <= 3:
+            raise ValueError("player_id must be within 0..3")
+        self.player_id = int(player_id)
+        self._pool = TablePool(1, version=4, device=device)
+        self._pool.reset([(0, 0)])
+        self._cache = None
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- update (state/update.rs:23-39)
+    def update(self, mjai_json):
+        ev = json.loads(mjai_json) if isinstance(mjai_json, str) else mjai_json
+        if ev["type"] in ("start_game", "end_game"):
+            ev = {"type": "end_kyoku"}  # same effect on a PlayerState: only the per-event reset of last_cans
+        words = mjai_log.encode_events([ev])
+        check(lib.mj_table_apply_event(self._pool.h, 0, words.ctypes.data, len(words), _stream()))
+        self._cache = None
+        code, _ = self._pool.first_error()
+        if code:
+            raise MortalAmdError(f"rule violation while applying {ev} (error code {code})")
+        return self.last_cans
+
+    def _table(self):
+        if self._cache is None:
+            self._cache = self._pool.debug_table(0)
+        return self._cache
+
+    def _query(self, what, args=()):
+        a = np.zeros(8, dtype=np.int32)
+        a[:len(args)] = args
+        out = np.zeros(8, dtype=np.int32)
+        check(lib.mj_table_query(self._pool.h, 0, self.player_id, what, a.ctypes.data, out.ctypes.data, _stream()))
+        self._cache = None
+        return out
+
+    # ---- obs (state/obs_repr.rs:776-791)
+    def encode_obs(self, version, at_kan_select):
+        self._pool.configure(0, version=int(version))
+        check(lib.mj_table_mark_row(self._pool.h, 0, self.player_id, int(bool(at_kan_select)), _stream()))
+        import ctypes as C
+
+        out = (C.c_int32 * 2)()
+        check(lib.mj_rows_count(self._pool.h, out, _stream()))
+        self._pool.n_rows = [out[0], out[1]]
+        obs, masks = self._pool.encode(0)
+        return obs[0].cpu().numpy(), masks[0].cpu().numpy()
+
+    # ---- getters (state/getter.rs)
+    @property
+    def last_cans(self):
+        t = self._table()
+        return ActionCandidate(int(t["cans"][self.player_id]), int(t["cans_target"][self.player_id]))
+
+    def _hand(self):
+        t = self._table()
+        mp, sz = int(t["hand_mp"][self.player_id]), int(t["hand_sz"][self.player_id])
+        return [(mp >> (3 * i)) & 7 for i in range(18)] + [(sz >> (3 * i)) & 7 for i in range(16)]
+
+    def _bits34(self, name):
+        v = int(self._table()[name][self.player_id])
+        return [bool((v >> i) & 1) for i in range(34)]
+
+    tehai = property(lambda s: s._hand())
+    waits = property(lambda s: s._bits34("waits"))
+    shanten = property(lambda s: int(np.int8(s._table()["shanten"][s.player_id])))
+    at_furiten = property(lambda s: bool(int(s._table()["pflags"][s.player_id]) & (1 << 5)))
+    has_next_shanten_discard = property(lambda s: bool(s._table()["has_next_shanten"][s.player_id]))
+    at_turn = property(lambda s: int(s._table()["at_turn"][s.player_id]))
+    tiles_left = property(lambda s: int(s._table()["tiles_left"][0]))
+    kyotaku = property(lambda s: int(s._table()["kyotaku"][0]))
+    honba = property(lambda s: int(s._table()["honba"][0]))
+    is_menzen = property(lambda s: bool(int(s._table()["pflags"][s.player_id]) & (1 << 7)))
+    akas_in_hand = property(lambda s: [bool((int(s._table()["akas_in_hand"][s.player_id]) >> i) & 1) for i in range(3)])
+    ankan_candidates = property(lambda s: [i for i, b in enumerate(s._bits34("ankan_cand")) if b])
+    kakan_candidates = property(lambda s: [i for i, b in enumerate(s._bits34("kakan_cand")) if b])
+
+    @property
+    def scores(self):
+        """Relative to the player: index 0 is self (player_state.rs:40)."""
+        sc = [int(x) for x in self._table()["scores"]]
+        return sc[self.player_id:] + sc[:self.player_id]
+
+    @property
+    def doras_owned(self):
+        return [int(x) for x in self._query(Q_DORAS_OWNED)[:4]]
+
+    def real_time_shanten(self):
+        return int(self._query(Q_REAL_TIME_SHANTEN)[0])
+
+    def rule_based_agari(self):
+        return bool(self._query(Q_RULE_BASED_AGARI)[0])
+
+    def agari_points(self, is_ron, ura_indicators=()):
+        ura = [mjai_log.TILE_ID[x] if isinstance(x, str) else int(x) for x in ura_indicators]
+        out = self._query(Q_AGARI_POINTS, [int(bool(is_ron)), len(ura)] + ura + [0] * (5 - len(ura)))
+        if not out[0]:
+            raise MortalAmdError("cannot agari / not a hora hand")
+        return dict(ron=int(out[1]), tsumo_ko=int(out[2]), tsumo_oya=int(out[3]))
+
+    def get_rank(self, scores_rel):
+        """update.rs:966-972 + rankings.rs:8-21: rank of self for scores given relative to self."""
+        abs_scores = [0] * 4
+        for i in range(4):
+            abs_scores[(i + self.player_id) % 4] = scores_rel[i]
+        order = sorted(range(4), key=lambda i: -abs_scores[i])
+        return order.index(self.player_id)
+
+    def discard_candidates_with_unconditional_tenpai(self):
+        """agent_helper.rs:88-197, read from the obs plane that carries it (v4 row 877)."""
+        obs, _ = self.encode_obs(4, False)
+        return [bool(x) for x in obs[877]]
+
+    # test hooks (state/test.rs pokes these fields directly)
+    def set_scores_rel(self, scores_rel):
+        abs_scores = [0] * 4
+        for i in range(4):
+            abs_scores[(i + self.player_id) % 4] = int(scores_rel[i])
+        self._query(Q_SET_SCORES, abs_scores)
+
+    def add_dora_indicator(self, tile):
+        self._query(Q_ADD_DORA, [mjai_log.TILE_ID[tile] if isinstance(tile, str) else int(tile)])
+
+    def brief_info(self):
+        names = mjai_log.TILE_NAMES
+        h = self._hand()
+        hand = " ".join(names[t] for t in range(34) for _ in range(h[t]))
+        return (f"player (abs): {self.player_id}\nscores (rel): {self.scores}\ntehai: {hand}\nshanten: {self.shanten}\n"
+                f"furiten: {self.at_furiten}\ntiles left: {self.tiles_left}\nlast cans: {self.last_cans!r}")
