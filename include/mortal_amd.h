@@ -78,9 +78,13 @@ int mj_step_q(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_
  * samples wanted for seat s of log t.  mj_replay_step applies events until some tracked seat has a sample, then
  * mj_rows_count / mj_encode(agent 0) / mj_encode_oracle deliver obs + masks exactly as in the arena, and mj_replay_meta the
  * per-row int32[8] = {label, log, seat, kyoku index, turn, shanten, is kan-select row, event index}.
- * counters()[1] = logs fully replayed. */
+ * counters()[1] = logs fully replayed.
+ * For the invisible obs (GameplayLoader(oracle=True), dataset/invisible.rs) a start_kyoku word may carry the whole wall
+ * (LG_SK_WALL_BIT) or ask for it to be rebuilt from the table's seed (LG_SK_DEAL_BIT, nonces/keys given; trust_seed);
+ * in replay mode mj_encode_oracle lists every undrawn yama tile like Invisible::encode. */
 int mj_replay_load(MjPool* pool, const uint64_t* script_host, const uint32_t* off_host, const uint8_t* tracked_host,
-                   int n_logs, int always_include_kan_select);
+                   int n_logs, int always_include_kan_select, const uint64_t* nonces_host /* NULL ok */,
+                   const uint64_t* keys_host /* NULL ok */);
 int mj_replay_step(MjPool* pool, void* stream);
 int mj_replay_meta(MjPool* pool, int32_t* meta_dev, void* stream);
 

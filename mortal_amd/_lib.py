@@ -53,7 +53,7 @@ def _load():
     L.mj_table_apply_event.argtypes = [vp, i32, vp, i32, vp]
     L.mj_table_mark_row.argtypes = [vp, i32, i32, i32, vp]
     L.mj_table_query.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-    L.mj_replay_load.argtypes = [vp, vp, vp, vp, i32, i32]
+    L.mj_replay_load.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     L.mj_replay_step.argtypes = [vp, vp]
     L.mj_replay_meta.argtypes = [vp, vp, vp]
     L.mj_pool_enable_log.argtypes = [vp, C.c_uint32]

@@ -84,6 +84,7 @@ struct MjPool {
     uint8_t *rp_kyoku = nullptr, *rp_tracked = nullptr;
     int32_t *rp_label = nullptr, *rp_kan_label = nullptr;
     int rp_always_kan = 1;
+    bool rp_active = false;    // replay mode: the invisible obs lists every undrawn yama tile
     uint64_t* log = nullptr;   // optional event log [n_tables][log_cap]
     uint32_t* log_len = nullptr;
     uint32_t log_cap = 0;
@@ -276,6 +277,7 @@ int mj_pool_reset(MjPool* P, const uint64_t* nonces, const uint64_t* keys, const
     HIP_OK(hipMemset(P->final_scores, 0, (size_t)P->n_games_total * 4 * sizeof(int)));
     HIP_OK(hipMemset(P->final_done, 0, (size_t)P->n_games_total));
     if (P->log_len) HIP_OK(hipMemset(P->log_len, 0, (size_t)P->n_tables * sizeof(uint32_t)));
+    P->rp_active = false;
     P->cycles = 0;
     P->rows_valid = false;
     return 0;
@@ -381,7 +383,7 @@ static int launch_rows(MjPool* P, hipStream_t s) {
 
 // ---------------------------------------------------------------- log replay (dataset/gameplay.rs)
 int mj_replay_load(MjPool* P, const uint64_t* script, const uint32_t* off, const uint8_t* tracked, int n_logs,
-                   int always_include_kan_select) {
+                   int always_include_kan_select, const uint64_t* nonces, const uint64_t* keys) {
     if (!P) return fail("null pool");
     if (n_logs != P->n_tables) return fail("mj_replay_load: one log per table (create the pool with n_tables = n_logs)");
     const size_t n_words = off[n_logs];
@@ -406,6 +408,12 @@ int mj_replay_load(MjPool* P, const uint64_t* script, const uint32_t* off, const
     std::vector<TableBlock> host(P->n_blocks);
     memset(host.data(), 0, host.size() * sizeof(TableBlock));
     for (int t = P->n_tables; t < P->n_blocks * MJ_LANES; t++) host[t >> 6].flags[t & 63] = TF_INACTIVE | TF_DONE | TF_ENDED;
+    if (nonces && keys)
+        for (int t = 0; t < P->n_tables; t++) {
+            host[t >> 6].seed_nonce[t & 63] = nonces[t];
+            host[t >> 6].seed_key[t & 63] = keys[t];
+        }
+    P->rp_active = true;
     HIP_OK(hipMemcpy(P->blocks, host.data(), host.size() * sizeof(TableBlock), hipMemcpyHostToDevice));
     HIP_OK(hipMemset(P->counters, 0, 8 * sizeof(unsigned long long)));
     P->cycles = 0;
@@ -424,6 +432,7 @@ int mj_replay_step(MjPool* P, void* stream) {
     rp.kyoku_idx = P->rp_kyoku;
     rp.tracked = P->rp_tracked;
     rp.always_include_kan_select = P->rp_always_kan;
+    rp.deal_algo = P->deal_algo;
     rp.block_rows = P->block_rows;
     rp.label = P->rp_label;
     rp.kan_label = P->rp_kan_label;
@@ -584,6 +593,7 @@ int mj_encode_oracle(MjPool* P, int agent, float* out, void* stream) {
     ep.version = P->version[agent & 1];
     ep.snap = P->snap;
     ep.out = out;
+    ep.all_yama = P->rp_active ? 1 : 0;
     size_t lds = enc_oracle_lds_bytes(ep.version);
     hipStream_t s = (hipStream_t)stream;
     if (ep.version == 1) hipLaunchKernelGGL(mj_k_encode_oracle<true>, dim3(n), dim3(ENC_THREADS), lds, s, ep);

@@ -565,6 +565,7 @@ struct OracleEncParams {
     int version;
     const TableOne* snap;
     float* out;  // [n_rows][rows][34]
+    int all_yama;  // dataset flavour (dataset/invisible.rs:217-224): every undrawn yama tile, not only the live ones
 };
 
 template <bool V1>
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode_oracle(OracleEncParam
         const int j = tid - 64;
         const int W0 = 3 * SEAT_ROWS, R0 = W0 + 138, D0 = R0 + 8, U0 = D0 + 10;
         if (j < 69) {
-            if (j < (int)F(tiles_left) && j < (int)F(yama_n)) encode_tile(W0 + 2 * j, F1(wall, 66 + F(yama_n) - 1 - j));
+            if ((P.all_yama || j < (int)F(tiles_left)) && j < (int)F(yama_n)) encode_tile(W0 + 2 * j, F1(wall, 66 + F(yama_n) - 1 - j));
         } else if (j < 73) {
             const int i = j - 69, n = F(rinshan_n);
             if (i < n) encode_tile(R0 + 2 * i, F1(wall, 52 + n - 1 - i));

@@ -19,6 +19,7 @@ struct ReplayParams {
     uint8_t* kyoku_idx;          // [n_tables] kyoku counter of the loader (gameplay.rs:279)
     const uint8_t* tracked;      // [n_tables] bit s: samples wanted for seat s
     int always_include_kan_select;
+    int deal_algo;
     int* block_rows;             // [n_blocks][2] row counts for mj_k_scan / mj_k_assign
     int32_t* label;              // [n_tables][4] label of the pending main row (valid when main_row >= 0)
     int32_t* kan_label;          // [n_tables][4] label (tile id) of the pending kan-select row
@@ -30,7 +31,7 @@ struct RpEvent {
 };
 MJD int rp_len(uint64_t w) {
     const int t = (int)(w & 15);
-    return t == LG_START_KYOKU ? 10 : t == LG_HORA ? 4 : t == LG_RYUKYOKU ? 3 : 1;
+    return t == LG_START_KYOKU ? (((w >> LG_SK_WALL_BIT) & 1) ? 27 : 10) : t == LG_HORA ? 4 : t == LG_RYUKYOKU ? 3 : 1;
 }
 MJD RpEvent rp_decode(uint64_t w) {
     RpEvent e;
@@ -45,7 +46,19 @@ MJD RpEvent rp_decode(uint64_t w) {
 }
 
 // PlayerState::update (state/update.rs:41-122) of all four seats for one event; `w` points at its header word.
-template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uint64_t* w) {
+template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uint64_t* w, int deal_algo = 0) {
+    // wall cursors for the invisible obs (dataset/gameplay.rs:281-300): a draw after a kan comes from the rinshan
+    if (ev.type == LG_TSUMO) {
+        u32 fl = F(flags);
+        if (fl & TF_DEAL_FROM_RINSHAN) {
+            F(flags) = fl & ~TF_DEAL_FROM_RINSHAN;
+            if (F(rinshan_n) > 0) F(rinshan_n) -= 1;
+        } else if (F(yama_n) > 0) {
+            F(yama_n) -= 1;
+        }
+    } else if (ev.type == LG_ANKAN || ev.type == LG_KAKAN || ev.type == LG_DAIMINKAN) {
+        F(flags) |= TF_DEAL_FROM_RINSHAN;
+    }
     switch (ev.type) {
         case LG_START_KYOKU: {
             F(kyoku) = (u8)ev.c[0];
@@ -64,6 +77,20 @@ template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uin
                 }
             }
             F1(wall, 60) = (u8)ev.pai;
+            if ((w[0] >> LG_SK_DEAL_BIT) & 1) {
+                // trust_seed (invisible.rs:36-71): the game came from this engine, rebuild the whole wall from its seed
+                u8 logged[52];
+                for (int i = 0; i < 52; i++) logged[i] = F1(wall, i);
+                deal_wall(&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), F(kyoku), F(honba), deal_algo);
+                bool same = F1(wall, 60) == ev.pai;
+                for (int i = 0; i < 52; i++) same = same && logged[i] == F1(wall, i);
+                if (!same) set_err(L, MJ_ERR_WALL);  // the seed does not reproduce the logged haipai
+            } else if ((w[0] >> LG_SK_WALL_BIT) & 1) {
+                for (int k = 0; k < 17; k++) {
+                    const uint64_t v = w[10 + k];
+                    for (int b = 0; b < 8; b++) F1(wall, k * 8 + b) = (u8)((v >> (8 * b)) & 0xFF);
+                }
+            }
             kyoku_init(L);
             F(flags) |= TF_HAIPAI_DONE;
             break;
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(64) void mj_k_replay(ReplayParams P) {
                 cur = n_words;
                 break;
             }
-            rp_apply(L, ev, sc + cur);
+            rp_apply(L, ev, sc + cur, P.deal_algo);
             if (ev.type == LG_END_KYOKU) P.kyoku_idx[table] += 1;
             cur += ev.len;
             P.ev_index[table] += 1;

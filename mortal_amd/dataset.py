@@ -5,8 +5,9 @@ one table per log, every seat's PlayerState advanced by the step kernel's event 
 decision of a wanted seat encoded by the arena's obs/mask kernels — obs, mask, label and bookkeeping are the
 reference's (gameplay.rs:239-443), produced for all logs of a batch at once instead of one rayon task per player.
 
-Not supported yet: `oracle=True` with `trust_seed=False` semantics of dataset/invisible.rs (the unseen-tile
-reconstruction); `oracle=True` raises NotImplementedError.
+`oracle=True` adds the invisible obs of dataset/invisible.rs: the wall of every kyoku is either rebuilt on the device from
+the game's seed (`trust_seed=True`, logs written by this engine / the reference arena) or reconstructed from the log with
+the never-seen tiles filled in at random — like the reference, that filler is not reproducible.
 """
 import gzip
 import json
@@ -179,9 +180,9 @@ class GameplayLoader:
         self.always_include_kan_select = bool(always_include_kan_select)
         self.augmented = bool(augmented)
         self.device = device
-        if self.oracle:
-            raise NotImplementedError("GameplayLoader(oracle=True): the unseen-tile reconstruction of "
-                                      "dataset/invisible.rs is not built yet; pass oracle=False")
+        if self.oracle and self.trust_seed and self.augmented:
+            raise NotImplementedError("oracle=True with trust_seed=True and augmented=True: the seed rebuilds the "
+                                      "un-augmented wall (the reference mixes the two as well); drop one of the flags")
 
     def __repr__(self):
         return (f"GameplayLoader {{ version: {self.version}, oracle: {self.oracle}, player_names: {self.player_names}, "
@@ -215,6 +216,74 @@ class GameplayLoader:
                 out.append(i)
         return out
 
+    @staticmethod
+    def _walls_from_events(events, augmented, rng):
+        """Invisible::new without a seed (invisible.rs:24-149): per kyoku the 136-tile wall in the pool's layout —
+        haipai 0..51, rinshan 52..55 (popped from the back), dora indicators 56..60 (back first), ura 61..65, yama 66..135
+        (popped from the back) — known tiles from the log, the rest drawn at random from the unseen tiles."""
+        tid = (lambda n: mjai_log.augment_tile_id(mjai_log.TILE_ID[n])) if augmented else (lambda n: mjai_log.TILE_ID[n])
+        walls = []
+        cur = None
+
+        def fresh():
+            unknown = [4] * 37
+            for t in (4, 13, 22):
+                unknown[t] = 3
+            unknown[34] = unknown[35] = unknown[36] = 1
+            return dict(hai=[], yama=[], rinshan=[], dora=[], ura=[], unknown=unknown, from_rinshan=False, ura_done=False)
+
+        for ev in events:
+            t = ev["type"]
+            if t == "start_kyoku":
+                cur = fresh()
+                cur["dora"].append(tid(ev["dora_marker"]))
+                cur["unknown"][cur["dora"][0]] -= 1
+                for hand in ev["tehais"]:
+                    for x in hand:
+                        cur["hai"].append(tid(x))
+                        cur["unknown"][tid(x)] -= 1
+            elif cur is None:
+                continue
+            elif t == "tsumo":
+                p = tid(ev["pai"])
+                if cur["from_rinshan"]:
+                    cur["rinshan"].append(p)
+                    cur["from_rinshan"] = False
+                else:
+                    cur["yama"].append(p)
+                cur["unknown"][p] -= 1
+            elif t in ("ankan", "kakan", "daiminkan"):
+                cur["from_rinshan"] = True
+            elif t == "dora":
+                cur["dora"].append(tid(ev["dora_marker"]))
+                cur["unknown"][cur["dora"][-1]] -= 1
+            elif t == "hora" and ev.get("ura_markers") is not None and not cur["ura_done"]:
+                for x in ev["ura_markers"]:
+                    cur["ura"].append(tid(x))
+                    cur["unknown"][tid(x)] -= 1
+                cur["ura_done"] = True
+            elif t == "end_kyoku":
+                if min(cur["unknown"]) < 0:
+                    raise ValueError("invalid log: more than four copies of a tile")
+                filler = [k for k, c in enumerate(cur["unknown"]) for _ in range(c)]
+                rng.shuffle(filler)
+                for key, size in (("yama", 70), ("rinshan", 4), ("dora", 5), ("ura", 5)):
+                    while len(cur[key]) < size:
+                        cur[key].append(filler.pop())
+                assert not filler
+                wall = [0] * 136
+                wall[:52] = cur["hai"]
+                for k in range(4):
+                    wall[52 + 3 - k] = cur["rinshan"][k]
+                for k in range(5):
+                    wall[56 + 4 - k] = cur["dora"][k]
+                    wall[61 + k] = cur["ura"][k]
+                for k in range(70):
+                    wall[66 + 69 - k] = cur["yama"][k]
+                walls.append(wall)
+                cur = None
+        return walls
+
     def load_logs(self, raw_logs):
         """Batch entry point: list of raw log texts -> list (per log) of lists of Gameplay (one per wanted player)."""
         games = []
@@ -228,13 +297,27 @@ class GameplayLoader:
         n = len(games)
         if n == 0:
             return []
-        scripts = [mjai_log.encode_events(g["events"], augmented=self.augmented) for g in games]
+        nonces = keys = None
+        if not self.oracle:
+            scripts = [mjai_log.encode_events(g["events"], augmented=self.augmented) for g in games]
+        else:
+            rng = np.random.default_rng()
+            seeds = [g["events"][0].get("seed") if self.trust_seed else None for g in games]
+            nonces = np.array([s[0] if s else 0 for s in seeds], dtype=np.uint64)
+            keys = np.array([s[1] if s else 0 for s in seeds], dtype=np.uint64)
+            scripts = []
+            for g, seed in zip(games, seeds):
+                if seed:  # the game was emulated by this engine: use the seed directly (invisible.rs:36-71)
+                    scripts.append(mjai_log.encode_events(g["events"], augmented=self.augmented, deal_from_seed=True))
+                else:
+                    walls = self._walls_from_events(g["events"], self.augmented, rng)
+                    scripts.append(mjai_log.encode_events(g["events"], augmented=self.augmented, walls=walls))
         tracked = [sum(1 << p for p in g["wanted"]) for g in games]
         total_events = sum(len(g["events"]) for g in games)
         pool = TablePool(n, version=self.version, device=self.device, max_rows=8 * n + 64)
         try:
-            pool.replay_load(scripts, tracked, self.always_include_kan_select)
-            obs_parts, mask_parts, meta_parts = [], [], []
+            pool.replay_load(scripts, tracked, self.always_include_kan_select, nonces, keys)
+            obs_parts, mask_parts, meta_parts, inv_parts = [], [], [], []
             for _ in range(total_events + 8):
                 k = pool.replay_step()
                 if k == 0:
@@ -245,6 +328,8 @@ class GameplayLoader:
                 obs_parts.append(obs)
                 mask_parts.append(masks)
                 meta_parts.append(pool.replay_meta())
+                if self.oracle:
+                    inv_parts.append(pool.encode_oracle(0))
             else:
                 raise RuntimeError("log replay did not terminate")
             code, tbl = pool.first_error()
@@ -266,6 +351,7 @@ class GameplayLoader:
         meta = meta[order]
         idx_dev = torch.as_tensor(order, device=obs.device, dtype=torch.long)
         obs, masks = obs[idx_dev], masks[idx_dev]
+        inv = torch.cat(inv_parts)[idx_dev].cpu().numpy() if (self.oracle and inv_parts) else None
         out = []
         pos = 0
         for t, g in enumerate(games):
@@ -278,6 +364,8 @@ class GameplayLoader:
                 gp = Gameplay(p, g["names"][p], Grp(g["grp"].feature.copy(), g["grp"].rank_by_player, g["grp"].final_scores))
                 gp.obs_dev = obs[lo:pos]
                 gp.masks_dev = masks[lo:pos]
+                if inv is not None:
+                    gp.invisible_obs = list(inv[lo:pos])
                 gp.actions = [int(x) for x in m[:, 0]]
                 gp.at_kyoku = [int(x) for x in m[:, 3]]
                 gp.at_turns = [int(x) for x in m[:, 4]]

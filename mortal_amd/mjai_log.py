@@ -45,7 +45,7 @@ def decode_events(words):
             for k in range(7):
                 v = int(words[i + 2 + k])
                 tiles += [(v >> (8 * b)) & 0xFF for b in range(8)]
-            i += 9
+            i += 9 + (17 if (w >> 63) & 1 else 0)
             evs.append({"type": "start_kyoku", "bakaze": tn[27 + kyoku // 4], "dora_marker": tn[pai], "kyoku": kyoku % 4 + 1,
                         "honba": (w >> _HONBA_SHIFT) & 0xFF, "kyotaku": (w >> _KYOTAKU_SHIFT) & 0xFF, "oya": kyoku % 4,
                         "scores": scores, "tehais": [[tn[x] for x in tiles[s * 13:(s + 1) * 13]] for s in range(4)]})
@@ -100,8 +100,11 @@ def augment_tile_id(t):
     return {4: 34, 13: 35, 22: 36}[d] if aka else d
 
 
-def encode_events(events, augmented=False):
-    """mjai event dicts (start_game / end_game skipped) -> uint64 words in the LG_* format (inverse of decode_events)."""
+def encode_events(events, augmented=False, walls=None, deal_from_seed=False):
+    """mjai event dicts (start_game / end_game skipped) -> uint64 words in the LG_* format (inverse of decode_events).
+
+    Replay scripts only: `walls` = one 136-tile id sequence per kyoku (appended to its start_kyoku, LG_SK_WALL_BIT), or
+    `deal_from_seed` (LG_SK_DEAL_BIT: the device rebuilds the wall from the table's seed)."""
     import numpy as np
 
     tid = (lambda name: augment_tile_id(TILE_ID[name])) if augmented else (lambda name: TILE_ID[name])
@@ -116,6 +119,7 @@ def encode_events(events, augmented=False):
         return (a & 0xFFFFFFFF) | ((b & 0xFFFFFFFF) << 32)
 
     out = []
+    n_kyoku = 0
     for e in events:
         t = e["type"]
         if t in ("start_game", "end_game", "none"):
@@ -131,6 +135,16 @@ def encode_events(events, augmented=False):
                 raise ValueError("start_kyoku needs 4 x 13 tiles")
             for k in range(7):
                 out.append(sum((tiles[k * 8 + b] if k * 8 + b < 52 else 0) << (8 * b) for b in range(8)))
+            if deal_from_seed:
+                out[-10] |= 1 << 62
+            elif walls is not None:
+                wall = [int(x) for x in walls[n_kyoku]]
+                if len(wall) != 136 or wall[:52] != tiles:
+                    raise ValueError("wall does not start with the logged haipai")
+                out[-10] |= 1 << 63
+                for k in range(17):
+                    out.append(sum(wall[k * 8 + b] << (8 * b) for b in range(8)))
+            n_kyoku += 1
         elif t == "tsumo":
             out.append(word(LG_TSUMO, e["actor"], pai=tid(e["pai"])))
         elif t == "dahai":

@@ -93,15 +93,19 @@ class TablePool:
         return out
 
     # ---- log replay (dataset loader)
-    def replay_load(self, scripts, tracked, always_include_kan_select=True):
-        """scripts: one uint64 word array per table (mjai_log.encode_events); tracked: 4-bit seat mask per table."""
+    def replay_load(self, scripts, tracked, always_include_kan_select=True, nonces=None, keys=None):
+        """scripts: one uint64 word array per table (mjai_log.encode_events); tracked: 4-bit seat mask per table;
+        nonces / keys: per-table game seeds for scripts that ask the device to rebuild the wall (trust_seed)."""
         assert len(scripts) == self.n_tables
         off = np.zeros(len(scripts) + 1, dtype=np.uint32)
         off[1:] = np.cumsum([len(x) for x in scripts])
         script = np.ascontiguousarray(np.concatenate(scripts) if len(scripts) else np.zeros(0), dtype=np.uint64)
         tr = np.ascontiguousarray(tracked, dtype=np.uint8)
+        n64 = np.ascontiguousarray(nonces, dtype=np.uint64) if nonces is not None else None
+        k64 = np.ascontiguousarray(keys, dtype=np.uint64) if keys is not None else None
         check(lib.mj_replay_load(self.h, script.ctypes.data, off.ctypes.data, tr.ctypes.data, len(scripts),
-                                 int(always_include_kan_select)))
+                                 int(always_include_kan_select), n64.ctypes.data if n64 is not None else None,
+                                 k64.ctypes.data if k64 is not None else None))
 
     def replay_step(self):
         check(lib.mj_replay_step(self.h, _stream()))

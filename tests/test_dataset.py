@@ -89,3 +89,32 @@ def test_gameplay_loader_matches_reference_restatement(oracle, version, always_k
             grp = g.take_grp()
             assert grp.take_feature().shape[1] == 7
     assert n_samples > 1500 and n_kan > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", [1, 4])
+def test_gameplay_loader_invisible_obs(oracle, version):
+    """oracle=True: with trust_seed the wall is rebuilt from the game seed on the device and every invisible obs equals
+    dataset/invisible.rs restated on the oracle; without it the opponents' planes still match and the wall planes hold
+    the right number of tiles (the never-seen tiles are a random fill in the reference too)."""
+    import dataset_ref
+    from libriichi.dataset import GameplayLoader
+
+    logs = _oracle_logs(oracle, 5, "greedy", 31337)
+    names = ["a", "c"]
+    trusted = GameplayLoader(version, oracle=True, trust_seed=True, player_names=names).load_logs(logs)
+    blind = GameplayLoader(version, oracle=True, trust_seed=False, player_names=names).load_logs(logs)
+    opp_rows = 45 if version == 1 else 51
+    n = 0
+    for raw, gt, gb in zip(logs, trusted, blind):
+        events = [json.loads(l) for l in raw.splitlines()]
+        for a, b in zip(gt, gb):
+            ref = dataset_ref.load_invisible_by_player(oracle, events, a.player_id, version)
+            inv_a, inv_b = a.take_invisible_obs(), b.take_invisible_obs()
+            assert len(inv_a) == len(ref) == len(inv_b) == len(a.actions)
+            for k in range(len(ref)):
+                assert (inv_a[k].view(np.uint32) == ref[k].view(np.uint32)).all(), (a.player_id, k)
+                assert (inv_b[k][:opp_rows] == ref[k][:opp_rows]).all()
+                assert inv_b[k][opp_rows:].sum(axis=1)[::2].sum() == ref[k][opp_rows:].sum(axis=1)[::2].sum()
+            n += len(ref)
+    assert n > 500

@@ -42,8 +42,7 @@ def test_libriichi_surface():
         OneVsThree(True)  # keyword-only like the pyo3 signature (one_vs_three.rs:27)
     assert hasattr(libriichi.stat.Stat, "from_dir") and hasattr(libriichi.stat.Stat, "avg_pt")
     assert hasattr(libriichi.dataset.GameplayLoader, "load_gz_log_files") and hasattr(libriichi.dataset.Grp, "load_log")
-    with pytest.raises(NotImplementedError):
-        libriichi.dataset.GameplayLoader(4, oracle=True)  # dataset/invisible.rs is not built yet
+    assert "oracle: true" in repr(libriichi.dataset.GameplayLoader(4)).lower()  # oracle=True is the reference's default
     with pytest.raises(NotImplementedError):
         libriichi.mjai.Bot
 
