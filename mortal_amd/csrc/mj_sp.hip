@@ -279,6 +279,7 @@ struct SpTeam {
     u64 r3[4];               // per suit s: merge of the three OTHER base rows
     int coff[34];            // per required tile t: offset of its first child inside the node's child list
     u8 tiles[36];            // required tiles in ascending order
+    u8 kinds[16];            // tile kinds present in the hand (<= 14), ascending
     union {
         struct {
             u64 rowt[34];    // expand: table row of (h + t) in suit(t)
@@ -457,9 +458,19 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            // ---- B2: (required t, d) probes, four items per lane and round so that their gathers overlap:
+            // ---- B2: (required t, d) probes over the tile kinds actually in the hand (+ the drawn tile itself), four
+            // items per lane and round so that their gathers overlap:
             // same suit -> final(r3[suit], gathered row of h+t-d); other suit -> final(U[t][suit d], row of h-d)
-            const int n_items = n_tiles * 34;
+            const u64 hmask = S.h.nonzero_mask();
+            const int n_kinds = __popcll(hmask), stride = n_kinds + 1;
+#pragma unroll
+            for (int rnd = 0; rnd < 2; rnd++) {
+                const int t = ln + 32 * rnd;
+                if (t < 34 && ((hmask >> t) & 1)) TM->kinds[__popcll(hmask & ((1ull << t) - 1))] = (u8)t;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            const int n_items = n_tiles * stride;
             for (int base = 0; base < n_items; base += 128) {
                 u64 rdv[4];
                 int tt[4], dd[4], tii[4];
@@ -468,12 +479,13 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                 for (int q = 0; q < 4; q++) {
                     const int item = base + q * 32 + ln;
                     valid[q] = item < n_items;
-                    const int ti = min(item, n_items - 1) / 34;
-                    const int t = TM->tiles[ti], d = item % 34;
+                    const int ti = min(item, n_items - 1) / stride, ki = min(item, n_items - 1) % stride;
+                    const int t = TM->tiles[ti];
+                    const int d = ki < n_kinds ? TM->kinds[ki] : t;  // last slot: the drawn tile when it is a new kind
                     tii[q] = ti;
                     tt[q] = t;
                     dd[q] = d;
-                    valid[q] = valid[q] && (S.h.get(d) + (d == t)) > 0;
+                    valid[q] = valid[q] && (ki < n_kinds || !((hmask >> t) & 1));
                     const int st = sh_suit(t);
                     rdv[q] = 0;
                     if (valid[q] && sh_suit(d) == st && d != t) rdv[q] = sh_load(Tb, st, B.key[st] + sh_pow(t) - sh_pow(d));
