@@ -64,12 +64,28 @@ struct Hand {
         else sz &= ~(7ull << (3 * (t - 18)));
     }
     MJD bool empty() const { return (mp | sz) == 0; }
-    MJD u64 nonzero_mask() const {  // bit t set iff count(t) > 0
-        u64 m = 0;
-#pragma unroll
-        for (int t = 0; t < 34; t++) m |= (u64)(get(t) != 0) << t;
-        return m;
+    // ---- bit-parallel views of the 3-bit count fields (bit 0 of field f = bit 3f)
+    static constexpr u64 LSB3 = 0x1249249249249249ull;
+    static MJD u64 nz_fields(u64 x) { return (x | (x >> 1) | (x >> 2)) & LSB3; }   // count >= 1
+    static MJD u64 ge2_fields(u64 x) { return ((x >> 1) | (x >> 2)) & LSB3; }      // count >= 2
+    static MJD u64 compress3(u64 x) {  // bit 3f -> bit f (21 fields)
+        x &= LSB3;
+        x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ull;
+        x = (x ^ (x >> 4)) & 0x100f00f00f00f00full;
+        x = (x ^ (x >> 8)) & 0x001f0000ff0000ffull;
+        x = (x ^ (x >> 16)) & 0x001f00000000ffffull;
+        x = (x ^ (x >> 32)) & 0x00000000001fffffull;
+        return x;
     }
+    MJD u64 nonzero_mask() const {  // bit t set iff count(t) > 0
+        return compress3(nz_fields(mp)) | (compress3(nz_fields(sz)) << 18);
+    }
+    // yaokyuu tiles as field masks: 1m 9m 1p 9p (mp fields 0 8 9 17), 1s 9s + honours (sz fields 0 8 9..15)
+    static constexpr u64 YAO_MP = 0x0008000009000001ull, YAO_SZ = 0x0000249249000001ull;
+    MJD int n_kinds() const { return __popcll(nz_fields(mp)) + __popcll(nz_fields(sz)); }
+    MJD int n_pairs() const { return __popcll(ge2_fields(mp)) + __popcll(ge2_fields(sz)); }
+    MJD int n_yao_kinds() const { return __popcll(nz_fields(mp) & YAO_MP) + __popcll(nz_fields(sz) & YAO_SZ); }
+    MJD int n_yao_pairs() const { return __popcll(ge2_fields(mp) & YAO_MP) + __popcll(ge2_fields(sz) & YAO_SZ); }
 };
 
 // ---------------------------------------------------------------- shanten (shanten.rs:51-150)
@@ -140,25 +156,12 @@ MJD int calc_normal(const MjTablesDev& T, Hand h, int len_div3) {  // shanten.rs
     return sh_add_jihai_final(v, rz, len_div3) - 1;
 }
 MJD int calc_chitoi(Hand h) {  // shanten.rs:104-118
-    int pairs = 0, kinds = 0;
-#pragma unroll
-    for (int t = 0; t < 34; t++) {
-        int c = h.get(t);
-        kinds += c > 0;
-        pairs += c >= 2;
-    }
+    const int pairs = h.n_pairs(), kinds = h.n_kinds();
     int redunct = kinds >= 7 ? 0 : 7 - kinds;
     return 7 - pairs + redunct - 1;
 }
 MJD int calc_kokushi(Hand h) {  // shanten.rs:120-137
-    int pairs = 0, kinds = 0;
-#pragma unroll
-    for (int t = 0; t < 34; t++) {
-        if (!((YAOKYUU_MASK >> t) & 1)) continue;
-        int c = h.get(t);
-        kinds += c > 0;
-        pairs += c >= 2;
-    }
+    const int pairs = h.n_yao_pairs(), kinds = h.n_yao_kinds();
     return 14 - kinds - (pairs > 0) - 1;
 }
 MJD int calc_all(const MjTablesDev& T, Hand h, int len_div3) {  // shanten.rs:139-150
@@ -180,11 +183,9 @@ struct ShBase {
     int pairs, kinds, kpairs, kkinds;  // chitoi / kokushi counters (shanten.rs:104-137)
 };
 MJD int sh_suit(int t) { return t < 9 ? 0 : t < 18 ? 1 : t < 27 ? 2 : 3; }
-MJD u32 sh_pow(int t) {  // weight of tile t inside its suit key (first tile most significant)
+MJD u32 sh_pow(int t) {  // weight of tile t inside its suit key (first tile most significant): 5^e, e = 0..8
     const int e = t < 27 ? 8 - t % 9 : 6 - (t - 27);
-    u32 p = 1;
-    for (int i = 0; i < e; i++) p *= 5;
-    return p;
+    return ((e & 1) ? 5u : 1u) * ((e & 2) ? 25u : 1u) * ((e & 4) ? 625u : 1u) * ((e & 8) ? 390625u : 1u);
 }
 MJD u64 sh_load(const MjTablesDev& T, int suit, u32 key) {
     return suit < 3 ? sh_row(T.suhai, T.n_suhai, key) : sh_row(T.jihai, T.n_jihai, key);
@@ -197,17 +198,10 @@ MJD ShBase sh_base(const MjTablesDev& T, Hand h) {
     b.key[3] = suit_key7(h.sz >> 27);
 #pragma unroll
     for (int i = 0; i < 4; i++) b.row[i] = sh_load(T, i, b.key[i]);
-    b.pairs = b.kinds = b.kpairs = b.kkinds = 0;
-#pragma unroll
-    for (int t = 0; t < 34; t++) {
-        int c = h.get(t);
-        b.kinds += c > 0;
-        b.pairs += c >= 2;
-        if ((YAOKYUU_MASK >> t) & 1) {
-            b.kkinds += c > 0;
-            b.kpairs += c >= 2;
-        }
-    }
+    b.pairs = h.n_pairs();
+    b.kinds = h.n_kinds();
+    b.kpairs = h.n_yao_pairs();
+    b.kkinds = h.n_yao_kinds();
     return b;
 }
 MJD int sh_eval(u64 rm, u64 rp, u64 rs, u64 rz, int len_div3, int pairs, int kinds, int kpairs, int kkinds) {

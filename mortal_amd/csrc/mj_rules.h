@@ -196,11 +196,7 @@ template <class LN> MJDN void ev_tsumo(const LN& L, int actor, int pai) {  // up
     const bool acc = accepted(L, s);
 
     if (pf & PF_CAN_W_RIICHI) {
-        int kinds = 0;
-#pragma unroll
-        for (int t = 0; t < 34; t++)
-            if ((YAOKYUU_MASK >> t) & 1) kinds += h.get(t) > 0;
-        if (kinds >= 9) cans |= CAN_RYUKYOKU;
+        if (h.n_yao_kinds() >= 9) cans |= CAN_RYUKYOKU;
     }
     if (!acc) {
         F1(cans, s) = (uint16_t)cans;  // (update_shanten_discards asserts can_discard in the reference)

@@ -437,12 +437,12 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             req |= bal << (32 * rnd);
         }
         req &= (1ull << 34) - 1;
-        int n_tiles = 0;
-        for (int t = 0; t < 34; t++)
-            if ((req >> t) & 1) {
-                if (ln == 0) TM->tiles[n_tiles] = (u8)t;
-                n_tiles++;
-            }
+        const int n_tiles = __popcll(req);
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int t = ln + 32 * rnd;
+            if (t < 34 && ((req >> t) & 1)) TM->tiles[__popcll(req & ((1ull << t) - 1))] = (u8)t;
+        }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
 
@@ -627,8 +627,7 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
 
     // ---- D (EVAL)
     int sum_required = 0;
-    for (int t = 0; t < 34; t++)
-        if ((req >> t) & 1) sum_required += S.w.get(t);
+    for (u64 rest = req; rest; rest &= rest - 1) sum_required += S.w.get(__ffsll((long long)rest) - 1);
     sum_required &= 0xFF;
     const float* nt = X->not_tsumo[min(sum_required, 123)];
     const float my_m = ln < T ? nt[ln] : 0.f;  // not_tsumo_probs[i] of this lane's turn
@@ -694,12 +693,12 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
         // Children are consumed in the reference's order (t ascending, plain before aka draw, discard ascending) but
         // FETCHED in batches: slots of a whole super-chunk in one coalesced read, then SP_CH children's value arrays
         // per round trip — instead of two dependent gathers per child.
-        int n_tiles = 0;
-        for (int t = 0; t < 34; t++)
-            if ((req >> t) & 1) {
-                if (ln == 0) TM->tiles[n_tiles] = (u8)t;
-                n_tiles++;
-            }
+        const int n_tiles = __popcll(req);
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int t = ln + 32 * rnd;
+            if (t < 34 && ((req >> t) & 1)) TM->tiles[__popcll(req & ((1ull << t) - 1))] = (u8)t;
+        }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         int ti_next = 0, cpos = child_base;
