@@ -274,6 +274,7 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
 #define SP_CH 8      // children gathered per batch in the evaluation pass
 #define SP_CCAP 256  // children staged per super-chunk (a required tile has at most 2 x 14)
 struct SpTeam {
+    static constexpr int CH = SP_CH, CCAP = SP_CCAP;
     u64 keep[34];            // per required tile t: set of shanten-keeping discards of h + t
     u64 r2[6];               // merges of two base rows (suit pairs 01 02 03 12 13 23), see mj_algo.h sh_merge
     u64 r3[4];               // per suit s: merge of the three OTHER base rows
@@ -292,6 +293,22 @@ struct SpTeam {
             float buf[SP_CH][3][SP_T];          // values of the current batch of children, one turn per lane
             unsigned short cs[SP_CCAP];         // child slots
             unsigned short meta[SP_CCAP];       // discard tile | last-of-group << 6 | draw count << 7
+        } ev;
+    } u;
+};
+
+// Half-width team scratch for sp_eval_team<16>: evaluation only, 16 of them alias the 8 full-width scratches.
+struct SpHalf {
+    static constexpr int CH = 4, CCAP = 96;
+    u64 keep[34];
+    int coff[34];
+    u8 tiles[36];
+    union {
+        float sc[SP_L0_MAX][4];
+        struct {
+            float buf[CH][3][16];
+            unsigned short cs[CCAP];
+            unsigned short meta[CCAP];
         } ev;
     } u;
 };
@@ -399,7 +416,7 @@ __device__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u3
 //      accumulator is a register and the `next[j+1]` operands arrive by intra-team shuffles; per accumulator the
 //      additions happen in the reference's order (draw tiles ascending, aka after its plain tile, j ascending),
 //      hence bit-identical f32 sums.
-template <bool EVAL>
+template <bool EVAL>  // EVAL is always false now: the evaluation lives in sp_eval_team
 __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
     const int ln = threadIdx.x & 31;
     const int sh32 = threadIdx.x & 32;  // bit offset of this team inside the wave's 64-bit ballot
@@ -603,13 +620,29 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             }
             return;
         }
-    } else if (L > 0) {
+    }
+}
+
+// Evaluate one state (tenpai/win/ev arrays of its node) with a TEAM of TW lanes, one turn per lane.  TW = 16 whenever the
+// row has at most 16 draws left (always, except during the first go-around of a kyoku): two states then share the 32
+// lanes that one used to occupy, halving the instructions issued per state in the accumulate-bound evaluation pass.
+template <int TW, class TMT>
+__device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM, int slot, int L) {
+    const int ln = threadIdx.x & (TW - 1);
+    SpNode& node = W->node[slot];
+    const SpState S = sp_state_of(node);
+    const int T = X->T;
+    float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
+    u64 req = 0;
+    int child_base = 0;
+    u32 l0_yaku = 0;  // level 0: bit i = draw entry i has a yaku
+    if (L > 0) {
         // level > 0: the expansion pass left req / keep / child slots in the node; fetch them in one round trip
         req = node.req;
         child_base = (int)node.child_off;
 #pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int t = ln + 32 * rnd;
+        for (int rnd = 0; rnd < (34 + TW - 1) / TW; rnd++) {
+            const int t = ln + TW * rnd;
             if (t < 34) TM->keep[t] = node.keep[t];
         }
         __builtin_amdgcn_wave_barrier();
@@ -620,7 +653,7 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
         l0_yaku = __hip_atomic_load(&node.child_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // set by L2 atomics
         const float* src = reinterpret_cast<const float*>(node.keep);
         float* dst = &TM->u.sc[0][0];
-        for (int i = ln; i < SP_L0_MAX * 4; i += 32) dst[i] = src[i];
+        for (int i = ln; i < SP_L0_MAX * 4; i += TW) dst[i] = src[i];
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
     }
@@ -642,9 +675,9 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
 #pragma unroll 1
         for (int j = 0; j < T; j++) {
             // next[j + 1] comes from lane j + 1 (only used when j < T - 1)
-            const float vt = __shfl(nx_t, (j + 1) & 31, 32);
-            const float vw = __shfl(nx_w, (j + 1) & 31, 32);
-            const float ve = __shfl(nx_e, (j + 1) & 31, 32);
+            const float vt = __shfl(nx_t, (j + 1) & (TW - 1), TW);
+            const float vw = __shfl(nx_w, (j + 1) & (TW - 1), TW);
+            const float ve = __shfl(nx_e, (j + 1) & (TW - 1), TW);
             const float n = nt[j];
             if (!(lane_on && j >= ln && n != 0.f)) continue;
             const float prob = tp[j] * n / my_m;
@@ -691,12 +724,12 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
         }
     } else {
         // Children are consumed in the reference's order (t ascending, plain before aka draw, discard ascending) but
-        // FETCHED in batches: slots of a whole super-chunk in one coalesced read, then SP_CH children's value arrays
+        // FETCHED in batches: slots of a whole super-chunk in one coalesced read, then TMT::CH children's value arrays
         // per round trip — instead of two dependent gathers per child.
         const int n_tiles = __popcll(req);
 #pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int t = ln + 32 * rnd;
+        for (int rnd = 0; rnd < (34 + TW - 1) / TW; rnd++) {
+            const int t = ln + TW * rnd;
             if (t < 34 && ((req >> t) & 1)) TM->tiles[__popcll(req & ((1ull << t) - 1))] = (u8)t;
         }
         __builtin_amdgcn_wave_barrier();
@@ -710,16 +743,16 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                 const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
                 const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
                 const int c = nvar * __popcll(TM->keep[t]);
-                if (n_ch + c > SP_CCAP) break;
+                if (n_ch + c > TMT::CCAP) break;
                 if (ln == 0) TM->coff[t] = n_ch;
                 n_ch += c;
                 ti_end++;
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            for (int i = ln; i < n_ch; i += 32) TM->u.ev.cs[i] = W->pool[min(cpos + i, SP_POOL - 1)];
+            for (int i = ln; i < n_ch; i += TW) TM->u.ev.cs[i] = W->pool[min(cpos + i, SP_POOL - 1)];
             // per-child metadata, one lane per draw entry (tile, variant)
-            for (int g = ln; g < 2 * (ti_end - ti_next); g += 32) {
+            for (int g = ln; g < 2 * (ti_end - ti_next); g += TW) {
                 const int t = TM->tiles[ti_next + (g >> 1)], variant = g & 1;
                 const int cnt = S.w.get(t);
                 const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
@@ -747,10 +780,10 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             // discard_slow (calc.rs:570-637) fold state of the current draw entry
             float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
             int max_value = INT_MIN, max_tile = T_UNK;
-            for (int c0 = 0; c0 < n_ch; c0 += SP_CH) {
-                float v[SP_CH][3];
+            for (int c0 = 0; c0 < n_ch; c0 += TMT::CH) {
+                float v[TMT::CH][3];
 #pragma unroll
-                for (int q = 0; q < SP_CH; q++) {
+                for (int q = 0; q < TMT::CH; q++) {
                     v[q][0] = v[q][1] = v[q][2] = 0.f;
                     if (c0 + q < n_ch && ln < T) {
                         const int cs = TM->u.ev.cs[c0 + q];
@@ -762,15 +795,15 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
                         }
                     }
                 }
-                if (ln < SP_T) {
+                if (ln < T) {
 #pragma unroll
-                    for (int q = 0; q < SP_CH; q++) {
+                    for (int q = 0; q < TMT::CH; q++) {
                         TM->u.ev.buf[q][0][ln] = v[q][0];
                         TM->u.ev.buf[q][1][ln] = v[q][1];
                         TM->u.ev.buf[q][2][ln] = v[q][2];
                     }
                 }
-                const int nq = min(SP_CH, n_ch - c0);
+                const int nq = min(TMT::CH, n_ch - c0);
                 for (int q = 0; q < nq; q++) {
                     const int m = TM->u.ev.meta[c0 + q];
                     if (TM->u.ev.cs[c0 + q] == 0xFFFF) {
@@ -799,10 +832,11 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             ti_next = ti_end;
         }
     }
-    if (ln < SP_T) {
-        node.tenpai[ln] = ln < T ? acc_t : 0.f;
-        node.win[ln] = ln < T ? acc_w : 0.f;
-        node.ev[ln] = ln < T ? acc_e : 0.f;
+    for (int k = ln; k < SP_T; k += TW) {  // entries past T (and past the team width) are zero
+        const bool mine = k == ln && k < T;
+        node.tenpai[k] = mine ? acc_t : 0.f;
+        node.win[k] = mine ? acc_w : 0.f;
+        node.ev[k] = mine ? acc_e : 0.f;
     }
 }
 
@@ -834,7 +868,11 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ TableOne st;
     __shared__ int s_row;
-    __shared__ SpTeam s_team[SP_THREADS / 32];
+    __shared__ union SpTeams {
+        SpTeam full[SP_THREADS / 32];
+        SpHalf half[SP_THREADS / 16];
+    } s_tm;
+    SpTeam* s_team = s_tm.full;
     SpWork* W = P.work + blockIdx.x;
     const int tid = threadIdx.x;
     constexpr int O_SP = 889;  // Lay<4>::sp
@@ -1072,7 +1110,13 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
                     __syncthreads();
                 }
-                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<true>(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                if (T <= 16) {
+                    for (int i = b + (tid >> 4); i < e; i += SP_THREADS / 16)
+                        sp_eval_team<16, SpHalf>(c_mj_tables, W, &X, &s_tm.half[tid >> 4], (int)W->list[i], lv);
+                } else {
+                    for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32)
+                        sp_eval_team<32, SpTeam>(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                }
                 __syncthreads();
                 if (lv == 0) t_3 = wall_clock64();
             }
