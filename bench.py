@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU")
     ap.add_argument("--version", type=int, default=4, help="obs version (consts.rs:20-28); 4 = reference default incl. SP tables")
+    ap.add_argument("--preroll", type=int, default=1024,
+                    help="untimed cycles played before the warmup (with the cheap v3 encode) so that the tables are spread "
+                         "over all phases of a hanchan instead of all sitting in the first turns of E1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
@@ -155,6 +158,11 @@ def main():
         return act[:n], n
 
     a_prev = None
+    if args.preroll > 0:  # steady-state mix of game phases (a hanchan lasts ~600-900 cycles under the random policy)
+        pool.configure(0, version=3)
+        for i in range(-args.preroll, 0):
+            a_prev, _ = cycle(i & 0xFFFFFFFF, a_prev)
+        pool.configure(0, version=args.version)
     for i in range(args.warmup):
         a_prev, _ = cycle(i, a_prev)
     torch.cuda.synchronize()
@@ -227,7 +235,9 @@ def main():
             "decisions_per_sec": rows_all / dt,
             "config": {
                 "workload": f"{N} tables per GPU, uniform-random legal policy on device, env-step + obs(v{args.version})"
-                            f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals",
+                            f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals; "
+                            f"{args.preroll} untimed pre-roll cycles spread the tables over all game phases",
+                "preroll_cycles": args.preroll,
                 "tables_per_gpu": N,
                 "obs_version": args.version,
                 "parallelism": f"tables sharded x{world}, no data-path collective (one RCCL gather of episode returns)",

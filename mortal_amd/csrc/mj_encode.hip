@@ -95,6 +95,11 @@ struct EncDerived {  // per-row scalars computed once in phase 2
     int klen[4], kpad[4], max_kawa_len;
     int owned[4], doras_seen, rank;
     unsigned long long dora_set, dc;  // tiles with dora factor > 0; discard candidates (37-bit)
+    // unconditional-tenpai scan (phase 2a): partial min-plus merges of the hand's four table rows (mj_algo.h sh_merge)
+    unsigned long long r2[6], r3[4];   // two-suit merges, "three other suits" merges
+    unsigned long long rowt[34];       // row of h + t in suit(t)
+    unsigned long long rowd[34];       // row of h - d in suit(d) (candidate discards only)
+    unsigned long long U[34][3];       // candidate d, k-th other suit: merge(two untouched suits, rowd[d])
 };
 
 template <class LN> MJD u64 enc_discard_candidates_aka(const LN& L, int s) {  // agent_helper.rs:35-79
@@ -172,16 +177,51 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
             uncond_scan = true;
             const u64 cand = (shanten == 1 ? F1(next_shanten, p) : F1(keep_shanten, p)) & ~F1(forbidden, p);
             const u64 disc = F1(discarded, p);
+            // Is h - d + t a complete hand?  (h differs from the probed hand in at most two suits, so the probe is one
+            // table gather + one final merge step on top of merges shared by the whole scan — see mj_algo.h sh_merge —
+            // instead of a from-scratch calc_all with four gathers and two full merges.)
+            const ShBase B = sh_base(c_mj_tables, h);
+            if (tid < 6) {
+                const int a = tid < 3 ? 0 : tid < 5 ? 1 : 2, b = tid < 3 ? tid + 1 : tid < 5 ? tid - 1 : 3;
+                D->r2[tid] = sh_merge(B.row[a], B.row[b], ld3);
+            } else if (tid >= 64 && tid < 98) {
+                const int t = tid - 64, st = sh_suit(t);
+                D->rowt[t] = h.get(t) < 4 ? sh_load(c_mj_tables, st, B.key[st] + sh_pow(t)) : 0ull;
+                D->rowd[t] = ((cand >> t) & 1) ? sh_load(c_mj_tables, st, B.key[st] - sh_pow(t)) : 0ull;
+            }
+            __syncthreads();
+            if (tid < 4) {
+                const u64 pr = tid == 0 ? D->r2[3] : tid == 1 ? D->r2[1] : D->r2[0];
+                D->r3[tid] = sh_merge(pr, B.row[tid == 3 ? 2 : 3], ld3);
+            } else if (tid >= 64 && tid < 64 + 34 * 3) {
+                const int d = (tid - 64) / 3, k = (tid - 64) % 3;
+                if ((cand >> d) & 1) {
+                    const int sd = sh_suit(d), st = k + (k >= sd);  // k-th suit != sd
+                    int x = -1, y = -1;  // the two suits other than sd and st
+                    for (int q = 0; q < 4; q++)
+                        if (q != sd && q != st) { if (x < 0) x = q; else y = q; }
+                    D->U[d][k] = sh_merge(D->r2[sh_pair_idx(x, y)], D->rowd[d], ld3);
+                }
+            }
+            __syncthreads();
             for (int w = tid; w < 34 * 34; w += ENC_THREADS) {
                 const int d = w / 34, t = w % 34;
                 if (!((cand >> d) & 1)) continue;
+                const int ht = h.get(t), hd = h.get(d);
+                if (t == d || ht == 4) continue;
+                const int st = sh_suit(t), sd = sh_suit(d);
+                int fin;
+                if (sd == st) fin = sh_final(D->r3[st], sh_load(c_mj_tables, st, B.key[st] + sh_pow(t) - sh_pow(d)), ld3);
+                else fin = sh_final(D->U[d][st - (st > sd)], D->rowt[t], ld3);
+                const int yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
+                const int pairs = B.pairs - (hd == 2) + (ht == 1), kinds = B.kinds - (hd == 1) + (ht == 0);
+                const int kpairs = B.kpairs - (yd && hd == 2) + (yt && ht == 1), kkinds = B.kkinds - (yd && hd == 1) + (yt && ht == 0);
+                if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) > -1) continue;
                 Hand g = h;
                 g.dec(d);
-                if (t == d || g.get(t) == 4) continue;
                 g.inc(t);
-                if (calc_all(c_mj_tables, g, ld3) > -1) continue;
                 if ((disc >> t) & 1) atomicOr(&D->furiten[d], 1ull);
-                else if (F1(pub_seen, t) + h.get(t) < 4) {  // tiles_seen (hand before the discard) != 4
+                else if (F1(pub_seen, t) + ht < 4) {  // tiles_seen (hand before the discard) != 4
                     if (seat_has_yaku(L, p, g, t, true)) atomicOr(&D->yaku[d], 1ull);
                 }
             }

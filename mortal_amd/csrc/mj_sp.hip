@@ -313,6 +313,21 @@ struct SpHalf {
     } u;
 };
 
+struct SpQuarter {  // sp_eval_team<8>: at most 8 draws left, four states per 32 lanes
+    static constexpr int CH = 2, CCAP = 64;
+    u64 keep[34];
+    int coff[34];
+    u8 tiles[36];
+    union {
+        float sc[SP_L0_MAX][4];
+        struct {
+            float buf[CH][3][8];
+            unsigned short cs[CCAP];
+            unsigned short meta[CCAP];
+        } ev;
+    } u;
+};
+
 // Partial merges of a state's four base rows, shared by all of its probes (lanes 0..5, then 0..3 of the team).
 __device__ __forceinline__ void sp_partial_merges(SpTeam* TM, const ShBase& B, int ld3, int ln) {
     if (ln < 6) {
@@ -871,6 +886,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ union SpTeams {
         SpTeam full[SP_THREADS / 32];
         SpHalf half[SP_THREADS / 16];
+        SpQuarter quarter[SP_THREADS / 8];
     } s_tm;
     SpTeam* s_team = s_tm.full;
     SpWork* W = P.work + blockIdx.x;
@@ -1110,7 +1126,10 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
                     __syncthreads();
                 }
-                if (T <= 16) {
+                if (T <= 8) {
+                    for (int i = b + (tid >> 3); i < e; i += SP_THREADS / 8)
+                        sp_eval_team<8, SpQuarter>(c_mj_tables, W, &X, &s_tm.quarter[tid >> 3], (int)W->list[i], lv);
+                } else if (T <= 16) {
                     for (int i = b + (tid >> 4); i < e; i += SP_THREADS / 16)
                         sp_eval_team<16, SpHalf>(c_mj_tables, W, &X, &s_tm.half[tid >> 4], (int)W->list[i], lv);
                 } else {
