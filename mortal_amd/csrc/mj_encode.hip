@@ -300,6 +300,49 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
     const int max_kawa_len = D->max_kawa_len;
     const u64 dora_set = D->dora_set;
 
+    // ---- 2c. kawa entry tasks (one lane per entry of the four perspective lists): everything that does not depend on
+    // the pass is decoded once here — slots, the decay-row ownership scan, the kawa_overview occurrence index
+    bool kt_on = false;
+    int kt_r = 0, kt_i = 0, kt_len = 0, kt_t = 0, kt_td = 0, kt_nk = 0, kt_turn = 0, kt_ovk = 0;
+    u64 kt_e = 0;
+    bool kt_later_any = false, kt_later_ted = false, kt_later_rii = false;
+    float kt_decay = 0.f;
+    if (tid >= 80 && tid < 80 + 4 * MJ_KAWA_MAX + 4) {
+        const int q = tid - 80;
+        kt_r = q / (MJ_KAWA_MAX + 1);
+        kt_i = q % (MJ_KAWA_MAX + 1);
+        kt_len = klen_all[kt_r];
+        if (kt_i < kt_len) {
+            const int a = (p + kt_r) & 3, pad = D->kpad[kt_r];
+            kt_e = kt_i < pad ? 0ull : F2(kawa, a, kt_i - pad);
+            if (kt_e & KW_VALID) {
+                kt_on = true;
+                kt_t = KW_TILE(kt_e);
+                kt_td = deaka(kt_t);
+                kt_nk = KW_NKAN(kt_e);
+                for (int j = pad; j < kt_i; j++) {  // earlier entries: overview row (obs_repr.rs:299-301), v2 turn index
+                    const u64 f = F2(kawa, a, j - pad);
+                    if (!(f & KW_VALID)) continue;
+                    kt_turn++;
+                    kt_ovk += deaka(KW_TILE(f)) == kt_td;
+                }
+                if (V >= 3) {
+                    // decay rows (obs_repr.rs:223-233,259-276): sequential assigns in the reference, so the LAST entry
+                    // holding a tile (resp. the last tedashi / riichi one) owns the cell
+                    for (int j = kt_i + 1; j < kt_len; j++) {
+                        const u64 f = F2(kawa, a, j - pad);
+                        if ((f & KW_VALID) && deaka(KW_TILE(f)) == kt_td) {
+                            kt_later_any = true;
+                            kt_later_ted |= KW_TEDASHI(f) != 0;
+                            kt_later_rii |= KW_RIICHI(f) != 0;
+                        }
+                    }
+                    kt_decay = P.decay_lut[max_kawa_len - 1 - kt_i];
+                }
+            }
+        }
+    }
+
     // ---- 3. passes
     float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)row * (C * 34));
     for (int pass = 0; pass < ENC_PASSES; pass++) {
@@ -315,9 +358,10 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         };
         auto fillr = [&](int r, float v) {
             if (r >= r0 && r < r1) {
-                float* q = tile + (r - r0) * 34;
+                float2* q = reinterpret_cast<float2*>(tile + (r - r0) * 34);  // row stride 136 B: 8-byte aligned
+                const float2 vv = make_float2(v, v);
 #pragma unroll
-                for (int c = 0; c < 34; c++) q[c] = v;
+                for (int c = 0; c < 17; c++) q[c] = vv;
             }
         };
         // obs_repr.rs:59-107 for one integer feature at row base `b`
@@ -463,22 +507,6 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                     if (su & SU_DORA) fillr(b + 2, 1.f);
                 }
             }
-        } else if (tid >= 56 && tid < 60) {
-            // kawa_overview = the Some() entries of a kawa, as a tile set (obs_repr.rs:299-301)
-            const int r = tid - 56, a = (p + r) & 3, n = F1(kawa_len, a);
-            const int b = O::kawa_ov + r * 7;
-            u64 c0 = 0, c1 = 0;  // 2-bit occurrence counter per tile id, bit-sliced
-            for (int i = 0; i < n; i++) {
-                u64 e = F2(kawa, a, i);
-                if (!(e & KW_VALID)) continue;
-                int t = KW_TILE(e), td = deaka(t);
-                int k = (int)((c0 >> td) & 1) + 2 * (int)((c1 >> td) & 1);
-                put(b + k, td, 1.f);
-                u64 bt = BIT(td), carry = c0 & bt;
-                c0 ^= bt;
-                c1 ^= carry;
-                if (is_aka(t)) fillr(b + 4 + (t - T_5MR), 1.f);
-            }
         } else if (tid >= 60 && tid < 64) {
             const int r = tid - 60, a = (p + r) & 3, na = F1(ankan_n, a);
             for (int k = 0; k < na; k++) put(O::ankan + r, F2(ankan, a, k), 1.f);
@@ -497,76 +525,61 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                     if (is_aka(tl[j])) fillr(b + 4, 1.f);
                 }
             }
-        } else if (tid < 80 + 4 * MJ_KAWA_MAX + 4) {
+        } else if (kt_on) {
             // ---- D. one lane per kawa entry of the perspective lists (r = relative seat, i = index incl. start pad)
-            const int q = tid - 80;
-            const int r = q / (MJ_KAWA_MAX + 1), i = q % (MJ_KAWA_MAX + 1);
-            const int len = klen_all[r];
-            if (i < len) {
-                const int a = (p + r) & 3, pad = D->kpad[r];
-                const u64 e = i < pad ? 0ull : F2(kawa, a, i - pad);
-                if (e & KW_VALID) {
-                    const int t = KW_TILE(e), td = deaka(t);
-                    const int nk = KW_NKAN(e);
-                    // slots: first six, last eighteen
-                    int slots[2], ns = 0;
-                    if (r == 0) {
-                        if (i < 6) slots[ns++] = O::self_kawa + i * 4;
-                        if (len - 1 - i < 18) slots[ns++] = O::self_kawa + 24 + (len - 1 - i) * 4;
-                        for (int s = 0; s < ns; s++) {  // obs_repr.rs:714-734
-                            const int b = slots[s];
-                            for (int k = 0; k < nk; k++) put(b, deaka(KW_KAN(e, k)), 1.f);
-                            put(b + 1, td, 1.f);
-                            if (is_aka(t)) fillr(b + 2, 1.f);
-                            if (KW_DORA(e)) fillr(b + 3, 1.f);
-                        }
-                    } else {
-                        const int ob = O::opp0 + (r - 1) * O::opp_stride;
-                        if (i < 6) slots[ns++] = ob + i * 8;
-                        if (len - 1 - i < 18) slots[ns++] = ob + 48 + (len - 1 - i) * 8;
-                        for (int s = 0; s < ns; s++) {  // obs_repr.rs:736-773
-                            const int b = slots[s];
-                            if (KW_HAS_CP(e)) {
-                                put(b, KW_CP_MIN(e), 1.f);
-                                put(b + 1, KW_CP_MAX(e), 1.f);
-                            }
-                            for (int k = 0; k < nk; k++) put(b + 2, deaka(KW_KAN(e, k)), 1.f);
-                            put(b + 3, td, 1.f);
-                            if (is_aka(t)) fillr(b + 4, 1.f);
-                            if (KW_DORA(e)) fillr(b + 5, 1.f);
-                            if (KW_TEDASHI(e)) fillr(b + 6, 1.f);
-                            if (KW_RIICHI(e)) fillr(b + 7, 1.f);
-                        }
-                    }
-                    if (V >= 3) {
-                        // decay rows (obs_repr.rs:223-233,259-276): sequential assigns in the reference, so the LAST
-                        // entry holding a tile (resp. the last tedashi / riichi one) owns the cell.
-                        bool later_any = false, later_ted = false, later_rii = false;
-                        for (int j = i + 1; j < len; j++) {
-                            u64 f = F2(kawa, a, j - pad);
-                            if ((f & KW_VALID) && deaka(KW_TILE(f)) == td) {
-                                later_any = true;
-                                later_ted |= KW_TEDASHI(f) != 0;
-                                later_rii |= KW_RIICHI(f) != 0;
-                            }
-                        }
-                        const float v = P.decay_lut[max_kawa_len - 1 - i];
-                        if (r == 0) {
-                            if (!later_any) put(O::self_decay, td, v);
-                        } else {
-                            const int b = O::opp0 + (r - 1) * O::opp_stride + 192;
-                            if (!later_any) put(b, td, v);
-                            if (KW_TEDASHI(e) && !later_ted) put(b + 1, td, v);
-                            if (KW_RIICHI(e) && !later_rii) put(b + 2, td, v);
-                        }
-                    } else if (V == 2 && r > 0) {
-                        int turn = 0;  // index among the Some() entries (obs_repr.rs:251-258)
-                        for (int j = pad; j < i; j++) turn += (F2(kawa, a, j - pad) & KW_VALID) != 0;
-                        const int b = O::opp0 + (r - 1) * O::opp_stride + 192, rr = min(turn / 6, 2);
-                        put(b + rr, td, 1.f);
-                        if (KW_TEDASHI(e)) put(b + 3 + rr, td, 1.f);
-                    }
+            const int r = kt_r, i = kt_i, len = kt_len, t = kt_t, td = kt_td, nk = kt_nk;
+            const u64 e = kt_e;
+            {   // kawa_overview = the Some() entries of a kawa as a tile set (obs_repr.rs:299-301)
+                const int b = O::kawa_ov + r * 7;
+                put(b + (kt_ovk & 3), td, 1.f);
+                if (is_aka(t)) fillr(b + 4 + (t - T_5MR), 1.f);
+            }
+            // slots: first six, last eighteen
+            int slots[2], ns = 0;
+            if (r == 0) {
+                if (i < 6) slots[ns++] = O::self_kawa + i * 4;
+                if (len - 1 - i < 18) slots[ns++] = O::self_kawa + 24 + (len - 1 - i) * 4;
+                for (int s = 0; s < ns; s++) {  // obs_repr.rs:714-734
+                    const int b = slots[s];
+                    if (b + 4 <= r0 || b >= r1) continue;
+                    for (int k = 0; k < nk; k++) put(b, deaka(KW_KAN(e, k)), 1.f);
+                    put(b + 1, td, 1.f);
+                    if (is_aka(t)) fillr(b + 2, 1.f);
+                    if (KW_DORA(e)) fillr(b + 3, 1.f);
                 }
+            } else {
+                const int ob = O::opp0 + (r - 1) * O::opp_stride;
+                if (i < 6) slots[ns++] = ob + i * 8;
+                if (len - 1 - i < 18) slots[ns++] = ob + 48 + (len - 1 - i) * 8;
+                for (int s = 0; s < ns; s++) {  // obs_repr.rs:736-773
+                    const int b = slots[s];
+                    if (b + 8 <= r0 || b >= r1) continue;
+                    if (KW_HAS_CP(e)) {
+                        put(b, KW_CP_MIN(e), 1.f);
+                        put(b + 1, KW_CP_MAX(e), 1.f);
+                    }
+                    for (int k = 0; k < nk; k++) put(b + 2, deaka(KW_KAN(e, k)), 1.f);
+                    put(b + 3, td, 1.f);
+                    if (is_aka(t)) fillr(b + 4, 1.f);
+                    if (KW_DORA(e)) fillr(b + 5, 1.f);
+                    if (KW_TEDASHI(e)) fillr(b + 6, 1.f);
+                    if (KW_RIICHI(e)) fillr(b + 7, 1.f);
+                }
+            }
+            if (V >= 3) {
+                if (r == 0) {
+                    if (!kt_later_any) put(O::self_decay, td, kt_decay);
+                } else {
+                    const int b = O::opp0 + (r - 1) * O::opp_stride + 192;
+                    if (!kt_later_any) put(b, td, kt_decay);
+                    if (KW_TEDASHI(e) && !kt_later_ted) put(b + 1, td, kt_decay);
+                    if (KW_RIICHI(e) && !kt_later_rii) put(b + 2, td, kt_decay);
+                }
+            } else if (V == 2 && r > 0) {
+                // kt_turn = index among the Some() entries (obs_repr.rs:251-258)
+                const int b = O::opp0 + (r - 1) * O::opp_stride + 192, rr = min(kt_turn / 6, 2);
+                put(b + rr, td, 1.f);
+                if (KW_TEDASHI(e)) put(b + 3 + rr, td, 1.f);
             }
         }
         __syncthreads();
