@@ -100,6 +100,7 @@ struct EncDerived {  // per-row scalars computed once in phase 2
     unsigned long long rowt[34];       // row of h + t in suit(t)
     unsigned long long rowd[34];       // row of h - d in suit(d) (candidate discards only)
     unsigned long long U[34][3];       // candidate d, k-th other suit: merge(two untouched suits, rowd[d])
+    float rowfill[256];                // per pass: value a whole tile row is filled with, < 0 = not filled
 };
 
 template <class LN> MJD u64 enc_discard_candidates_aka(const LN& L, int s) {  // agent_helper.rs:35-79
@@ -351,18 +352,16 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int i = tid; i < TILE_ROWS * 34 / 4; i += ENC_THREADS) smem4[i] = z;
+            D->rowfill[tid] = -1.f;
         }
         __syncthreads();
         auto put = [&](int r, int c, float v) {
             if (r >= r0 && r < r1) tile[(r - r0) * 34 + c] = v;
         };
         auto fillr = [&](int r, float v) {
-            if (r >= r0 && r < r1) {
-                float2* q = reinterpret_cast<float2*>(tile + (r - r0) * 34);  // row stride 136 B: 8-byte aligned
-                const float2 vv = make_float2(v, v);
-#pragma unroll
-                for (int c = 0; c < 17; c++) q[c] = vv;
-            }
+            // `arr.fill(row, v)` is deferred: one LDS word now, merged into the row while it is streamed out (no row is
+            // both filled and assigned cell-wise in any obs version)
+            if (r >= r0 && r < r1) D->rowfill[r - r0] = v;
         };
         // obs_repr.rs:59-107 for one integer feature at row base `b`
         auto int_encode = [&](int b, u32 n_in, int cap, bool rescale, int rbf, const float* lut) {
@@ -596,10 +595,18 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
             const int shift = (int)((reinterpret_cast<uintptr_t>(d4) >> 4) & 7);
             for (int i = tid - shift; i < n4; i += ENC_THREADS) {
                 if (i < 0) continue;
+                vfloat4 v = s4[i];
+                const int ra = (4 * i) / 34, off = 4 * i - 34 * ra;  // a 16-byte chunk touches at most two rows
+                const float f0 = D->rowfill[ra], f1 = D->rowfill[min(ra + 1, TILE_ROWS - 1)];
+                const float fa = f0, fb = off + 1 < 34 ? f0 : f1, fc = off + 2 < 34 ? f0 : f1, fd = off + 3 < 34 ? f0 : f1;
+                if (fa >= 0.f) v.x = fa;
+                if (fb >= 0.f) v.y = fb;
+                if (fc >= 0.f) v.z = fc;
+                if (fd >= 0.f) v.w = fd;
 #if ENC_NT
-                __builtin_nontemporal_store(s4[i], d4 + i);
+                __builtin_nontemporal_store(v, d4 + i);
 #else
-                d4[i] = s4[i];
+                d4[i] = v;
 #endif
             }
         }
