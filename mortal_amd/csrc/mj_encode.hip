@@ -351,7 +351,12 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         if (r0 >= C) break;
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = tid; i < TILE_ROWS * 34 / 4; i += ENC_THREADS) smem4[i] = z;
+            constexpr int N4 = TILE_ROWS * 34 / 4;
+#pragma unroll
+            for (int k = 0; k < (N4 + ENC_THREADS - 1) / ENC_THREADS; k++) {
+                const int i = tid + k * ENC_THREADS;
+                if (i < N4) smem4[i] = z;
+            }
             D->rowfill[tid] = -1.f;
         }
         __syncthreads();
@@ -593,8 +598,11 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
             // no cache line is written in two halves by two different waves (PMC WRITE_SIZE showed 1.37x the
             // algorithmic bytes without this).
             const int shift = (int)((reinterpret_cast<uintptr_t>(d4) >> 4) & 7);
-            for (int i = tid - shift; i < n4; i += ENC_THREADS) {
-                if (i < 0) continue;
+            constexpr int N4MAX = TILE_ROWS * 34 / 4;
+#pragma unroll
+            for (int k = 0; k < (N4MAX + 7 + ENC_THREADS - 1) / ENC_THREADS; k++) {
+                const int i = tid - shift + k * ENC_THREADS;
+                if (i < 0 || i >= n4) continue;
                 vfloat4 v = s4[i];
                 const int ra = (4 * i) / 34, off = 4 * i - 34 * ra;  // a 16-byte chunk touches at most two rows
                 const float f0 = D->rowfill[ra], f1 = D->rowfill[min(ra + 1, TILE_ROWS - 1)];
