@@ -53,7 +53,7 @@ def main():
             w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value_KiB"])
             for r in rows:
                 w.writerow([r["Kernel_Name"][:60], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
-        enc = [r for r in rows if "mj_k_encode" in r["Kernel_Name"]]
+        enc = [r for r in rows if "mj_k_encode<4>" in r["Kernel_Name"]]  # the timed v4 launches, not the v3 pre-roll
         per = [float(r["Counter_Value"]) * 1024 * scale / (int(r["Grid_Size"]) / int(r["Workgroup_Size"])) for r in enc]
         out[f"{key}_bytes_per_decision"] = sum(per) / len(per)
         out[f"{key}_dispatches"] = len(per)
