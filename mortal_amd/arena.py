@@ -122,6 +122,9 @@ class BatchRunner:
         code, tbl = pool.first_error()
         if code:
             raise MortalAmdError(f"table {tbl}: illegal action or rule violation (error code {code})")
+        if pool.counters()["sp_overflow"]:
+            raise MortalAmdError("obs v4: a decision's single-player state graph exceeded the device scratch capacity "
+                                 "(SP_CAP in mortal_amd/csrc/mj_sp.hip); its SP planes would be incomplete")
         scores, done = pool.results()
         if not (done == 1).all():
             raise MortalAmdError("some games did not finish")

@@ -335,6 +335,8 @@ class GameplayLoader:
             code, tbl = pool.first_error()
             if code:
                 raise ValueError(f"log {tbl}: the event stream is not a legal game (error code {code})")
+            if pool.counters()["sp_overflow"]:
+                raise RuntimeError("obs v4: a sample's single-player state graph exceeded the device scratch capacity")
         finally:
             pool.close()
         C = OBS_ROWS[self.version]
