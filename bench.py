@@ -115,6 +115,10 @@ def main():
     ap.add_argument("--preroll", type=int, default=1024,
                     help="untimed cycles played before the warmup (with the cheap v3 encode) so that the tables are spread "
                          "over all phases of a hanchan instead of all sitting in the first turns of E1")
+    ap.add_argument("--policy", choices=["random", "brain"], default="random",
+                    help="random = uniform-random legal action on device (BASELINE configs[1]); brain = greedy argmax of a "
+                         "random-init network of the reference's Brain/DQN architecture (192 ch x 40 blocks, bf16 autocast), "
+                         "consuming the encoded batch in place (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
@@ -151,9 +155,19 @@ def main():
     masks = torch.empty((2 * N, 46), dtype=torch.bool, device=dev)
     act = torch.empty(2 * N, dtype=torch.int32, device=dev)
 
+    engine = None
+    if args.policy == "brain":
+        from mortal_amd.policy import DeviceEngine, PolicyNet
+
+        torch.manual_seed(0)
+        engine = DeviceEngine(PolicyNet(version=args.version if args.version >= 2 else 2), args.version, dev, enable_amp=True)
+    use_net = [False]
+
     def cycle(i, a_prev):
         n, _ = pool.step(a_prev, None)
         pool.encode(0, obs, masks)
+        if use_net[0]:
+            return engine.react_batch_device(obs[:n], masks[:n]), n
         pool.random_policy(0, masks, 0x9E3779B97F4A7C15, i, act)
         return act[:n], n
 
@@ -163,6 +177,7 @@ def main():
         for i in range(-args.preroll, 0):
             a_prev, _ = cycle(i & 0xFFFFFFFF, a_prev)
         pool.configure(0, version=args.version)
+    use_net[0] = engine is not None
     for i in range(args.warmup):
         a_prev, _ = cycle(i, a_prev)
     torch.cuda.synchronize()
@@ -234,10 +249,14 @@ def main():
             "games_per_sec": games / dt,
             "decisions_per_sec": rows_all / dt,
             "config": {
-                "workload": f"{N} tables per GPU, uniform-random legal policy on device, env-step + obs(v{args.version})"
+                "workload": f"{N} tables per GPU, "
+                            + ("uniform-random legal policy on device" if engine is None else
+                               "greedy policy of a random-init Brain/DQN-shaped net (192x40, bf16) on the same device")
+                            + f", env-step + obs(v{args.version})"
                             f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals; "
                             f"{args.preroll} untimed pre-roll cycles spread the tables over all game phases",
                 "preroll_cycles": args.preroll,
+                "policy": args.policy,
                 "tables_per_gpu": N,
                 "obs_version": args.version,
                 "parallelism": f"tables sharded x{world}, no data-path collective (one RCCL gather of episode returns)",
@@ -264,7 +283,7 @@ def main():
             "kernel_ms_per_step": {"mj_k_encode": enc_ms / args.steps, "mj_k_sp": sp_ms / args.steps,
                                    "everything_else": (dt * 1e3 - enc_ms - sp_ms) / args.steps},
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
+        if not args.no_cpu_baseline and world == 1 and args.policy == "random":  # reported at N=1 only (rank 0)
             line["cpu_baseline"] = cpu_baseline(args.version, args.cpu_budget, args.cpu_tables)
         print(json.dumps(line))
     pool.close()
