@@ -1084,7 +1084,9 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
         }
         __syncthreads();
 
-        const bool with_probs = cur_shanten <= 3;
+        // fewer draws left than the shanten number: tenpai / win / EV are exactly zero for every candidate (reaching tenpai
+        // takes cur_shanten draws), so the state graph need not be built at all
+        const bool with_probs = cur_shanten <= 3 && X.T >= cur_shanten;
         t_1 = wall_clock64();
         t_2 = t_3 = t_4 = t_1;
         if (with_probs) {
