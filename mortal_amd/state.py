@@ -73,6 +73,82 @@ class PlayerState:
             raise MortalAmdError(f"rule violation while applying {ev} (error code {code})")
         return self.last_cans
 
+    # ---- validate_reaction (state/action.rs:91-228)
+    def validate_reaction(self, mjai_json):
+        """Raises ValueError when `action` is not a valid reaction to the current state (same checks and messages)."""
+        ev = json.loads(mjai_json) if isinstance(mjai_json, str) else mjai_json
+        cans = self.last_cans
+        t = ev["type"]
+
+        def ensure(cond, msg):
+            if not cond:
+                raise ValueError(msg)
+
+        if t == "ryukyoku":
+            return ensure(cans.can_ryukyoku, "cannot ryukyoku")
+        if t == "none":
+            return None
+        ensure("actor" in ev, "action does not have actor and is not ryukyoku")
+        ensure(ev["actor"] == self.player_id, f"actor is {ev['actor']}, not self ({self.player_id})")
+        tid = mjai_log.TILE_ID
+        deaka = lambda x: {34: 4, 35: 13, 36: 22}.get(x, x)
+        hand, akas = self._hand(), self.akas_in_hand
+        tbl = self._table()
+        raw = int(tbl["last_kawa_tile"][self.player_id])
+        last_kawa = None if raw >= 38 else raw
+        raw = int(tbl["last_self_tsumo"][self.player_id])
+        last_tsumo = None if raw >= 38 else raw
+
+        def in_hand(tiles):
+            for name in tiles:
+                x = tid[name]
+                ensure(hand[deaka(x)] > 0, f"{name} is not in hand")
+                if x >= 34:
+                    ensure(akas[x - 34], f"{name} is not in hand")
+
+        if t == "dahai":
+            ensure(cans.can_discard, "cannot discard")
+            in_hand([ev["pai"]])
+            if ev["tsumogiri"]:
+                ensure(last_tsumo is not None, "tsumogiri but the player has not dealt any tile yet")
+                ensure(last_tsumo == tid[ev["pai"]], "cannot tsumogiri")
+        elif t == "reach":
+            ensure(cans.can_riichi, "cannot riichi")
+        elif t == "chi":
+            ensure((ev["target"] + 1) % 4 == ev["actor"], "chi from non-kamicha")
+            ensure(last_kawa is not None and last_kawa == tid[ev["pai"]], "chi target is not the last kawa tile")
+            in_hand(ev["consumed"])
+            a, b = sorted(deaka(tid[x]) for x in ev["consumed"])
+            pai = deaka(tid[ev["pai"]])
+            if pai < a:
+                ensure(cans.can_chi_low, "cannot chi low")
+            elif pai < b:
+                ensure(cans.can_chi_mid, "cannot chi mid")
+            else:
+                ensure(cans.can_chi_high, "cannot chi high")
+        elif t in ("pon", "daiminkan"):
+            ensure(ev["target"] != ev["actor"], f"{t} from itself")
+            ensure(last_kawa is not None and last_kawa == tid[ev["pai"]], f"{t} target is not the last kawa tile")
+            ensure(cans.can_pon if t == "pon" else cans.can_daiminkan, f"cannot {t}")
+            in_hand(ev["consumed"])
+        elif t == "kakan":
+            ensure(cans.can_kakan, "cannot kakan")
+            ensure(deaka(tid[ev["pai"]]) in self.kakan_candidates, f"cannot kakan {ev['pai']}")
+            in_hand([ev["pai"]])
+        elif t == "ankan":
+            ensure(cans.can_ankan, "cannot ankan")
+            tile = deaka(tid[ev["consumed"][0]])
+            ensure(tile in self.ankan_candidates, f"cannot ankan {mjai_log.TILE_NAMES[tile]}")
+            in_hand(ev["consumed"])
+        elif t == "hora":
+            if ev["target"] == self.player_id:
+                ensure(cans.can_tsumo_agari, "cannot tsumo agari")
+            else:
+                ensure(cans.can_ron_agari, "cannot ron agari")
+        else:
+            raise ValueError(f"unexpected action {ev!r}")
+        return None
+
     def _table(self):
         if self._cache is None:
             self._cache = self._pool.debug_table(0)

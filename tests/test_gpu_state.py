@@ -103,3 +103,41 @@ def test_device_player_state_obs_matches_oracle(oracle):
                 assert (og.view(np.uint32) == oo.view(np.uint32)).all(), (ev, v)
                 checked += 1
     assert checked >= 40
+
+
+def test_device_player_state_validate_reaction(oracle):
+    """validate_reaction (state/action.rs:91-228) agrees with the oracle's on every logged reaction of a kyoku and on a
+    set of illegal ones."""
+    from libriichi.state import PlayerState
+
+    sc = T.SCEN["discard_candidates_with_unconditional_tenpai"]
+    evs = [s["ev"] for s in sc["steps"] if "ev" in s]
+    pid = next(s["new"] for s in sc["steps"] if "new" in s)
+    dev, ora = PlayerState(pid), oracle.PlayerState(pid)
+    probes = [{"type": "dahai", "actor": pid, "pai": "1m", "tsumogiri": False}, {"type": "dahai", "actor": pid, "pai": "C", "tsumogiri": True},
+              {"type": "reach", "actor": pid}, {"type": "hora", "actor": pid, "target": pid}, {"type": "hora", "actor": pid, "target": (pid + 1) % 4},
+              {"type": "pon", "actor": pid, "target": (pid + 2) % 4, "pai": "E", "consumed": ["E", "E"]},
+              {"type": "chi", "actor": pid, "target": (pid + 3) % 4, "pai": "3s", "consumed": ["4s", "5s"]},
+              {"type": "ankan", "actor": pid, "consumed": ["9m", "9m", "9m", "9m"]}, {"type": "ryukyoku"},
+              {"type": "dahai", "actor": (pid + 1) % 4, "pai": "1m", "tsumogiri": False}]
+    agree = rejected = 0
+    for k, ev in enumerate(evs):
+        dev.update(ev)
+        ora.update(ev)
+        cand = list(probes)
+        if k + 1 < len(evs) and evs[k + 1].get("actor") == pid and evs[k + 1]["type"] in ("dahai", "chi", "pon", "reach"):
+            cand.append(evs[k + 1])
+        for a in cand:
+            ok_dev = ok_ora = True
+            try:
+                dev.validate_reaction(a)
+            except ValueError:
+                ok_dev = False
+            try:
+                ora.validate_reaction(a)
+            except oracle.OracleError:
+                ok_ora = False
+            assert ok_dev == ok_ora, (ev, a)
+            agree += 1
+            rejected += not ok_dev
+    assert agree > 500 and 0 < rejected < agree
