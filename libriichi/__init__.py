@@ -4,7 +4,7 @@ the MI355X table pool (mortal_amd).  Put the repository root on PYTHONPATH and t
 
 Implemented: `libriichi.consts`, `libriichi.arena` (OneVsThree/TwoVsTwo `py_vs_py`, incl. `log_dir` mjai dumps),
 `libriichi.stat.Stat`, `libriichi.dataset` (GameplayLoader with oracle=False, Gameplay, Grp), `libriichi.state.PlayerState`
-(update / encode_obs / getters).  Present as a stub that raises NotImplementedError on use: `libriichi.mjai`.
+(update / validate_reaction / encode_obs / getters), `libriichi.mjai.Bot`.
 """
 import importlib as _il
 import sys as _sys

@@ -1,5 +1,5 @@
-"""libriichi.mjai — a "next" row of the hot-path scope table; not built this round."""
+"""libriichi.mjai (reference libriichi/src/mjai/): `Bot(engine, player_id).react(line, can_act=True)` — see
+mortal_amd/mjai.py."""
+from mortal_amd.mjai import Bot  # noqa: F401
 
-
-def __getattr__(name):
-    raise NotImplementedError(f"libriichi.mjai.{name} is not implemented yet (SURVEY.md §8(f))")
+__all__ = ["Bot"]

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void mj_k_mark_row(TableBlock* blocks, int n_ta
 }
 // queries / pokes: out int32[8]
 enum { MJ_Q_AGARI_POINTS = 0, MJ_Q_RULE_BASED_AGARI = 1, MJ_Q_REAL_TIME_SHANTEN = 2, MJ_Q_DORAS_OWNED = 3,
-       MJ_Q_ADD_DORA = 4, MJ_Q_SET_SCORES = 5 };
+       MJ_Q_ADD_DORA = 4, MJ_Q_SET_SCORES = 5, MJ_Q_SCENE = 6, MJ_Q_DECODE_ACTION = 7 };
 __global__ void mj_k_query(TableBlock* blocks, int table, int seat, int what, const int32_t* args, int32_t* out) {
     Lane L = {blocks + (table >> 6), table & 63, &c_mj_tables};
     const int p = seat;
@@ -370,5 +370,43 @@ __global__ void mj_k_query(TableBlock* blocks, int table, int seat, int what, co
         case MJ_Q_SET_SCORES:
             for (int i = 0; i < 4; i++) F1(scores, i) = args[i];
             break;
+        case MJ_Q_SCENE: {  // agent/mortal.rs:200-250 set_scene: args[0] = enable_quick_eval -> quick discard (raw id) or -1, need_kan_select
+            const u32 cans = F1(cans, p);
+            out[0] = -1;
+            out[1] = 0;
+            if (args[0] && (cans & CAN_DISCARD) && !(cans & (CAN_RIICHI | CAN_TSUMO_AGARI | CAN_ANKAN | CAN_KAKAN | CAN_RYUKYOKU))) {
+                const u64 dc = discard_candidates_aka(L, p);
+                if (__popcll(dc) == 1) out[0] = __ffsll((long long)dc) - 1;
+            }
+            if (cans & (CAN_ANKAN | CAN_KAKAN))
+                out[1] = !args[0] || __popcll(F1(ankan_cand, p)) + __popcll(F1(kakan_cand, p)) > 1;
+            out[2] = F1(last_self_tsumo, p);
+            break;
+        }
+        case MJ_Q_DECODE_ACTION: {  // agent/mortal.rs:338-573: args = action id, kan-select tile or -1 -> event word (LG_*), error
+            const Reaction r = decode_action(L, p, args[0], args[1]);
+            unsigned long long w = 0;
+            switch (r.type) {
+                case RX_DAHAI: w = LG_WORD(LG_DAHAI, r.actor, 0, r.pai, 0, 0, 0, 0, r.tsumogiri); break;
+                case RX_CHI: w = LG_WORD(LG_CHI, r.actor, r.target, r.pai, r.c0, r.c1, 0, 0, 0); break;
+                case RX_PON: w = LG_WORD(LG_PON, r.actor, r.target, r.pai, r.c0, r.c1, 0, 0, 0); break;
+                case RX_DAIMINKAN: w = LG_WORD(LG_DAIMINKAN, r.actor, r.target, r.pai, r.c0, r.c1, r.c2, 0, 0); break;
+                case RX_ANKAN: w = LG_WORD(LG_ANKAN, r.actor, 0, 0, akaize(r.pai), r.pai, r.pai, r.pai, 0); break;
+                case RX_KAKAN: {
+                    const int t = deaka(r.pai);
+                    w = LG_WORD(LG_KAKAN, r.actor, 0, r.pai, is_aka(r.pai) ? t : akaize(t), t, t, 0, 0);
+                    break;
+                }
+                case RX_REACH: w = LG_WORD(LG_REACH, r.actor, 0, 0, 0, 0, 0, 0, 0); break;
+                case RX_HORA: w = LG_WORD(LG_HORA, r.actor, r.target, 0, 0, 0, 0, 0, 0); break;
+                case RX_RYUKYOKU: w = LG_WORD(LG_RYUKYOKU, 0, 0, 0, 0, 0, 0, 0, 0); break;
+                default: w = 0; break;  // pass
+            }
+            out[0] = (int32_t)(uint32_t)w;
+            out[1] = (int32_t)(uint32_t)(w >> 32);
+            out[2] = F(err);
+            F(err) = MJ_OK;  // an illegal action is reported to the caller, the table stays usable
+            break;
+        }
     }
 }

@@ -141,3 +141,62 @@ def test_device_player_state_validate_reaction(oracle):
             agree += 1
             rejected += not ok_dev
     assert agree > 500 and 0 < rejected < agree
+
+
+def test_bot_replays_a_game_like_the_oracle_agent(oracle):
+    """libriichi.mjai.Bot (mjai/bot.rs): fed the example game from seat 1's point of view with an engine that always
+    picks a fixed legal action, the reactions equal the oracle's agent glue (scene + action decode, agent/mortal.rs)."""
+    import json
+    import os
+
+    from libriichi.mjai import Bot
+
+    pid = 1
+    events = [json.loads(l) for l in open(os.path.join(os.path.dirname(__file__), "golden", "example_game.jsonl"))]
+
+    class Eng:
+        engine_type, name, is_oracle, version = "mortal", "probe", False, 3
+        enable_quick_eval, enable_rule_based_agari_guard = True, False
+
+        def react_batch(self, obs, masks, invisible_obs):
+            m = np.stack(masks)
+            acts = [int(np.flatnonzero(r)[len(np.flatnonzero(r)) // 2]) for r in m]  # a legal action in the middle
+            q = np.where(m, 0.0, -np.inf).astype(np.float32)
+            return acts, q.tolist(), m.tolist(), [True] * len(acts)
+
+    def hide(ev):  # the log as seat `pid` sees it
+        ev = dict(ev)
+        if ev["type"] == "start_kyoku":
+            ev["tehais"] = [h if s == pid else ["?"] * 13 for s, h in enumerate(ev["tehais"])]
+        if ev["type"] == "tsumo" and ev["actor"] != pid:
+            ev["pai"] = "?"
+        return ev
+
+    bot, ora, eng = Bot(Eng(), pid), oracle.PlayerState(pid), Eng()
+    n = 0
+    for ev in events:
+        if ev["type"] in ("start_game", "end_game"):
+            assert bot.react(json.dumps(ev)) is None
+            continue
+        ev = hide(ev)
+        got = bot.react(json.dumps(ev))
+        cans = ora.update(ev)
+        sc = ora.scene(True)
+        if not sc["can_act"]:
+            assert got is None
+            continue
+        got = json.loads(got)
+        got.pop("meta", None)
+        if sc["quick_eval"]:
+            want = {"type": "dahai", "actor": pid, "pai": oracle.TILE_NAMES[sc["quick_pai"]], "tsumogiri": sc["quick_tsumogiri"]}
+        else:
+            rows = []
+            if sc["need_kan_select"]:
+                rows.append(ora.encode_obs(3, True)[1])
+            rows.append(ora.encode_obs(3, False)[1])
+            acts, _, _, _ = eng.react_batch(None, rows, None)
+            want = ora.decode_action(acts[-1], acts[0] if sc["need_kan_select"] else -1)
+            want = {k: v for k, v in want.items() if k not in ("deltas", "ura_markers")}
+        assert got == want, (ev, got, want)
+        n += 1
+    assert n >= 30

@@ -43,8 +43,7 @@ def test_libriichi_surface():
     assert hasattr(libriichi.stat.Stat, "from_dir") and hasattr(libriichi.stat.Stat, "avg_pt")
     assert hasattr(libriichi.dataset.GameplayLoader, "load_gz_log_files") and hasattr(libriichi.dataset.Grp, "load_log")
     assert "oracle: true" in repr(libriichi.dataset.GameplayLoader(4)).lower()  # oracle=True is the reference's default
-    with pytest.raises(NotImplementedError):
-        libriichi.mjai.Bot
+    assert hasattr(libriichi.mjai.Bot, "react")
 
 
 def test_stack_proxy_is_zero_copy():
