@@ -887,6 +887,15 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
         SpTeam full[SP_THREADS / 32];
         SpHalf half[SP_THREADS / 16];
         SpQuarter quarter[SP_THREADS / 8];
+        struct {                 // row set-up (candidates + their required tiles), before any team runs
+            u64 r2[6], r3[4];    // partial merges of the root hand's rows (mj_algo.h sh_merge)
+            u64 rowt[34];        // row of root + t in suit(t)
+            u64 rowd[34];        // row of root - d in suit(d)
+            u64 U[34][3];        // discard d, k-th other suit: merge(two untouched suits, rowd[d])
+            int sh_d[34];        // shanten of root - d (only for tiles in hand)
+            u64 req[SP_MAX_CAND];
+            int nreq[SP_MAX_CAND];
+        } setup;
     } s_tm;
     SpTeam* s_team = s_tm.full;
     SpWork* W = P.work + blockIdx.x;
@@ -1045,16 +1054,49 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
         }
         __syncthreads();
 
-        // ---- candidates: analyze_discard / analyze_draw (+ *_simple for shanten > 3)  (calc.rs:205-312)
+        // ---- candidates: analyze_discard / analyze_draw (+ *_simple for shanten > 3)  (calc.rs:205-312).
+        // All shanten numbers here are of hands one or two tiles away from the root hand, so they are incremental probes
+        // (one table gather + one final merge step) on partial merges shared by the whole row, spread over the workgroup.
+        auto& SU = s_tm.setup;
+        const ShBase RB = sh_base(c_mj_tables, root.h);
+        const u64 root_mask = root.h.nonzero_mask();
+        if (tid < 6) {
+            const int a = tid < 3 ? 0 : tid < 5 ? 1 : 2, b = tid < 3 ? tid + 1 : tid < 5 ? tid - 1 : 3;
+            SU.r2[tid] = sh_merge(RB.row[a], RB.row[b], ld3);
+        } else if (tid >= 64 && tid < 98) {
+            const int t = tid - 64, st = sh_suit(t);
+            SU.rowt[t] = root.w.get(t) > 0 ? sh_load(c_mj_tables, st, RB.key[st] + sh_pow(t)) : 0ull;
+            SU.rowd[t] = (can_discard && ((root_mask >> t) & 1)) ? sh_load(c_mj_tables, st, RB.key[st] - sh_pow(t)) : 0ull;
+        }
+        if (tid < SP_MAX_CAND) { SU.req[tid] = 0; SU.nreq[tid] = 0; }
+        __syncthreads();
+        if (tid < 4) {
+            const u64 pr = tid == 0 ? SU.r2[3] : tid == 1 ? SU.r2[1] : SU.r2[0];
+            SU.r3[tid] = sh_merge(pr, RB.row[tid == 3 ? 2 : 3], ld3);
+        } else if (can_discard && tid >= 64 && tid < 64 + 34 * 3) {
+            const int d = (tid - 64) / 3, k = (tid - 64) % 3;
+            if ((root_mask >> d) & 1) {
+                const int sd = sh_suit(d), st = k + (k >= sd);
+                int x = -1, y = -1;
+                for (int q = 0; q < 4; q++)
+                    if (q != sd && q != st) { if (x < 0) x = q; else y = q; }
+                SU.U[d][k] = sh_merge(SU.r2[sh_pair_idx(x, y)], SU.rowd[d], ld3);
+            }
+        }
+        __syncthreads();
+        if (can_discard && tid < 34 && ((root_mask >> tid) & 1)) {  // shanten of root - d
+            const int d = tid, sd = sh_suit(d), hd = root.h.get(d), yd = (int)((YAOKYUU_MASK >> d) & 1);
+            SU.sh_d[d] = sh_finish(sh_final(SU.r3[sd], SU.rowd[d], ld3), ld3, RB.pairs - (hd == 2), RB.kinds - (hd == 1),
+                                   RB.kpairs - (yd && hd == 2), RB.kkinds - (yd && hd == 1));
+        }
+        __syncthreads();
         if (tid == 0) {
             int n = 0;
             if (can_discard) {
                 for (int d = 0; d < 34; d++) {
                     int c = root.h.get(d);
                     if (c == 0) continue;
-                    Hand g = root.h;
-                    g.dec(d);
-                    int diff = calc_all(c_mj_tables, g, ld3) - cur_shanten;
+                    int diff = SU.sh_d[d] - cur_shanten;
                     int dt = d;
                     if (d == T_5M && (root.akas & 1) && c == 1) dt = T_5MR;
                     else if (d == T_5P && (root.akas & 2) && c == 1) dt = T_5PR;
@@ -1073,12 +1115,39 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
         }
         __syncthreads();
         const int n_cand = X.n_cand;
+        // required tiles of every candidate (state.rs:176-200): draws t that lower the shanten number of root - d (+ t)
+        for (int w = tid; w < n_cand * 34; w += SP_THREADS) {
+            const int c = w / 34, t = w % 34;
+            const int wc = root.w.get(t);  // the discard does not change the wall
+            if (wc == 0) continue;
+            const int st = sh_suit(t), ht = root.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1);
+            int sh_base_c, sh_new;
+            if (can_discard) {
+                const int d = deaka(X.cand_tile[c]), sd = sh_suit(d), hd = root.h.get(d), yd = (int)((YAOKYUU_MASK >> d) & 1);
+                sh_base_c = SU.sh_d[d];
+                if (t == d) {
+                    sh_new = calc_all(c_mj_tables, root.h, ld3);  // root - d + d
+                } else {
+                    int fin;
+                    if (sd == st) fin = sh_final(SU.r3[st], sh_load(c_mj_tables, st, RB.key[st] + sh_pow(t) - sh_pow(d)), ld3);
+                    else fin = sh_final(SU.U[d][st - (st > sd)], SU.rowt[t], ld3);
+                    sh_new = sh_finish(fin, ld3, RB.pairs - (hd == 2) + (ht == 1), RB.kinds - (hd == 1) + (ht == 0),
+                                       RB.kpairs - (yd && hd == 2) + (yt && ht == 1), RB.kkinds - (yd && hd == 1) + (yt && ht == 0));
+                }
+            } else {
+                sh_base_c = calc_all(c_mj_tables, root.h, ld3);
+                sh_new = sh_finish(sh_final(SU.r3[st], SU.rowt[t], ld3), ld3, RB.pairs + (ht == 1), RB.kinds + (ht == 0),
+                                   RB.kpairs + (yt && ht == 1), RB.kkinds + (yt && ht == 0));
+            }
+            if (sh_new < sh_base_c) {
+                atomicOr((unsigned long long*)&SU.req[c], 1ull << t);
+                atomicAdd(&SU.nreq[c], wc);
+            }
+        }
+        __syncthreads();
         if (tid < n_cand) {
-            SpState s = root;
-            if (can_discard) sp_discard(s, X.cand_tile[tid]);
-            int num;
-            X.cand_req[tid] = sp_required_tiles(c_mj_tables, s, ld3, num);
-            X.cand_nreq[tid] = num;
+            X.cand_req[tid] = SU.req[tid];
+            X.cand_nreq[tid] = SU.nreq[tid] & 0xFF;
             X.cand_slot[tid] = -1;
             X.cand_tp0[tid] = X.cand_wp0[tid] = X.cand_ev0[tid] = 0.f;
         }
