@@ -84,3 +84,50 @@ def test_decode_events_word_format():
         {"type": "hora", "actor": 2, "target": 0, "deltas": [8000, -8000, 0, 0], "ura_markers": ["8m", "9m"]},
         {"type": "ryukyoku", "deltas": [1500, -1500, 1500, -1500]}, {"type": "end_kyoku"}]
     assert list(ev[0].keys()) == ["type", "bakaze", "dora_marker", "kyoku", "honba", "kyotaku", "oya", "scores", "tehais"]
+
+
+def test_encode_decode_roundtrip_and_augment():
+    """encode_events / decode_events are inverse on the example game (incl. the replay-only wall payload), and the suit
+    augmentation (Tile::augment, tile.rs:154-167) is an involution that swaps manzu and pinzu only."""
+    lines = [json.loads(l) for l in open(GOLDEN)]
+    events = lines[1:-1]
+    words = mjai_log.encode_events(lines)  # start_game / end_game are skipped
+    assert mjai_log.decode_events(words) == events
+    aug = mjai_log.decode_events(mjai_log.encode_events(events, augmented=True))
+    assert aug != events and mjai_log.decode_events(mjai_log.encode_events(aug, augmented=True)) == events
+    swap = {"m": "p", "p": "m"}
+    t0, t1 = events[0]["tehais"][0][0], aug[0]["tehais"][0][0]
+    assert t1 == (t0[0] + swap.get(t0[1], t0[1]) + t0[2:] if len(t0) > 1 and t0[1] in "mps" else t0)
+    for t in range(37):
+        assert mjai_log.augment_tile_id(mjai_log.augment_tile_id(t)) == t
+    assert [mjai_log.augment_tile_id(t) for t in (0, 9, 18, 27, 34, 35, 36)] == [9, 0, 18, 27, 35, 34, 36]
+
+
+def test_walls_from_events_are_consistent():
+    """GameplayLoader's wall reconstruction for oracle=True without a seed (dataset/invisible.rs:73-149): every kyoku's wall
+    is a permutation of the 136 tiles, starts with the logged haipai, replays the logged draws / dora / ura in order."""
+    from mortal_amd.dataset import GameplayLoader
+
+    events = [json.loads(l) for l in open(GOLDEN)]
+    walls = GameplayLoader._walls_from_events(events, False, np.random.default_rng(0))
+    assert len(walls) == 3
+    full = sorted([t for t in range(34) for _ in range(4)])
+    deaka = {34: 4, 35: 13, 36: 22}
+    tid = mjai_log.TILE_ID
+    kyokus = []
+    for e in events:
+        if e["type"] == "start_kyoku":
+            kyokus.append([e])
+        elif kyokus and e["type"] != "end_game":
+            kyokus[-1].append(e)
+    for wall, kev in zip(walls, kyokus):
+        assert sorted(deaka.get(t, t) for t in wall) == full and sorted(t for t in wall if t >= 34) == [34, 35, 36]
+        assert wall[:52] == [tid[x] for h in kev[0]["tehais"] for x in h]
+        assert wall[60] == tid[kev[0]["dora_marker"]]
+        draws = [tid[e["pai"]] for e in kev if e["type"] == "tsumo"]  # no kans in this game: all from the yama
+        assert [wall[66 + 69 - k] for k in range(len(draws))] == draws
+        ura = next(e["ura_markers"] for e in kev if e["type"] == "hora")
+        assert [wall[61 + k] for k in range(len(ura))] == [tid[x] for x in ura]
+    # the words carry the wall and still decode to the same events
+    w = mjai_log.encode_events(events, walls=walls)
+    assert mjai_log.decode_events(w) == events[1:-1]
