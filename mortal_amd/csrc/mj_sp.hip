@@ -3,17 +3,19 @@
 // Reference: PlayerState::single_player_tables (state/agent_helper.rs:509-593) -> SPCalculator::calc
 // (algo/sp/calc.rs:84-133, production flags: no tegawari, no shanten-down, maximise EV, sorted) and the encoder block
 // obs_repr.rs:564-692.  The reference is a memoised depth-first recursion (draw -> discard -> draw ...) over hand
-// states with order-sensitive f32 sums.  On the GPU the same values are produced LEVEL-SYNCHRONOUSLY by one workgroup
-// per decision:
-//   expand   : for shanten level L = s .. 1, every 3n+1 state of level L (one thread per state) enumerates its
-//              children  (required draw t, shanten-keeping discard d)  and inserts them into a per-workgroup hash set
-//              (64-bit tag claimed by atomicCAS, full 256-bit key verified after a barrier);
-//   evaluate : for L = 0 .. s, one thread per state reproduces draw_without_tegawari (calc.rs:447-561) with the
-//              reference's exact loop order (draw tiles ascending, aka after its plain tile; i, j ascending), reading
-//              the children's 3x17 values through the hash set and folding discards like discard_slow (calc.rs:563-637).
+// states with order-sensitive f32 sums.  On the GPU the same values are produced LEVEL-SYNCHRONOUSLY, one decision row
+// per (persistent) workgroup at a time:
+//   set-up   : candidates and their required tiles as workgroup-parallel incremental shanten probes;
+//   expand   : for shanten level L = s .. 1, every 3n+1 state of level L (a 32-lane team per state, sp_expand_team)
+//              finds its required draws t and the shanten-keeping discards d of h+t and inserts the children h+t-d into
+//              a per-workgroup hash set (64-bit tag claimed by atomicCAS);
+//   evaluate : for L = 0 .. s: level 0 in three passes (probe / dense thread-per-item scoring / sum), levels > 0 by
+//              teams of 32, 16 or 8 lanes (one lane per remaining draw, sp_eval_team) that reproduce
+//              draw_without_tegawari (calc.rs:447-561) with the reference's exact loop order (draw tiles ascending, aka
+//              after its plain tile; i, j ascending) and fold discards like discard_slow (calc.rs:563-637).
 // Memoisation in the reference is a pure cache, so evaluating every reachable state exactly once gives bit-identical
 // f32 results as long as each state's own accumulation order is kept — it is.  Compiled with -ffp-contract=off
-// (Rust never fuses a*b+c).
+// (Rust never fuses a*b+c).  DESIGN.md §6 has the cost model and the optimisation history.
 #include <hip/hip_runtime.h>
 
 #include "mj_rules.h"
@@ -270,7 +272,7 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
     return true;
 }
 
-// Per-team LDS scratch of sp_visit_team.
+// Per-team LDS scratch of sp_expand_team / sp_eval_team<32>.
 #define SP_CH 8      // children gathered per batch in the evaluation pass
 #define SP_CCAP 256  // children staged per super-chunk (a required tile has at most 2 x 14)
 struct SpTeam {
@@ -349,7 +351,7 @@ __device__ __forceinline__ void sp_partial_merges(SpTeam* TM, const ShBase& B, i
 // draws (get_score: agari decomposition + yaku + fu) runs with every lane busy instead of ~3 lanes per 32-lane team:
 //   probe : team per state — which draws win (34 shanten probes)        -> node.req, one work item per draw entry
 //   score : THREAD per item, dense across the workgroup                  -> 4 scores per item in the node (keep[] area)
-//   sum   : team per state — sp_visit_team<true>(L = 0) accumulates the scores in the reference's order
+//   sum   : team per state — sp_eval_team(L = 0) accumulates the scores in the reference's order
 __device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot) {
     const int ln = threadIdx.x & 31;
     const int sh32 = threadIdx.x & 32;
@@ -417,33 +419,23 @@ __device__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u3
     }
 }
 
-// Visit one 3n+1 state of shanten level L with a TEAM of 32 lanes (half a wavefront).
-//   EVAL == false (L >= 1): find the required draws and shanten-keeping discards, insert every child state (level
-//                  L-1) into the hash set, and leave req / keep / child slots in the node for the evaluation pass.
-//   EVAL == true : compute the state's tenpai/win/ev arrays (draw_without_tegawari_slow, calc.rs:454-561).
-// The kernel is bound by 8-byte table / hash-set gathers (64-byte sectors), so the work is organised in PHASES whose
-// gathers are independent and in flight together, and nothing is gathered twice:
+// Expand one 3n+1 state of shanten level L >= 1 with a TEAM of 32 lanes (half a wavefront): find the required draws and
+// the shanten-keeping discards, insert every child state (level L-1) into the hash set, and leave req / keep / child
+// slots in the node for the evaluation pass.  The work is organised in PHASES whose table / hash-set gathers are
+// independent and in flight together, and nothing is gathered twice:
 //   A  34 "+t" shanten probes, one lane per tile (1 gather each)          -> required set (ballot); rows of h-d
-//   B  (required t, d) "-d" probes; only same-suit pairs need a gather    -> keep[t] (LDS atomicOr)
-//   C  children (t, variant, keep d): hash-set insert                     -> child slots in the pool
-//   D  (EVAL) per required tile in the reference's order: fold the children like discard_slow (calc.rs:570-637) and
-//      accumulate like calc.rs:486-548.  The per-turn arrays live one turn per lane (lane i owns index i), so every
-//      accumulator is a register and the `next[j+1]` operands arrive by intra-team shuffles; per accumulator the
-//      additions happen in the reference's order (draw tiles ascending, aka after its plain tile, j ascending),
-//      hence bit-identical f32 sums.
-template <bool EVAL>  // EVAL is always false now: the evaluation lives in sp_eval_team
-__device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
+//   B  (required t, d) "-d" probes over the tile kinds in the hand; only same-suit pairs need a gather -> keep[t]
+//   C  children (t, variant, keep d): compacted into an LDS list, hash-set insert -> child slots in the pool
+__device__ void sp_expand_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
     const int ln = threadIdx.x & 31;
     const int sh32 = threadIdx.x & 32;  // bit offset of this team inside the wave's 64-bit ballot
     SpNode& node = W->node[slot];
     const SpState S = sp_state_of(node);
-    const int ld3 = X->len_div3, T = X->T;
-    float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
+    const int ld3 = X->len_div3;
     u64 req = 0;
     int child_base = 0;
 
-    u32 l0_yaku = 0;  // level 0: bit i = draw entry i has a yaku
-    if (!EVAL) {
+    {
         // ---- A
         const ShBase B = sh_base(Tb, S.h);
         sp_partial_merges(TM, B, ld3, ln);
@@ -454,7 +446,7 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
             if (t < 34) {
                 u64 r = 0, rd = 0;
                 const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
-                if (!EVAL && hc > 0) rd = sh_load(Tb, st, B.key[st] - sh_pow(t));
+                if (hc > 0) rd = sh_load(Tb, st, B.key[st] - sh_pow(t));
                 if (S.w.get(t) > 0) {
                     r = sh_load(Tb, st, B.key[st] + sh_pow(t));
                     int sh = sh_finish(sh_final(TM->r3[st], r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
@@ -478,7 +470,7 @@ __device__ void sp_visit_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
 
-        if (!EVAL) {
+        {
             // ---- B1: per required tile t and each of the three other suits: U = merge(two untouched suits, row of h+t)
             for (int item = ln; item < n_tiles * 3; item += 32) {
                 const int ti = item / 3, k = item % 3, t = TM->tiles[ti];
@@ -673,7 +665,7 @@ __device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM
         __threadfence_block();
     }
 
-    // ---- D (EVAL)
+    // ---- D
     int sum_required = 0;
     for (u64 rest = req; rest; rest &= rest - 1) sum_required += S.w.get(__ffsll((long long)rest) - 1);
     sum_required &= 0xFF;
@@ -1176,7 +1168,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_visit_team<false>(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_expand_team(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 __syncthreads();
                 if (tid == 0) {
                     X.lvl_begin[lv - 1] = e;
