@@ -77,3 +77,26 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     with pytest.raises(L.MortalAmdError):
         L._load()
     importlib.reload(L)
+
+
+def test_rankings_reference_vectors():
+    """rankings.rs:29-65: the five vectors of the reference's own test, applied to every host-side ranking in the product
+    (arena rank histogram, Stat, Grp) — stable sort by descending score, ties to the lower seat."""
+    from mortal_amd.arena import _rank_by_player
+
+    vectors = [([25000, 25000, 30000, 20000], [1, 2, 0, 3]), ([25000, 25000, 25000, 25000], [0, 1, 2, 3]),
+               ([18000, 32000, 32000, 18000], [2, 0, 1, 3]), ([32000, 18000, 18000, 32000], [0, 2, 3, 1]),
+               ([0, 100000, 0, 0], [1, 0, 2, 3])]
+    from mortal_amd.dataset import Grp
+    from mortal_amd.stat import Stat
+
+    for scores, rank_by_player in vectors:
+        assert _rank_by_player(scores) == rank_by_player
+        ev = [{"type": "start_game", "names": list("abcd")},
+              {"type": "start_kyoku", "bakaze": "E", "dora_marker": "1m", "kyoku": 1, "honba": 0, "kyotaku": 0, "oya": 0,
+               "scores": scores, "tehais": [["?"] * 13] * 4},
+              {"type": "ryukyoku", "deltas": [0, 0, 0, 0]}, {"type": "end_kyoku"}, {"type": "end_game"}]
+        assert Grp.load_events(ev).rank_by_player == rank_by_player
+        for p in range(4):
+            st = Stat.from_game(ev, p)
+            assert [st.rank_1, st.rank_2, st.rank_3, st.rank_4].index(1) == rank_by_player[p]
