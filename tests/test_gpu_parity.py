@@ -70,3 +70,51 @@ def test_lockstep_event_logs(oracle):
     st = parity_util.run_lockstep(oracle, 64, version=3, max_cycles=4000, compare_obs=False, policy="random",
                                   compare_logs=True, seeds=parity_util.default_seeds(64, 777))
     assert st["scores_checked"] == 64
+
+
+@pytest.mark.parametrize("version", [1, 2])
+def test_lockstep_obs_v1_v2(oracle, version):
+    """The two older obs layouts (938 / 942 planes: thermometer integers, no decay rows / RBF rows) under the greedy
+    policy, every obs compared."""
+    st = parity_util.run_lockstep(oracle, 128, version=version, max_cycles=400, obs_every=1, policy="greedy")
+    assert st["obs_checked"] > 40000
+
+
+@pytest.mark.parametrize("version,cycles", [(3, 48), (4, 14)])
+def test_full_size_pool_is_size_independent(version, cycles):
+    """BASELINE's 65,536-table configuration: tables are independent, so the first 1,024 tables of the big pool must
+    produce exactly the rows / masks / obs of a 1,024-table pool on the same seeds and policy, cycle after cycle; plus
+    whole-pool invariants (no table in error, every mask row has a legal action, every live table steps every cycle)."""
+    import numpy as np
+    import torch
+
+    from mortal_amd.pool import TablePool
+
+    big_n, small_n = 65536, 1024
+    seeds = parity_util.default_seeds(big_n)
+    big = TablePool(big_n, version=version, max_rows=2 * big_n)
+    small = TablePool(small_n, version=version)
+    big.reset(seeds, game_ids=np.arange(big_n), n_games_total=big_n)
+    small.reset(seeds[:small_n], game_ids=np.arange(small_n), n_games_total=small_n)
+    obs = torch.empty((2 * big_n, big.C, 34), dtype=torch.float32, device="cuda")
+    masks = torch.empty((2 * big_n, 46), dtype=torch.bool, device="cuda")
+    act_b = act_s = None
+    for cyc in range(cycles):
+        nb, _ = big.step(act_b, None)
+        ns, _ = small.step(act_s, None)
+        ob, mb = big.encode(0, obs, masks)
+        os_, ms = small.encode(0)
+        rows_b, rows_s = big.rows(0), small.rows(0)
+        sel = np.flatnonzero(rows_b[:, 0] < small_n)  # rows are ordered by table: the small pool's tables come first
+        assert len(sel) == ns and (rows_b[sel] == rows_s).all()
+        idx = torch.as_tensor(sel, device="cuda")
+        assert torch.equal(mb[idx], ms)
+        assert torch.equal(ob[idx].view(torch.int32), os_.view(torch.int32))
+        assert bool(mb.any(dim=1).all())
+        act_b = big.random_policy(0, mb, 0x9E3779B97F4A7C15, cyc).clone()
+        act_s = small.random_policy(0, ms, 0x9E3779B97F4A7C15, cyc).clone()
+    assert big.first_error()[0] == 0 and small.first_error()[0] == 0
+    c = big.counters()
+    assert c["steps"] == cycles * big_n and c["games"] == 0 and c["sp_overflow"] == 0
+    big.close()
+    small.close()
