@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU")
     ap.add_argument("--version", type=int, default=4, help="obs version (consts.rs:20-28); 4 = reference default incl. SP tables")
-    ap.add_argument("--preroll", type=int, default=1024,
+    ap.add_argument("--preroll", type=int, default=3072,
                     help="untimed cycles played before the warmup (with the cheap v3 encode) so that the tables are spread "
                          "over all phases of a hanchan instead of all sitting in the first turns of E1")
     ap.add_argument("--policy", choices=["random", "brain"], default="random",
@@ -172,7 +172,9 @@ def main():
         return act[:n], n
 
     a_prev = None
-    if args.preroll > 0:  # steady-state mix of game phases (a hanchan lasts ~600-900 cycles under the random policy)
+    # steady-state mix of game phases: a hanchan lasts a few thousand cycles under the random policy and its kyoku end at
+    # different times, so after 3072 cycles the tables are spread over every phase (SP cost depends strongly on it)
+    if args.preroll > 0:
         pool.configure(0, version=3)
         for i in range(-args.preroll, 0):
             a_prev, _ = cycle(i & 0xFFFFFFFF, a_prev)
