@@ -200,3 +200,31 @@ def test_bot_replays_a_game_like_the_oracle_agent(oracle):
         assert got == want, (ev, got, want)
         n += 1
     assert n >= 30
+
+
+@pytest.mark.parametrize("pid", [0, 1, 2, 3])
+def test_reference_bench_kyoku_obs_device_vs_oracle(oracle, pid):
+    """benches/bench.rs:136-241 (the reference's encode-obs benchmark input, full-information log): device PlayerState vs
+    oracle PlayerState for every seat — cans after each event, obs v4 at every decision, obs v1..v4 at the end."""
+    import json
+    import os
+
+    from libriichi.state import PlayerState
+
+    evs = [json.loads(l) for l in open(os.path.join(os.path.dirname(__file__), "golden", "bench_kyoku.jsonl"))]
+    dev, ora = PlayerState(pid), oracle.PlayerState(pid)
+    n = 0
+    for ev in evs:
+        c = dev.update(ev)
+        co = ora.update(ev)
+        assert {k: int(getattr(c, k)) for k in T.O.CANS if k != "target_actor"} == {k: v for k, v in co.items() if k != "target_actor"}, ev
+        if c.can_act:
+            og, mg = dev.encode_obs(4, False)
+            oo, mo = ora.encode_obs(4, False)
+            assert (mg == mo).all() and (og.view(np.uint32) == oo.view(np.uint32)).all(), ev
+            n += 1
+    assert n >= 10
+    for v in (1, 2, 3, 4):
+        og, mg = dev.encode_obs(v, False)
+        oo, mo = ora.encode_obs(v, False)
+        assert (mg == mo).all() and (og.view(np.uint32) == oo.view(np.uint32)).all(), v

@@ -180,3 +180,21 @@ def test_scenarios_cover_reference_file():
     # the 10 #[test] functions of state/test.rs at the pinned reference revision
     assert len(SCEN) == 10
     assert sum(sum("assert" in s for s in t["steps"]) for t in SCEN.values()) >= 90
+
+
+def test_reference_bench_kyoku_replays(oracle):
+    """benches/bench.rs:136-241: the reference's encode-obs benchmark input replays on the oracle for every seat, the
+    PlayerState invariants hold after each event, and all four obs versions encode."""
+    evs = [json.loads(l) for l in open(os.path.join(HERE, "golden", "bench_kyoku.jsonl"))]
+    assert evs[0]["type"] == "start_kyoku" and len(evs) > 80
+    for pid in range(4):
+        ps = O.PlayerState(pid)
+        n_act = 0
+        for ev in evs:
+            cans = ps.update(ev)
+            _invariants(ps)
+            n_act += any(v for k, v in cans.items() if k != "target_actor")
+        assert n_act >= 10
+        for v in (1, 2, 3, 4):
+            obs, mask = ps.encode_obs(v, False)
+            assert obs.shape[1] == 34 and np.isfinite(obs).all() and obs.min() >= 0.0
