@@ -13,6 +13,7 @@ engine consumes the encoded batch in place.  Engines that define `react_batch_de
 returns a device int tensor of actions) skip the `.tolist()` round trip as well.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -71,6 +72,8 @@ class BatchRunner:
             self.pool.configure(1, enable_quick_eval=self.cfg[0]["quick"], version=self.cfg[0]["version"],
                                 enable_rule_based_agari_guard=self.cfg[0]["guard"])
         self.cycles = 0
+        self.keep_log = keep_log
+        self.meta_batches = {}  # step index -> per agent (q_values, masks, is_greedy, eval_time_ns) of the rows it commits
 
     def _policy(self, agent, obs, masks, invisible=None):
         """-> (actions int32 cuda [n], q_values f32 cuda [n,46] or None).  q-values are kept only for a guarded agent."""
@@ -90,6 +93,9 @@ class BatchRunner:
             raise RuntimeError(f"failed to execute `react_batch` on Python engine: {ex}") from ex
         if len(actions) != obs.shape[0]:
             raise RuntimeError("react_batch returned a batch of the wrong size")
+        if self.keep_log:  # per-decision metadata of the game logs (agent/mortal.rs:161-186)
+            self._last_meta = (np.asarray(q_values, dtype=np.float32).reshape(-1, ACTION_SPACE),
+                               np.asarray(_m, dtype=bool).reshape(-1, ACTION_SPACE), np.asarray(_g, dtype=bool).reshape(-1))
         q = torch.as_tensor(q_values, dtype=torch.float32, device=self.device).contiguous() if guard else None
         return torch.as_tensor(actions, dtype=torch.int32, device=self.device), q
 
@@ -116,7 +122,12 @@ class BatchRunner:
                     continue
                 obs, masks = pool.encode(a)
                 inv = pool.encode_oracle(a) if self.cfg[min(a, len(self.cfg) - 1)]["oracle"] else None
+                self._last_meta = None
+                t0 = time.perf_counter_ns()
                 acts[a], qs[a] = self._policy(a, obs, masks, inv)
+                if self.keep_log and self._last_meta is not None:
+                    # these rows are committed by the NEXT mj_step call, whose index the device writes into the log tags
+                    self.meta_batches.setdefault(self.cycles, {})[a] = self._last_meta + (time.perf_counter_ns() - t0,)
             if self.cycles >= max_cycles:
                 raise MortalAmdError("max_cycles exceeded")
         code, tbl = pool.first_error()
@@ -130,6 +141,21 @@ class BatchRunner:
             raise MortalAmdError("some games did not finish")
         return scores
 
+    @staticmethod
+    def _meta(batch, row, tag, with_batch=False):
+        """Metadata of one decision (agent/mortal.rs:161-186 gen_meta + :575-591), keys in the order of mjai::Metadata."""
+        q, m, greedy, eval_ns = batch
+        bits = 0
+        for i in np.flatnonzero(m[row]):
+            bits |= 1 << int(i)
+        meta = {"q_values": [float(x) for x in q[row][m[row]]], "mask_bits": bits, "is_greedy": bool(greedy[row])}
+        if with_batch:
+            meta["batch_size"] = int(q.shape[0])
+            meta["eval_time_ns"] = int(eval_ns)
+        meta["shanten"] = tag["shanten"]
+        meta["at_furiten"] = tag["at_furiten"]
+        return meta
+
     def dump_logs(self, log_dir, splits):
         """Write one mjai `.json.gz` per game (result.rs:32-51, one_vs_three.rs:195-225); `splits` = files per seed."""
         from . import mjai_log
@@ -141,7 +167,19 @@ class BatchRunner:
         paths = []
         for g, words in enumerate(self.pool.read_logs()):
             names = [names_of_agent[(int(self.agent_of_seat[g]) >> s) & 1] for s in range(4)]  # game.rs:186
-            events = mjai_log.decode_events(words)
+            tags = []
+            events = mjai_log.decode_events(words, tags)
+            for ev, tag in zip(events, tags):
+                if tag is None:
+                    continue
+                agent = (int(self.agent_of_seat[g]) >> ev.get("actor", 0)) & 1
+                batch = self.meta_batches.get(tag["cycle"], {}).get(agent)
+                if batch is None:
+                    continue  # device-side engine (react_batch_device): no q-values came back to the host
+                meta = self._meta(batch, tag["row"], tag, with_batch=True)
+                if tag["kan_row"] is not None:
+                    meta["kan_select"] = self._meta(batch, tag["kan_row"], tag)
+                ev["meta"] = meta
             name = f"{self.seeds[g][0]}_{self.seeds[g][1]}_{'abcd'[g % splits]}.json.gz"
             paths.append(mjai_log.write_game_log_as(os.path.join(log_dir, name), names, self.seeds[g], events))
         return paths

@@ -344,6 +344,7 @@ int mj_step_q(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, 
     sp.log = P->log;
     sp.log_len = P->log_len;
     sp.log_cap = P->log_cap;
+    sp.cycle = (uint32_t)P->cycles;
     sp.deal_algo = P->deal_algo;
     for (int a = 0; a < 2; a++) {
         sp.enable_quick_eval[a] = P->enable_quick_eval[a];

@@ -31,7 +31,8 @@ struct RpEvent {
 };
 MJD int rp_len(uint64_t w) {
     const int t = (int)(w & 15);
-    return t == LG_START_KYOKU ? (((w >> LG_SK_WALL_BIT) & 1) ? 27 : 10) : t == LG_HORA ? 4 : t == LG_RYUKYOKU ? 3 : 1;
+    const int tag = (int)((w >> LG_TAG_BIT) & 1);  // arena logs fed back as scripts: the tag word is skipped
+    return t == LG_START_KYOKU ? (((w >> LG_SK_WALL_BIT) & 1) ? 27 : 10) : (t == LG_HORA ? 4 : t == LG_RYUKYOKU ? 3 : 1) + tag;
 }
 MJD RpEvent rp_decode(uint64_t w) {
     RpEvent e;

@@ -191,6 +191,9 @@ enum MjLogType : uint32_t {
      ((uint64_t)((c0) & 63) << 14) | ((uint64_t)((c1) & 63) << 20) | ((uint64_t)((c2) & 63) << 26) |                   \
      ((uint64_t)((c3) & 63) << 32) | ((uint64_t)((tsumogiri) & 1) << 38))
 #define LG_NURA_SHIFT 39   /* hora: number of ura indicators (0..5) */
+#define LG_TAG_BIT 43      /* the event is an agent's reaction: one tag word follows the header (before other payload):
+                              cycle (20 bits) | main row (18) | kan-select row + 1 (18) | shanten + 1 (4) | furiten (1) | bit 63
+                              -> the host attaches the per-decision `meta` object (agent/mortal.rs:161-186,575-591) */
 #define LG_HONBA_SHIFT 44  /* start_kyoku: honba (8 bits); kyoku (0..11) travels in the c0 field, dora marker in pai */
 #define LG_KYOTAKU_SHIFT 52
 /* start_kyoku words of a REPLAY script only (dataset loader with oracle=True, dataset/invisible.rs): */

@@ -14,6 +14,7 @@ struct Reaction {
     u8 actor, target, pai;
     u8 c0, c1, c2;
     u8 tsumogiri;
+    uint64_t tag;  // 0, or the log tag word of a policy decision (mj_state.h LG_TAG_BIT)
 };
 enum { RX_NONE = 0, RX_DAHAI, RX_REACH, RX_CHI, RX_PON, RX_DAIMINKAN, RX_KAKAN, RX_ANKAN, RX_HORA, RX_RYUKYOKU };
 
@@ -26,6 +27,7 @@ struct StepParams {
     uint64_t* log;             // [n_tables][log_cap] event words or NULL (logging off)
     uint32_t* log_len;         // [n_tables]
     uint32_t log_cap;
+    uint32_t cycle;            // index of this mj_step call (log tags)
     int deal_algo;
     int enable_quick_eval[2];
     int enable_agari_guard[2];
@@ -61,7 +63,7 @@ template <class LN> MJD u64 discard_candidates_aka(const LN& L, int s) {  // 37-
 
 // ---------------------------------------------------------------- action id -> reaction (mortal.rs:338-573)
 template <class LN> MJDN Reaction decode_action(const LN& L, int s, int action, int kan_tile) {
-    Reaction r = {RX_NONE, (u8)s, 0, MJ_NONE, MJ_NONE, MJ_NONE, MJ_NONE, 0};
+    Reaction r = {RX_NONE, (u8)s, 0, MJ_NONE, MJ_NONE, MJ_NONE, MJ_NONE, 0, 0ull};
     const u32 cans = F1(cans, s);
     const int akas = F1(akas_in_hand, s);
     const int lkt = F1(last_kawa_tile, s);
@@ -170,11 +172,11 @@ template <class LN> MJDN Reaction decode_action(const LN& L, int s, int action, 
 }
 
 // ---------------------------------------------------------------- board (arena/board.rs)
-template <class LN> MJD void abortive_ryukyoku(const LN& L) {  // board.rs:502-509
+template <class LN> MJD void abortive_ryukyoku(const LN& L, uint64_t tag = 0) {  // board.rs:502-509
     F(flags) |= TF_HAS_ABORTIVE;
     if (L.log) {
         const int z[4] = {0, 0, 0, 0};
-        log_push(L, LG_WORD(LG_RYUKYOKU, 0, 0, 0, 0, 0, 0, 0, 0));
+        log_push_rx(L, LG_WORD(LG_RYUKYOKU, 0, 0, 0, 0, 0, 0, 0, 0), tag);
         log_push_i32x4(L, z);
     }
 }
@@ -229,11 +231,22 @@ template <class LN> MJDN void exhaustive_ryukyoku(const LN& L) {  // board.rs:24
     }
 }
 
+// Log an agent's reaction: header (+ tag word when the reaction came from a policy row).
+template <class LN> MJD void log_push_rx(const LN& L, uint64_t word, uint64_t tag) {
+    if (!L.log) return;
+    if (tag) {
+        log_push(L, word | (1ull << LG_TAG_BIT));
+        log_push(L, tag);
+    } else {
+        log_push(L, word);
+    }
+}
+
 // Hora{actor, target, deltas, ura_markers}: the ura indicators are listed only for a winner in riichi (board.rs:418-426)
-template <class LN> MJD void log_hora(const LN& L, int actor, int target, const int d[4], int n_ura) {
+template <class LN> MJD void log_hora(const LN& L, int actor, int target, const int d[4], int n_ura, uint64_t tag) {
     if (!L.log) return;
     const int n = accepted(L, actor) ? n_ura : 0;
-    log_push(L, LG_WORD(LG_HORA, actor, target, 0, 0, 0, 0, 0, 0) | ((uint64_t)n << LG_NURA_SHIFT));
+    log_push_rx(L, LG_WORD(LG_HORA, actor, target, 0, 0, 0, 0, 0, 0) | ((uint64_t)n << LG_NURA_SHIFT), tag);
     log_push_i32x4(L, d);
     uint64_t u = 0;
     for (int i = 0; i < n; i++) u |= (uint64_t)F1(wall, 61 + i) << (6 * i);
@@ -274,7 +287,7 @@ template <class LN> MJDN void handle_hora(const LN& L, int single_actor, int sin
             kyotaku_point = 0;
             honba_left = 0;
             for (int i = 0; i < 4; i++) F1(kyoku_deltas, i) += d[i];
-            log_hora(L, actor, single_target, d, n_ura);
+            log_hora(L, actor, single_target, d, n_ura, rx[actor].tag);
         }
         return;
     }
@@ -291,7 +304,7 @@ template <class LN> MJDN void handle_hora(const LN& L, int single_actor, int sin
     }
     d[single_actor] = tsumo_total(p, single_actor == oya) + kyotaku_point + honba_left * 300;
     for (int i = 0; i < 4; i++) F1(kyoku_deltas, i) += d[i];
-    log_hora(L, single_actor, single_target, d, n_ura);
+    log_hora(L, single_actor, single_target, d, n_ura, rx[single_actor].tag);
 }
 
 // One BoardState::step (board.rs:511-678).  Returns true when the kyoku has ended.
@@ -362,7 +375,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
                 F(flags) = fl & ~TF_NEW_DORA_AT_DISCARD;
                 add_new_dora(L);
             }
-            log_push(L, LG_WORD(LG_DAHAI, ev.actor, 0, ev.pai, 0, 0, 0, 0, ev.tsumogiri));
+            log_push_rx(L, LG_WORD(LG_DAHAI, ev.actor, 0, ev.pai, 0, 0, 0, 0, ev.tsumogiri), ev.tag);
             ev_dahai(L, ev.actor, ev.pai, ev.tsumogiri);
             const int next_actor = (ev.actor + 1) & 3;
             F(tsumo_actor) = (u8)next_actor;
@@ -403,7 +416,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
         case RX_CHI:
         case RX_PON:
             check_riichi_accepted(L);
-            log_push(L, LG_WORD(ev.type == RX_PON ? LG_PON : LG_CHI, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, 0, 0, 0));
+            log_push_rx(L, LG_WORD(ev.type == RX_PON ? LG_PON : LG_CHI, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, 0, 0, 0), ev.tag);
             ev_chi_pon(L, ev.type == RX_PON, ev.actor, ev.target, ev.pai, ev.c0, ev.c1);
             break;
         case RX_ANKAN:
@@ -412,7 +425,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
                 add_new_dora(L);
             }
             // consumed = [akaize(t), t, t, t] (agent/mortal.rs:505-520)
-            log_push(L, LG_WORD(LG_ANKAN, ev.actor, 0, 0, akaize(ev.pai), ev.pai, ev.pai, ev.pai, 0));
+            log_push_rx(L, LG_WORD(LG_ANKAN, ev.actor, 0, 0, akaize(ev.pai), ev.pai, ev.pai, ev.pai, 0), ev.tag);
             ev_ankan(L, ev.actor, ev.pai);
             add_new_dora(L);
             F(tsumo_actor) = ev.actor;
@@ -424,12 +437,12 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
             if (fl & TF_NEW_DORA_AT_DISCARD) F(flags) = fl | TF_NEW_DORA_AT_TSUMO;
             check_riichi_accepted(L);
             if (ev.type == RX_DAIMINKAN) {
-                log_push(L, LG_WORD(LG_DAIMINKAN, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, ev.c2, 0, 0));
+                log_push_rx(L, LG_WORD(LG_DAIMINKAN, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, ev.c2, 0, 0), ev.tag);
                 ev_daiminkan(L, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, ev.c2);
             } else {
                 // pai = the added tile; consumed = the pon it extends: red five first unless it is the added tile
                 const int t = deaka(ev.pai);
-                log_push(L, LG_WORD(LG_KAKAN, ev.actor, 0, ev.pai, is_aka(ev.pai) ? t : akaize(t), t, t, 0, 0));
+                log_push_rx(L, LG_WORD(LG_KAKAN, ev.actor, 0, ev.pai, is_aka(ev.pai) ? t : akaize(t), t, t, 0, 0), ev.tag);
                 ev_kakan(L, ev.actor, ev.pai);
             }
             F(flags) |= TF_NEW_DORA_AT_DISCARD | TF_DEAL_FROM_RINSHAN;
@@ -437,7 +450,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
             F(kans) += 1;
             break;
         case RX_REACH:
-            log_push(L, LG_WORD(LG_REACH, ev.actor, 0, 0, 0, 0, 0, 0, 0));
+            log_push_rx(L, LG_WORD(LG_REACH, ev.actor, 0, 0, 0, 0, 0, 0, 0), ev.tag);
             ev_reach(L, ev.actor);
             F(riichi_to_be_accepted) = ev.actor;
             break;
@@ -445,7 +458,7 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
             handle_hora(L, ev.actor, ev.target, rx);
             return true;
         case RX_RYUKYOKU:  // 九種九牌
-            abortive_ryukyoku(L);
+            abortive_ryukyoku(L);  // (the reference logs this Ryukyoku without the agent's meta, board.rs:502-509)
             return true;
     }
     // update_paos (board.rs:473-499)
@@ -554,7 +567,7 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
             if (!((pend >> s) & 1)) continue;
             const int qp = F1(quick_pai, s);
             if (qp != MJ_NONE) {
-                rx[s] = {RX_DAHAI, (u8)s, 0, (u8)qp, MJ_NONE, MJ_NONE, MJ_NONE, (u8)(F1(last_self_tsumo, s) == qp)};
+                rx[s] = {RX_DAHAI, (u8)s, 0, (u8)qp, MJ_NONE, MJ_NONE, MJ_NONE, (u8)(F1(last_self_tsumo, s) == qp), 0ull};
                 continue;
             }
             const int agent = (F(agent_of_seat) >> s) & 1;
@@ -579,6 +592,10 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
                 action = best;
             }
             rx[s] = decode_action(L, s, action, kan_tile);
+            if (L.log)
+                rx[s].tag = (uint64_t)(P.cycle & 0xFFFFFu) | ((uint64_t)(mr & 0x3FFFF) << 20) |
+                            ((uint64_t)((kr >= 0 ? kr + 1 : 0) & 0x3FFFF) << 38) | ((uint64_t)((F1(shanten, s) + 1) & 15) << 56) |
+                            ((uint64_t)((F1(pflags, s) & PF_AT_FURITEN) != 0) << 60) | (1ull << 63);
         }
         F(pending) = 0;
         // ---- poll

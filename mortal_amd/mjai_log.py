@@ -15,6 +15,7 @@ TILE_NAMES = ([f"{n}{s}" for s in "mps" for n in range(1, 10)] + ["E", "S", "W",
 (LG_START_KYOKU, LG_TSUMO, LG_DAHAI, LG_CHI, LG_PON, LG_DAIMINKAN, LG_KAKAN, LG_ANKAN, LG_DORA, LG_REACH,
  LG_REACH_ACCEPTED, LG_HORA, LG_RYUKYOKU, LG_END_KYOKU) = range(1, 15)
 _NURA_SHIFT, _HONBA_SHIFT, _KYOTAKU_SHIFT = 39, 44, 52
+_TAG_BIT = 43
 
 
 def _i32x4(w0, w1):
@@ -26,8 +27,11 @@ def _i32x4(w0, w1):
     return out
 
 
-def decode_events(words):
-    """u64 words of one table -> list of mjai event dicts (keys in the reference's serialisation order)."""
+def decode_events(words, tags=None):
+    """u64 words of one table -> list of mjai event dicts (keys in the reference's serialisation order).
+
+    Arena logs mark an agent's reactions with a tag word (LG_TAG_BIT); pass a list as `tags` to receive, per event,
+    None or dict(cycle, row, kan_row, shanten, at_furiten) — the link to the decision's batch row for the `meta` object."""
     evs = []
     i, n = 0, len(words)
     tn = TILE_NAMES
@@ -38,6 +42,15 @@ def decode_events(words):
         actor, target = (w >> 4) & 3, (w >> 6) & 3
         pai = (w >> 8) & 63
         c = [(w >> (14 + 6 * k)) & 63 for k in range(4)]
+        tag = None
+        if t != LG_START_KYOKU and (w >> _TAG_BIT) & 1:
+            tw = int(words[i])
+            i += 1
+            kr = (tw >> 38) & 0x3FFFF
+            tag = dict(cycle=tw & 0xFFFFF, row=(tw >> 20) & 0x3FFFF, kan_row=kr - 1 if kr else None,
+                       shanten=((tw >> 56) & 15) - 1, at_furiten=bool((tw >> 60) & 1))
+        if tags is not None:
+            tags.append(tag)
         if t == LG_START_KYOKU:
             kyoku = c[0]
             scores = _i32x4(int(words[i]), int(words[i + 1]))

@@ -132,3 +132,42 @@ def test_log_dir_and_stat(oracle, tmp_path):
     assert st.game == 8 and [st.rank_1, st.rank_2, st.rank_3, st.rank_4] == got
     ch = Stat.from_dir(d, "champion", True)
     assert ch.game == 24 and st.point + ch.point == 0
+
+
+def test_log_meta_objects(oracle, tmp_path):
+    """With the legacy react_batch engines the dumped logs carry the reference's per-decision `meta` objects
+    (agent/mortal.rs:161-186,575-591): compact q-values over the mask, mask bits, greedy flag, batch size, shanten and
+    furiten of the acting seat — and the events themselves are unchanged."""
+    import gzip
+    import json
+    import os
+
+    from libriichi.arena import OneVsThree
+
+    chal, _ = _engine(3, 1, "challenger", False)
+    cham, _ = _engine(3, 2, "champion", False)
+    d = str(tmp_path / "logs")
+    OneVsThree(disable_progress_bar=True, log_dir=d).py_vs_py(challenger=chal, champion=cham, seed_start=(10000, KEY), seed_count=1)
+    n_meta = n_kan = 0
+    for f in sorted(os.listdir(d)):
+        evs = [json.loads(l) for l in gzip.open(os.path.join(d, f), "rt")]
+        ps = [oracle.PlayerState(p) for p in range(4)]
+        at_decision = [None] * 4  # (mask, shanten, furiten) of each seat when it last could act
+        for ev in evs[1:-1]:
+            meta = ev.pop("meta", None)
+            if meta is not None:
+                a = ev["actor"]
+                mask, shanten, furiten = at_decision[a]
+                assert list(meta)[:3] == ["q_values", "mask_bits", "is_greedy"] and meta["batch_size"] >= 1
+                assert meta["shanten"] == shanten and meta["at_furiten"] == furiten, (ev, meta)
+                bits = sum(1 << int(i) for i in np.flatnonzero(mask))
+                assert meta["mask_bits"] == bits and len(meta["q_values"]) == int(mask.sum())
+                n_meta += 1
+                n_kan += "kan_select" in meta
+            for a, p in enumerate(ps):
+                cans = p.update(ev)
+                # a reach_accepted logged between a discard and the call answering it does not renew the decision
+                if ev["type"] != "reach_accepted" and any(v for k, v in cans.items() if k != "target_actor"):
+                    sn = p.snapshot()
+                    at_decision[a] = (p.encode_obs(3, False)[1], sn["shanten"], sn["at_furiten"])
+    assert n_meta > 500
