@@ -101,3 +101,81 @@ def test_hand_parser(oracle):
     assert h[4] == 1 and h[27] == h[28] == h[29] == 1 and h.sum() == 4
     h37 = oracle.hand_with_aka("50m")
     assert h37[4] == 1 and h37[34] == 1
+
+
+def _bruteforce_normal_shanten(cnt, n_melds_needed):
+    """Textbook recursive shanten of the standard form (independent of the reference's tables): maximise
+    2*mentsu + taatsu(+pair) under the 4-block rule.  cnt: 34 tile counts; n_melds_needed = len_div3."""
+    best = [8]
+    cnt = list(cnt)
+
+    def scan(i, mentsu, taatsu, pair):
+        while i < 34 and cnt[i] == 0:
+            i += 1
+        blocks = mentsu + taatsu
+        if blocks > n_melds_needed:
+            taatsu_eff = n_melds_needed - mentsu
+        else:
+            taatsu_eff = taatsu
+        sh = 2 * (n_melds_needed - mentsu) - taatsu_eff - pair
+        best[0] = min(best[0], sh)
+        if i >= 34:
+            return
+        suited = i < 27
+        pos = i % 9
+        # kotsu
+        if cnt[i] >= 3:
+            cnt[i] -= 3
+            scan(i, mentsu + 1, taatsu, pair)
+            cnt[i] += 3
+        # shuntsu
+        if suited and pos <= 6 and cnt[i + 1] and cnt[i + 2]:
+            cnt[i] -= 1; cnt[i + 1] -= 1; cnt[i + 2] -= 1
+            scan(i, mentsu + 1, taatsu, pair)
+            cnt[i] += 1; cnt[i + 1] += 1; cnt[i + 2] += 1
+        # pair (as the head, once) / pair as a taatsu
+        if cnt[i] >= 2:
+            cnt[i] -= 2
+            if not pair:
+                scan(i, mentsu, taatsu, 1)
+            scan(i, mentsu, taatsu + 1, pair)
+            cnt[i] += 2
+        # ryanmen / penchan
+        if suited and pos <= 7 and cnt[i + 1]:
+            cnt[i] -= 1; cnt[i + 1] -= 1
+            scan(i, mentsu, taatsu + 1, pair)
+            cnt[i] += 1; cnt[i + 1] += 1
+        # kanchan
+        if suited and pos <= 6 and cnt[i + 2]:
+            cnt[i] -= 1; cnt[i + 2] -= 1
+            scan(i, mentsu, taatsu + 1, pair)
+            cnt[i] += 1; cnt[i + 2] += 1
+        # skip this tile kind entirely
+        c = cnt[i]
+        cnt[i] = 0
+        scan(i + 1, mentsu, taatsu, pair)
+        cnt[i] = c
+
+    scan(0, 0, 0, 0)
+    return best[0]
+
+
+def test_shanten_tables_vs_bruteforce(oracle):
+    """The table-driven calc_normal (shanten.rs:88-102 restated + the reference's packed tables) against an independent
+    recursive search on random hands of every meld count."""
+    rng = np.random.default_rng(7)
+    tiles = np.repeat(np.arange(34), 4)
+    n = 0
+    for trial in range(260):
+        melds = trial % 5  # tehai_len_div3 = 4 - melds
+        ld3 = 4 - melds
+        k = 3 * ld3 + 1 + (trial // 5) % 2
+        rng.shuffle(tiles)
+        # bias towards connected hands: half of the trials draw from two suits only
+        pool = tiles if trial % 2 else np.array([t for t in tiles if t < 18])
+        hand = np.bincount(pool[:k], minlength=34).astype(np.uint8)
+        got = oracle.calc_shanten(hand, ld3, which=1)  # 1 = normal form only
+        want = _bruteforce_normal_shanten(hand, ld3)
+        assert got == want, (hand.tolist(), ld3, got, want)
+        n += 1
+    assert n == 260
