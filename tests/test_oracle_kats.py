@@ -179,3 +179,41 @@ def test_shanten_tables_vs_bruteforce(oracle):
         assert got == want, (hand.tolist(), ld3, got, want)
         n += 1
     assert n == 260
+
+
+def test_agari_index_vs_constructed_hands(oracle):
+    """The agari key / division table path (agari.rs:24-51,767-838) on hands that are complete by construction (four
+    random mentsu + a pair, closed) and on hands that are not: with one extra han every complete hand scores, every
+    incomplete one is rejected."""
+    rng = np.random.default_rng(11)
+    n_win = n_lose = 0
+    for trial in range(400):
+        cnt = np.zeros(34, dtype=np.int64)
+        ok = True
+        for _ in range(4):
+            if rng.random() < 0.6:  # shuntsu
+                s, p = int(rng.integers(0, 3)), int(rng.integers(0, 7))
+                cnt[9 * s + p:9 * s + p + 3] += 1
+            else:
+                cnt[int(rng.integers(0, 34))] += 3
+        cnt[int(rng.integers(0, 34))] += 2
+        if cnt.max() > 4:
+            continue
+        hand = cnt.astype(np.uint8)
+        assert oracle.calc_shanten(hand, 4) == -1
+        win_tile = int(rng.choice(np.flatnonzero(hand)))
+        res = oracle.agari(hand, win_tile, False, mode=0, additional_hans=1, jikaze=28, bakaze=27)
+        assert res is not None and (res[0] == "yakuman" or (res[2] >= 1 and (res[1] >= 20 or res[2] >= 5))), (hand.tolist(), win_tile, res)  # fu is only computed below mangan
+        n_win += 1
+        # break it: move one tile somewhere else so that it is no longer complete
+        broken = hand.copy()
+        src = int(rng.choice(np.flatnonzero(broken)))
+        dst = int(rng.integers(0, 34))
+        if dst == src or broken[dst] >= 4:
+            continue
+        broken[src] -= 1
+        broken[dst] += 1
+        if oracle.calc_shanten(broken, 4) >= 0:
+            assert oracle.agari(broken, dst, False, mode=0, additional_hans=1, jikaze=28, bakaze=27) is None, broken.tolist()
+            n_lose += 1
+    assert n_win > 250 and n_lose > 150
