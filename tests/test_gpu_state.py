@@ -228,3 +228,49 @@ def test_reference_bench_kyoku_obs_device_vs_oracle(oracle, pid):
         og, mg = dev.encode_obs(v, False)
         oo, mo = ora.encode_obs(v, False)
         assert (mg == mo).all() and (og.view(np.uint32) == oo.view(np.uint32)).all(), v
+
+
+def test_random_hands_device_vs_oracle(oracle):
+    """Hands that games rarely produce (heavy one-suit, many pairs / terminals, quads): a fresh kyoku with a random
+    13-tile hand plus one draw, device vs oracle — shanten, waits, furiten, every can_* flag, kan candidates and the
+    whole v4 obs (which includes the SP tables)."""
+    from libriichi.state import PlayerState
+
+    names = oracle.TILE_NAMES
+    rng = np.random.default_rng(5)
+    full = np.array([t for t in range(34) for _ in range(4)])
+    dev, ora = PlayerState(0), oracle.PlayerState(0)
+    n = 0
+    for trial in range(120):
+        kind = trial % 4
+        if kind == 0:
+            pool = full[full < 9]  # one suit only (chinitsu shapes)
+        elif kind == 1:
+            yao = [0, 8, 9, 17, 18, 26, 27, 28, 29, 30, 31, 32, 33]
+            pool = np.array([t for t in yao for _ in range(4)])  # terminals and honours (kokushi / chitoi territory)
+        elif kind == 2:
+            pool = np.array([t for t in rng.choice(34, 7, replace=False) for _ in range(4)])  # pairs and quads
+        else:
+            pool = full
+        pool = pool.copy()
+        rng.shuffle(pool)
+        hand, draw = pool[:13], int(pool[13])
+        held = np.bincount(pool[:14], minlength=34)
+        marker = int(rng.choice(np.flatnonzero(held < 4)))  # a fifth visible copy is a rule violation on both sides
+        ev0 = {"type": "start_kyoku", "bakaze": "E", "dora_marker": names[marker], "kyoku": 1, "honba": 0,
+               "kyotaku": 0, "oya": 0, "scores": [25000] * 4,
+               "tehais": [[names[int(t)] for t in hand]] + [["?"] * 13] * 3}
+        ev1 = {"type": "tsumo", "actor": 0, "pai": names[draw]}
+        for ev in (ev0, ev1):
+            cd = dev.update(ev)
+            co = ora.update(ev)
+        sn = ora.snapshot()
+        assert dev.shanten == sn["shanten"] and dev.at_furiten == sn["at_furiten"], (hand.tolist(), draw)
+        assert dev.waits == [bool(x) for x in sn["waits"]]
+        assert {k: int(getattr(cd, k)) for k in T.O.CANS if k != "target_actor"} == {k: v for k, v in co.items() if k != "target_actor"}
+        assert len(dev.ankan_candidates) == sn["n_ankan_cand"] and len(dev.kakan_candidates) == sn["n_kakan_cand"]
+        og, mg = dev.encode_obs(4, False)
+        oo, mo = ora.encode_obs(4, False)
+        assert (mg == mo).all() and (og.view(np.uint32) == oo.view(np.uint32)).all(), (hand.tolist(), draw)
+        n += 1
+    assert n == 120
