@@ -250,6 +250,7 @@ int mjo_ps_snapshot(void* h, int* o) {
     for (int i = 0; i < 4; i++) o[238 + i] = s->scores[i];
     o[242] = (int)s->ankan_candidates.size();
     o[243] = (int)s->kakan_candidates.size();
+    o[244] = s->last_self_tsumo ? (int)*s->last_self_tsumo : -1;
     return 0;
 }
 // kawa of relative seat `rel` in the pool's u64 entry format (mortal_amd/csrc/mj_state.h KW_*); returns length

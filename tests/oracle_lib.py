@@ -298,6 +298,7 @@ class PlayerState:
             cans=dict(zip(CANS, (int(x) for x in o[218:231]))), akas_in_hand=o[231:234].astype(bool),
             real_time_shanten=int(o[234]), can_w_riichi=bool(o[235]), at_ippatsu=bool(o[236]),
             at_rinshan=bool(o[237]), scores=[int(x) for x in o[238:242]], n_ankan_cand=int(o[242]), n_kakan_cand=int(o[243]),
+            last_self_tsumo=int(o[244]),
         )
 
     def set_scores(self, scores):

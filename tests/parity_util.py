@@ -66,6 +66,19 @@ def greedy_actions(masks, rows, cycle, obs_rows3, seed):
     return act
 
 
+def tsumogiri_actions(arena, masks, rows):
+    """agent/tsumogiri.rs:17-38: discard the tile just drawn whenever a discard is possible, otherwise pass."""
+    masks = np.asarray(masks, dtype=bool)
+    act = np.full(len(masks), 45, dtype=np.int32)
+    for r in range(len(masks)):
+        if rows[r][2]:  # kan-select rows never occur (no kan is ever declared)
+            raise AssertionError("kan-select row under the tsumogiri policy")
+        if masks[r, :37].any():
+            act[r] = arena.player_state(int(rows[r][0]), int(rows[r][1])).snapshot()["last_self_tsumo"]
+        assert masks[r, act[r]], (r, int(act[r]), np.flatnonzero(masks[r]).tolist())
+    return act
+
+
 def fake_q_values(masks, rows, cycle, seed):
     """Deterministic stand-in for the engine's q-values: a hash per (row, action) in [-1, 1), -inf where illegal
     (engine.py masks illegal actions the same way), with deliberate ties to exercise max_by's last-maximum rule."""
@@ -186,6 +199,8 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         if policy == "greedy":
             d0 = DISCARD_ROW[version]
             act = greedy_actions(masks_o, rows_o, cycle, obs_g[:, d0:d0 + 3].cpu().numpy(), policy_seed)
+        elif policy == "tsumogiri":
+            act = tsumogiri_actions(arena, masks_o, rows_o)
         else:
             act = oracle.random_actions(masks_o, rows_o, cycle, seed=policy_seed)
         if guard:

@@ -72,6 +72,15 @@ def test_lockstep_event_logs(oracle):
     assert st["scores_checked"] == 64
 
 
+def test_lockstep_tsumogiri_reference_seeds(oracle):
+    """arena/game.rs:323-371 (the reference's only whole-arena test): four Tsumogiri agents on seeds (1009, 0) and
+    (1021, 0); the device pool follows the oracle event for event through all twelve kyoku (E1 .. W4)."""
+    st = parity_util.run_lockstep(oracle, 2, version=3, seeds=[(1009, 0), (1021, 0)], policy="tsumogiri", compare_logs=True,
+                                  max_cycles=3000)
+    assert st["done_gpu"] == 2 and st["done_oracle"] == 2 and st["scores_checked"] == 2
+    assert st["log_events_checked"] == 2 * 1716
+
+
 @pytest.mark.parametrize("version", [1, 2])
 def test_lockstep_obs_v1_v2(oracle, version):
     """The two older obs layouts (938 / 942 planes: thermometer integers, no decay rows / RBF rows) under the greedy

@@ -136,3 +136,32 @@ def test_replay_golden_log_through_board(oracle):
         if e["type"] == "reach_accepted":
             expect[e["actor"]] -= 1000
     assert view[4:8].tolist() == expect.tolist()
+
+
+def test_tsumogiri_hanchan_reference_seeds(oracle):
+    """arena/game.rs:323-371: two hanchan of four Tsumogiri agents on seeds (1009, 0) and (1021, 0) run to the end.
+    Nobody ever wins or calls, so every kyoku is a ryukyoku (exhaustive, or suufon renda), the renchan/honba logic
+    carries the game to its end, and the points only move through noten payments."""
+    import parity_util
+
+    arena = oracle.Arena([(1009, 0), (1021, 0)], version=3, enable_quick_eval=True, keep_log=True)
+    cycles = 0
+    while arena.n_live > 0:
+        rows = arena.poll()  # poll every game, then commit every game (game.rs:286-304) — also when no row is open
+        _, masks = arena.encode(0, len(rows), want_obs=False)
+        arena.commit(parity_util.tsumogiri_actions(arena, masks, rows))
+        cycles += 1
+        assert cycles < 5000
+    for g in range(2):
+        scores, done = arena.result(g)
+        assert done and int(scores.sum()) == 100000
+        log = arena.log(g)
+        kinds = {e["type"] for e in log}
+        assert kinds <= {"start_game", "start_kyoku", "tsumo", "dahai", "ryukyoku", "end_kyoku", "end_game"}, kinds
+        assert all(e["tsumogiri"] for e in log if e["type"] == "dahai")
+        # all four are noten at every exhaustive draw here, so the dealer always rotates with honba + 1; nobody reaches
+        # 30,000, so the game enters the West round and stops after W4 (game.rs:163-222)
+        kyokus = [(e["bakaze"], e["kyoku"], e["honba"]) for e in log if e["type"] == "start_kyoku"]
+        assert kyokus == [("ESW"[k // 4], k % 4 + 1, k) for k in range(12)]
+        assert all(e["deltas"] == [0, 0, 0, 0] for e in log if e["type"] == "ryukyoku")
+        assert scores.tolist() == [25000] * 4
