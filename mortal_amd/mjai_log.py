@@ -137,6 +137,13 @@ def encode_events(events, augmented=False, walls=None, deal_from_seed=False):
         t = e["type"]
         if t in ("start_game", "end_game", "none"):
             continue
+        # serde's bounded integers (mjai/event.rs:20-120, `BoundedU8<0, 3>` actors, kyoku 1..=4): reject, never wrap
+        for k in ("actor", "target", "oya"):
+            if k in e and not 0 <= int(e[k]) <= 3:
+                raise ValueError(f"{t}: {k} {e[k]} out of range 0..3")
+        if t == "start_kyoku" and not (1 <= int(e["kyoku"]) <= 4 and 0 <= int(e["honba"]) <= 255 and 0 <= int(e["kyotaku"]) <= 255
+                                       and e["bakaze"] in ("E", "S", "W", "N")):
+            raise ValueError("start_kyoku: kyoku / honba / kyotaku / bakaze out of range")
         if t == "start_kyoku":
             kyoku = (TILE_ID[e["bakaze"]] - 27) * 4 + e["kyoku"] - 1
             out.append(word(LG_START_KYOKU, pai=tid(e["dora_marker"]), c=(kyoku,)) | (e["honba"] << _HONBA_SHIFT)

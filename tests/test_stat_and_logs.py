@@ -131,3 +131,50 @@ def test_walls_from_events_are_consistent():
     # the words carry the wall and still decode to the same events
     w = mjai_log.encode_events(events, walls=walls)
     assert mjai_log.decode_events(w) == events[1:-1]
+
+
+EVENT_LINES = os.path.join(os.path.dirname(__file__), "golden", "event_lines.jsonl")
+
+
+def test_event_lines_of_the_reference_round_trip(oracle):
+    """mjai/event.rs:260-294 (`json_consistency`): every event kind, with and without the optional hora / ryukyoku
+    fields.  The oracle's packed event and the device's LG_* word format both reproduce the reference's serialisation
+    (serde declaration order, compact separators) byte for byte."""
+    lines = [l.rstrip("\n") for l in open(EVENT_LINES)]
+    assert len(lines) == 19
+    kinds = set()
+    for line in lines:
+        ev = json.loads(line)
+        kinds.add(ev["type"])
+        if ev["type"] not in ("none", "start_game", "end_game"):  # written by dump_json_log / never logged
+            assert mjai_log._dumps(oracle.unpack_event(oracle.pack_event(ev))) == line
+        if ev["type"] in ("none", "start_game", "end_game"):
+            assert len(mjai_log.encode_events([ev])) == 0
+            continue
+        words = mjai_log.encode_events([ev])
+        got = mjai_log.decode_events(words)
+        assert len(got) == 1
+        if ev["type"] in ("hora", "ryukyoku") and "deltas" not in ev:
+            # the word format always carries the deltas (the arena always logs them): absent == zeros
+            want = dict(ev, deltas=[0, 0, 0, 0])
+            if ev["type"] == "hora":
+                want["ura_markers"] = []
+            assert got[0] == want
+        else:
+            assert mjai_log._dumps(got[0]) == line
+    assert kinds == {"none", "start_game", "start_kyoku", "tsumo", "dahai", "chi", "pon", "daiminkan", "kakan", "ankan", "dora",
+                     "reach", "reach_accepted", "hora", "ryukyoku", "end_kyoku", "end_game"}
+    names, seed = json.loads(lines[1])["names"], json.loads(lines[1])["seed"]
+    assert mjai_log.dump_json_log(names, seed, []).splitlines() == [lines[1], lines[-1]]
+
+
+def test_event_bound_check():
+    """mjai/event.rs:296-337 (`bound_check`): actor / target above 3 and kyoku outside 1..=4 are errors, not wrapped."""
+    import pytest
+
+    sk = json.loads(open(EVENT_LINES).read().splitlines()[2])
+    assert len(mjai_log.encode_events([sk])) == 10
+    for bad in ({"type": "reach", "actor": 4}, {"type": "hora", "actor": 0, "target": 5}, dict(sk, kyoku=0), dict(sk, kyoku=5),
+                dict(sk, oya=4)):
+        with pytest.raises(ValueError):
+            mjai_log.encode_events([bad])
