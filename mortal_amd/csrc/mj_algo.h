@@ -181,6 +181,10 @@ struct ShBase {
     u32 key[4];
     u64 row[4];
     int pairs, kinds, kpairs, kkinds;  // chitoi / kokushi counters (shanten.rs:104-137)
+    // lane-dependent suit index: selects, so that key[] / row[] stay in registers (a dynamically indexed local array
+    // lives in scratch memory, and every scratch access shares vmcnt with the table gathers)
+    MJD u32 key_of(int s) const { return s == 0 ? key[0] : s == 1 ? key[1] : s == 2 ? key[2] : key[3]; }
+    MJD u64 row_of(int s) const { return s == 0 ? row[0] : s == 1 ? row[1] : s == 2 ? row[2] : row[3]; }
 };
 MJD int sh_suit(int t) { return t < 9 ? 0 : t < 18 ? 1 : t < 27 ? 2 : 3; }
 MJD u32 sh_pow(int t) {  // weight of tile t inside its suit key (first tile most significant): 5^e, e = 0..8
@@ -189,6 +193,43 @@ MJD u32 sh_pow(int t) {  // weight of tile t inside its suit key (first tile mos
 }
 MJD u64 sh_load(const MjTablesDev& T, int suit, u32 key) {
     return suit < 3 ? sh_row(T.suhai, T.n_suhai, key) : sh_row(T.jihai, T.n_jihai, key);
+}
+// The two table base pointers as values (wave-uniform scalar loads from the constant block, once per function): a probe
+// with a lane-dependent suit then selects between two registers, instead of first gathering the POINTER from
+// &T.suhai / &T.jihai with a per-lane load and only then the row (two dependent memory round trips per probe).
+#define MJ_HBM __attribute__((address_space(1)))
+struct ShTab {
+    const MJ_HBM u64* su;
+    const MJ_HBM u64* ji;
+    u32 nsu, nji;
+};
+MJD ShTab sh_tab(const MjTablesDev& T) {
+    ShTab t;
+    t.su = (const MJ_HBM u64*)T.suhai;
+    t.ji = (const MJ_HBM u64*)T.jihai;
+    t.nsu = T.n_suhai;
+    t.nji = T.n_jihai;
+    return t;
+}
+MJD u64 sh_load(const ShTab& T, int suit, u32 key) {
+    const MJ_HBM u64* tab = suit < 3 ? T.su : T.ji;
+    const u32 n = suit < 3 ? T.nsu : T.nji;
+    const u64 r = tab[key < n ? key : 0u];  // unconditional load (always a valid address), so gathers can be batched
+    return key < n ? r : 0ull;
+}
+MJD ShBase sh_base(const ShTab& T, Hand h) {
+    ShBase b;
+    b.key[0] = suit_key9(h.mp);
+    b.key[1] = suit_key9(h.mp >> 27);
+    b.key[2] = suit_key9(h.sz);
+    b.key[3] = suit_key7(h.sz >> 27);
+#pragma unroll
+    for (int i = 0; i < 4; i++) b.row[i] = sh_load(T, i, b.key[i]);
+    b.pairs = h.n_pairs();
+    b.kinds = h.n_kinds();
+    b.kpairs = h.n_yao_pairs();
+    b.kkinds = h.n_yao_kinds();
+    return b;
 }
 MJD ShBase sh_base(const MjTablesDev& T, Hand h) {
     ShBase b;

@@ -64,6 +64,19 @@ __device__ static const float SP_URADORA[5][13] = {
     {0.101768f, 0.275319f, 0.313742f, 0.20189f, 0.081774f, 0.0215394f, 0.0035918f, 0.0003607f, 1.52e-5f, 3e-7f, 0.f, 0.f, 0.f}};
 __device__ static const u8 SP_DISCARD_PRIO[38] = {  // tile.rs:21-28
     6, 5, 4, 3, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 3, 4, 5, 6, 7, 7, 7, 7, 7, 7, 7, 1, 1, 1, 0};
+// The same table in closed form (no memory access): used inside the evaluation fold, where the order of two discards is
+// the order of the keys  prio * 64 + (63 - tile)  (higher priority first, then the lower tile id; tile.rs:169-177).
+constexpr __host__ __device__ int sp_discard_prio(int t) {
+    return t < 27 ? 2 + (t % 9 > 4 ? t % 9 - 4 : 4 - t % 9) : t < 34 ? 7 : t < 37 ? 1 : 0;
+}
+constexpr bool sp_discard_prio_matches_table() {
+    constexpr int tab[38] = {6, 5, 4, 3, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 3, 4, 5, 6, 7, 7, 7, 7, 7, 7, 7, 1, 1, 1, 0};
+    for (int t = 0; t < 38; t++)
+        if (sp_discard_prio(t) != tab[t]) return false;
+    return true;
+}
+static_assert(sp_discard_prio_matches_table(), "sp_discard_prio != SP_DISCARD_PRIO");
+MJD int sp_discard_key(int t) { return sp_discard_prio(t) * 64 + (63 - t); }
 MJD int cmp_discard_priority(int l, int r) {  // tile.rs:169-177
     int pl = SP_DISCARD_PRIO[l], pr = SP_DISCARD_PRIO[r];
     if (pl != pr) return pl < pr ? -1 : 1;
@@ -127,6 +140,16 @@ struct SpCtx {  // per-decision constants (LDS)
     float cand_tp0[SP_MAX_CAND], cand_wp0[SP_MAX_CAND], cand_ev0[SP_MAX_CAND];
 };
 
+// Out-of-line phase functions receive their LDS scratch / HBM work area as generic pointers; telling the compiler which
+// address space they are in (an assumption for LDS, an explicit global-address-space pointer for HBM) turns every flat_load (which counts on BOTH vmcnt and lgkmcnt, so each LDS read waits for all
+// HBM gathers in flight) into ds_read / global_load with independent counters.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SP_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define SP_ASSUME_LDS(p) ((void)0)  // host pass of the single-source compile: the builtin only exists on the device
+#endif
+#define SP_HBM __attribute__((address_space(1)))
+
 // hash-set insert; returns the slot or -1 on overflow.  `fresh` tells whether this call created the slot.
 __device__ int sp_insert(SpWork* W, SpCtx* X, const SpState& s, bool& fresh) {
     u64 k[4];
@@ -148,31 +171,41 @@ __device__ int sp_insert(SpWork* W, SpCtx* X, const SpState& s, bool& fresh) {
     X->overflow = 1;
     return -1;
 }
-// Two-step insert so that several first probes (one L2 atomic each) can be in flight per lane.
+// Two-step insert so that several first probes (one L2 atomic each) can be in flight per lane.  WP = SpWork* in any
+// address space (the out-of-line phase functions pass their global-address-space pointer).
 struct SpIns {
     u64 k[4], h, old;
     u32 pos;
 };
-__device__ __forceinline__ void sp_insert_begin(SpWork* W, const SpState& s, SpIns& I) {
+template <class TagP>
+MJD u64 sp_claim_tag(TagP tagp, u64 h, u64 expected = 0ull) {  // atomicCAS(tag, 0, h) -> previous value (relaxed, agent scope)
+    __hip_atomic_compare_exchange_strong(tagp, &expected, h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expected;
+}
+// `real == false` (a lane that has no child in this slot of the batch) issues a compare-and-swap that cannot change the
+// tag (expected = desired = all ones), so that both probes of a batch are unconditional and stay in flight together.
+template <class WP>
+__device__ __forceinline__ void sp_insert_begin(WP W, const SpState& s, SpIns& I, bool real = true) {
     sp_key(s, I.k);
     I.h = sp_hash(I.k);
     I.pos = (u32)(I.h >> 20) & (SP_CAP - 1);
-    I.old = atomicCAS((unsigned long long*)&W->tag[I.pos], 0ull, (unsigned long long)I.h);
+    I.old = sp_claim_tag(&W->tag[I.pos], real ? I.h : ~0ull, real ? 0ull : ~0ull);
 }
-__device__ __forceinline__ int sp_insert_finish(SpWork* W, SpCtx* X, SpIns& I, bool& fresh) {
+template <class WP>
+__device__ __forceinline__ int sp_insert_finish(WP W, SpCtx* X, SpIns& I, bool& fresh) {
     fresh = false;
     u64 old = I.old;
     u32 pos = I.pos;
     for (int probe = 0; probe < SP_CAP; probe++) {
         if (old == 0ull) {
-            SpNode& n = W->node[pos];
+            auto& n = W->node[pos];
             n.k0 = I.k[0]; n.k1 = I.k[1]; n.k2 = I.k[2]; n.k3 = I.k[3];
             fresh = true;
             return (int)pos;
         }
         if (old == I.h) return (int)pos;
         pos = (pos + 1) & (SP_CAP - 1);
-        old = atomicCAS((unsigned long long*)&W->tag[pos], 0ull, (unsigned long long)I.h);
+        old = sp_claim_tag(&W->tag[pos], I.h);
     }
     X->overflow = 1;
     return -1;
@@ -195,7 +228,8 @@ __device__ int sp_lookup(const SpWork* W, const SpState& s) {
     }
     return -1;
 }
-MJD SpState sp_state_of(const SpNode& n) {
+template <class NodeT>
+MJD SpState sp_state_of(const NodeT& n) {
     SpState s;
     s.h.mp = n.k0;
     s.h.sz = n.k1 & 0xFFFFFFFFFFFFull;
@@ -294,7 +328,7 @@ struct SpTeam {
         struct {             // level > 0 evaluation
             float buf[SP_CH][3][SP_T];          // values of the current batch of children, one turn per lane
             unsigned short cs[SP_CCAP];         // child slots
-            unsigned short meta[SP_CCAP];       // discard tile | last-of-group << 6 | draw count << 7
+            unsigned short meta[SP_CCAP];       // discard order key (9 bits) | last-of-group << 9 | draw count << 10
         } ev;
     } u;
 };
@@ -334,14 +368,14 @@ struct SpQuarter {  // sp_eval_team<8>: at most 8 draws left, four states per 32
 __device__ __forceinline__ void sp_partial_merges(SpTeam* TM, const ShBase& B, int ld3, int ln) {
     if (ln < 6) {
         const int a = ln < 3 ? 0 : ln < 5 ? 1 : 2, b = ln < 3 ? ln + 1 : ln < 5 ? ln - 1 : 3;
-        TM->r2[ln] = sh_merge(B.row[a], B.row[b], ld3);
+        TM->r2[ln] = sh_merge(B.row_of(a), B.row_of(b), ld3);
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     if (ln < 4) {
         // others of suit 0: (1,2)+3, of 1: (0,2)+3, of 2: (0,1)+3, of 3: (0,1)+2
         const u64 pr = ln == 0 ? TM->r2[3] : ln == 1 ? TM->r2[1] : TM->r2[0];
-        TM->r3[ln] = sh_merge(pr, B.row[ln == 3 ? 2 : 3], ld3);
+        TM->r3[ln] = sh_merge(pr, ln == 3 ? B.row[2] : B.row[3], ld3);
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -352,13 +386,26 @@ __device__ __forceinline__ void sp_partial_merges(SpTeam* TM, const ShBase& B, i
 //   probe : team per state — which draws win (34 shanten probes)        -> node.req, one work item per draw entry
 //   score : THREAD per item, dense across the workgroup                  -> 4 scores per item in the node (keep[] area)
 //   sum   : team per state — sp_eval_team(L = 0) accumulates the scores in the reference's order
-__device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot) {
+__device__ __noinline__ void sp_l0_probe(SpWork* W, SpCtx* X, SpTeam* TM, int slot) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(TM);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int ln = threadIdx.x & 31;
     const int sh32 = threadIdx.x & 32;
-    SpNode& node = W->node[slot];
+    SP_HBM SpNode& node = Wg->node[slot];
     const SpState S = sp_state_of(node);
     const int ld3 = X->len_div3;
-    const ShBase B = sh_base(Tb, S.h);
+    // all table gathers of the state go out first (4 base rows + the two probe rounds; their keys are arithmetic on the base
+    // keys), the partial merges then run while the probe rows are still in flight
+    const ShTab ST = sh_tab(c_mj_tables);
+    const ShBase B = sh_base(ST, S.h);
+    u64 rv[2];
+#pragma unroll
+    for (int rnd = 0; rnd < 2; rnd++) {
+        const int t = min(ln + 32 * rnd, 33), st = sh_suit(t);
+        const u32 kb = B.key_of(st);
+        rv[rnd] = sh_load(ST, st, S.w.get(t) > 0 ? kb + sh_pow(t) : kb);
+    }
     sp_partial_merges(TM, B, ld3, ln);
     u64 req = 0;
 #pragma unroll
@@ -367,8 +414,7 @@ __device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* 
         bool is_req = false;
         if (t < 34 && S.w.get(t) > 0) {
             const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
-            const u64 r = sh_load(Tb, st, B.key[st] + sh_pow(t));
-            const int sh = sh_finish(sh_final(TM->r3[st], r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
+            const int sh = sh_finish(sh_final(TM->r3[st], rv[rnd], ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
                                      B.kpairs + (yao && hc == 1), B.kkinds + (yao && hc == 0));
             is_req = sh == -1;
         }
@@ -400,22 +446,23 @@ __device__ void sp_l0_probe(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* 
     }
     base = __shfl(base, 0, 32);
     if (ln < cnt) {
-        if (base + ln < SP_ITEMS) W->items[base + ln] = (u32)slot | ((u32)ln << 14) | mine;
+        if (base + ln < SP_ITEMS) Wg->items[base + ln] = (u32)slot | ((u32)ln << 14) | mine;
         else X->overflow = 1;
     }
 }
-__device__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
+__device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
+    SP_ASSUME_LDS(X);
     const int slot = item & 0x3FFF, idx = (item >> 14) & 31, t = (item >> 19) & 63, variant = (item >> 25) & 1;
-    SpNode& node = W->node[slot];
+    SP_HBM SpNode& node = ((SP_HBM SpWork*)W)->node[slot];
     SpState S1 = sp_state_of(node);
     const int tile = variant ? akaize(t) : t;
     sp_deal(S1, tile);
     float scv[4];
     if (sp_get_score(Tb, X, S1, tile, scv)) {
-        float2* dst = reinterpret_cast<float2*>(node.keep) + 2 * idx;  // node.keep is 8-byte aligned
-        dst[0] = make_float2(scv[0], scv[1]);
-        dst[1] = make_float2(scv[2], scv[3]);
-        atomicOr(&node.child_off, 1u << idx);
+        SP_HBM float* dst = reinterpret_cast<SP_HBM float*>(node.keep) + 4 * idx;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[q] = scv[q];
+        __hip_atomic_fetch_or(&node.child_off, 1u << idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -426,10 +473,13 @@ __device__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u3
 //   A  34 "+t" shanten probes, one lane per tile (1 gather each)          -> required set (ballot); rows of h-d
 //   B  (required t, d) "-d" probes over the tile kinds in the hand; only same-suit pairs need a gather -> keep[t]
 //   C  children (t, variant, keep d): compacted into an LDS list, hash-set insert -> child slots in the pool
-__device__ void sp_expand_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
+__device__ __noinline__ void sp_expand_team(SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(TM);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int ln = threadIdx.x & 31;
     const int sh32 = threadIdx.x & 32;  // bit offset of this team inside the wave's 64-bit ballot
-    SpNode& node = W->node[slot];
+    SP_HBM SpNode& node = Wg->node[slot];
     const SpState S = sp_state_of(node);
     const int ld3 = X->len_div3;
     u64 req = 0;
@@ -437,18 +487,29 @@ __device__ void sp_expand_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTea
 
     {
         // ---- A
-        const ShBase B = sh_base(Tb, S.h);
+        // all table gathers of the phase go out first: 4 base rows + per round the rows of h + t and h - t (their keys are
+        // arithmetic on the base keys; a lane without a probe re-reads its base row, so the loads are unconditional);
+        // the partial merges then run while the probe rows are in flight
+        const ShTab ST = sh_tab(c_mj_tables);
+        const ShBase B = sh_base(ST, S.h);
+        u64 rv[2], rdv[2];
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int t = min(ln + 32 * rnd, 33), st = sh_suit(t);
+            const u32 kb = B.key_of(st), pw = sh_pow(t);
+            rv[rnd] = sh_load(ST, st, S.w.get(t) > 0 ? kb + pw : kb);
+            rdv[rnd] = sh_load(ST, st, S.h.get(t) > 0 ? kb - pw : kb);
+        }
         sp_partial_merges(TM, B, ld3, ln);
 #pragma unroll
         for (int rnd = 0; rnd < 2; rnd++) {
             const int t = ln + 32 * rnd;
             bool is_req = false;
             if (t < 34) {
-                u64 r = 0, rd = 0;
                 const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
-                if (hc > 0) rd = sh_load(Tb, st, B.key[st] - sh_pow(t));
-                if (S.w.get(t) > 0) {
-                    r = sh_load(Tb, st, B.key[st] + sh_pow(t));
+                const bool in_wall = S.w.get(t) > 0;
+                const u64 r = in_wall ? rv[rnd] : 0ull, rd = hc > 0 ? rdv[rnd] : 0ull;
+                if (in_wall) {
                     int sh = sh_finish(sh_final(TM->r3[st], r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
                                        B.kpairs + (yao && hc == 1), B.kkinds + (yao && hc == 0));
                     is_req = sh - L == -1;
@@ -511,8 +572,8 @@ __device__ void sp_expand_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTea
                     dd[q] = d;
                     valid[q] = valid[q] && (ki < n_kinds || !((hmask >> t) & 1));
                     const int st = sh_suit(t);
-                    rdv[q] = 0;
-                    if (valid[q] && sh_suit(d) == st && d != t) rdv[q] = sh_load(Tb, st, B.key[st] + sh_pow(t) - sh_pow(d));
+                    const u32 kb = B.key_of(st);  // unconditional load (base row when no gather is needed): 4 in flight per lane
+                    rdv[q] = sh_load(ST, st, (valid[q] && sh_suit(d) == st && d != t) ? kb + sh_pow(t) - sh_pow(d) : kb);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -522,7 +583,7 @@ __device__ void sp_expand_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTea
                     const int st = sh_suit(t), sd = sh_suit(d);
                     const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
                     int fin;
-                    if (sd == st) fin = sh_final(TM->r3[st], d == t ? B.row[st] : rdv[q], ld3);
+                    if (sd == st) fin = sh_final(TM->r3[st], d == t ? B.row_of(st) : rdv[q], ld3);
                     else fin = sh_final(TM->u.ex.U[tii[q]][sd - (sd > st)], TM->u.ex.rowd[d], ld3);
                     const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
                     const int kpairs = B.kpairs + (yt && hct == 1) - (yd && c == 2), kkinds = B.kkinds + (yt && hct == 0) - (yd && c == 1);
@@ -604,19 +665,22 @@ __device__ void sp_expand_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTea
                 };
                 auto child_done = [&](int i, SpIns& I) {
                     bool fresh;
-                    const int cs = sp_insert_finish(W, X, I, fresh);
+                    const int cs = sp_insert_finish(Wg, X, I, fresh);
                     if (fresh && cs >= 0) {
                         int idx = atomicAdd(&X->n_list, 1);
-                        if (idx < SP_CAP) W->list[idx] = (u32)cs;
+                        if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
                         else X->overflow = 1;
                     }
-                    if (cpos + i < SP_POOL) W->pool[cpos + i] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
+                    if (cpos + i < SP_POOL) Wg->pool[cpos + i] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
                 };
                 for (int i = ln; i < n_ch; i += 64) {
                     const bool two = i + 32 < n_ch;
                     SpIns Ia, Ib;
-                    sp_insert_begin(W, child_state(i), Ia);
-                    if (two) sp_insert_begin(W, child_state(i + 32), Ib);
+                    sp_insert_begin(Wg, child_state(i), Ia);
+                    sp_insert_begin(Wg, child_state(two ? i + 32 : i), Ib, two);
+                    // both atomics are issued before either result is looked at (the empty asm redefines both results, so
+                    // the compiler cannot test the first one — and wait for it — before the second one is on its way)
+                    asm volatile("" : "+v"(Ia.old), "+v"(Ib.old));
                     child_done(i, Ia);
                     if (two) child_done(i + 32, Ib);
                 }
@@ -634,33 +698,44 @@ __device__ void sp_expand_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, SpTea
 // row has at most 16 draws left (always, except during the first go-around of a kyoku): two states then share the 32
 // lanes that one used to occupy, halving the instructions issued per state in the accumulate-bound evaluation pass.
 template <int TW, class TMT>
-__device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM, int slot, int L) {
+__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot, int L) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(TM);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int ln = threadIdx.x & (TW - 1);
-    SpNode& node = W->node[slot];
+    SP_HBM SpNode& node = Wg->node[slot];
     const SpState S = sp_state_of(node);
     const int T = X->T;
     float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
     u64 req = 0;
     int child_base = 0;
     u32 l0_yaku = 0;  // level 0: bit i = draw entry i has a yaku
-    if (L > 0) {
-        // level > 0: the expansion pass left req / keep / child slots in the node; fetch them in one round trip
-        req = node.req;
-        child_base = (int)node.child_off;
+    {
+        // One round trip for everything the node holds: key (above), req, child_off and the 272-byte keep[] area — the
+        // keep sets left by the expansion pass (L > 0) or, in the same bytes, the 17 x 4 scores of sp_l0_score (L == 0).
+        constexpr int NR = (34 + TW - 1) / TW;
+        u64 kv[NR];
 #pragma unroll
-        for (int rnd = 0; rnd < (34 + TW - 1) / TW; rnd++) {
+        for (int rnd = 0; rnd < NR; rnd++) {
             const int t = ln + TW * rnd;
-            if (t < 34) TM->keep[t] = node.keep[t];
+            kv[rnd] = node.keep[min(t, 33)];
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-    } else {
-        // level 0: sp_l0_probe left the winning draws in node.req, sp_l0_score the scores of every draw entry
         req = node.req;
-        l0_yaku = __hip_atomic_load(&node.child_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // set by L2 atomics
-        const float* src = reinterpret_cast<const float*>(node.keep);
-        float* dst = &TM->u.sc[0][0];
-        for (int i = ln; i < SP_L0_MAX * 4; i += TW) dst[i] = src[i];
+        if (L > 0) child_base = (int)node.child_off;
+        else l0_yaku = __hip_atomic_load(&node.child_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // set by L2 atomics
+        u32* sc32 = reinterpret_cast<u32*>(&TM->u.sc[0][0]);  // float[17][4] == 34 x 8 bytes
+#pragma unroll
+        for (int rnd = 0; rnd < NR; rnd++) {
+            const int t = ln + TW * rnd;
+            if (t < 34) {
+                if (L > 0) {
+                    TM->keep[t] = kv[rnd];
+                } else {
+                    sc32[2 * t] = (u32)kv[rnd];
+                    sc32[2 * t + 1] = (u32)(kv[rnd] >> 32);
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
     }
@@ -692,7 +767,7 @@ __device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM
                 int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
                                (int)(X->calc_haitei && j == T - 1);
                 acc_w += prob;
-                acc_e += prob * scores[han_plus];
+                acc_e += prob * (han_plus == 0 ? scores[0] : han_plus == 1 ? scores[1] : han_plus == 2 ? scores[2] : scores[3]);
             } else {
                 if (L == 1) acc_t += prob;
                 if (j < T - 1) {
@@ -757,7 +832,7 @@ __device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            for (int i = ln; i < n_ch; i += TW) TM->u.ev.cs[i] = W->pool[min(cpos + i, SP_POOL - 1)];
+            for (int i = ln; i < n_ch; i += TW) TM->u.ev.cs[i] = Wg->pool[min(cpos + i, SP_POOL - 1)];
             // per-child metadata, one lane per draw entry (tile, variant)
             for (int g = ln; g < 2 * (ti_end - ti_next); g += TW) {
                 const int t = TM->tiles[ti_next + (g >> 1)], variant = g & 1;
@@ -779,14 +854,14 @@ __device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM
                     if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
                     else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
                     else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
-                    TM->u.ev.meta[pos] = (unsigned short)(dt | ((k == nk - 1) ? 64 : 0) | (count << 7));
+                    TM->u.ev.meta[pos] = (unsigned short)(sp_discard_key(dt) | ((k == nk - 1) ? 512 : 0) | (count << 10));
                 }
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
             // discard_slow (calc.rs:570-637) fold state of the current draw entry
             float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
-            int max_value = INT_MIN, max_tile = T_UNK;
+            int max_value = INT_MIN, max_key = sp_discard_key(T_UNK);
             for (int c0 = 0; c0 < n_ch; c0 += TMT::CH) {
                 float v[TMT::CH][3];
 #pragma unroll
@@ -795,7 +870,7 @@ __device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM
                     if (c0 + q < n_ch && ln < T) {
                         const int cs = TM->u.ev.cs[c0 + q];
                         if (cs != 0xFFFF) {
-                            const SpNode& ch = W->node[cs];
+                            const SP_HBM SpNode& ch = Wg->node[cs];
                             v[q][0] = ch.tenpai[ln];
                             v[q][1] = ch.win[ln];
                             v[q][2] = ch.ev[ln];
@@ -818,20 +893,20 @@ __device__ void sp_eval_team(const MjTablesDev& Tb, SpWork* W, SpCtx* X, TMT* TM
                     } else if (ln < T) {
                         const float ce = TM->u.ev.buf[q][2][ln];
                         const int value = (int)ce;  // `as i32` (maximize_win_prob = false)
-                        const int dt = m & 63;
-                        if (value > max_value || (value == max_value && cmp_discard_priority(dt, max_tile) > 0)) {
+                        const int key = m & 511;  // cmp_discard_priority(dt, max_tile) > 0  <=>  key > max_key
+                        if (value > max_value || (value == max_value && key > max_key)) {
                             nx_t = TM->u.ev.buf[q][0][ln];
                             nx_w = TM->u.ev.buf[q][1][ln];
                             nx_e = ce;
                             max_value = value;
-                            max_tile = dt;
+                            max_key = key;
                         }
                     }
-                    if (m & 64) {  // last child of this draw entry
-                        accumulate(m >> 7, nx_t, nx_w, nx_e, false, nullptr);
+                    if (m & 512) {  // last child of this draw entry
+                        accumulate(m >> 10, nx_t, nx_w, nx_e, false, nullptr);
                         nx_t = nx_w = nx_e = -3.40282347e+38f;
                         max_value = INT_MIN;
-                        max_tile = T_UNK;
+                        max_key = sp_discard_key(T_UNK);
                     }
                 }
             }
@@ -1050,21 +1125,25 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
         // All shanten numbers here are of hands one or two tiles away from the root hand, so they are incremental probes
         // (one table gather + one final merge step) on partial merges shared by the whole row, spread over the workgroup.
         auto& SU = s_tm.setup;
-        const ShBase RB = sh_base(c_mj_tables, root.h);
+        const ShTab ST = sh_tab(c_mj_tables);
+        const ShBase RB = sh_base(ST, root.h);
         const u64 root_mask = root.h.nonzero_mask();
         if (tid < 6) {
             const int a = tid < 3 ? 0 : tid < 5 ? 1 : 2, b = tid < 3 ? tid + 1 : tid < 5 ? tid - 1 : 3;
-            SU.r2[tid] = sh_merge(RB.row[a], RB.row[b], ld3);
+            SU.r2[tid] = sh_merge(RB.row_of(a), RB.row_of(b), ld3);
         } else if (tid >= 64 && tid < 98) {
             const int t = tid - 64, st = sh_suit(t);
-            SU.rowt[t] = root.w.get(t) > 0 ? sh_load(c_mj_tables, st, RB.key[st] + sh_pow(t)) : 0ull;
-            SU.rowd[t] = (can_discard && ((root_mask >> t) & 1)) ? sh_load(c_mj_tables, st, RB.key[st] - sh_pow(t)) : 0ull;
+            const u32 kb = RB.key_of(st), pw = sh_pow(t);
+            const bool in_wall = root.w.get(t) > 0, in_hand = can_discard && ((root_mask >> t) & 1);
+            const u64 rt = sh_load(ST, st, in_wall ? kb + pw : kb), rd = sh_load(ST, st, in_hand ? kb - pw : kb);
+            SU.rowt[t] = in_wall ? rt : 0ull;
+            SU.rowd[t] = in_hand ? rd : 0ull;
         }
         if (tid < SP_MAX_CAND) { SU.req[tid] = 0; SU.nreq[tid] = 0; }
         __syncthreads();
         if (tid < 4) {
             const u64 pr = tid == 0 ? SU.r2[3] : tid == 1 ? SU.r2[1] : SU.r2[0];
-            SU.r3[tid] = sh_merge(pr, RB.row[tid == 3 ? 2 : 3], ld3);
+            SU.r3[tid] = sh_merge(pr, tid == 3 ? RB.row[2] : RB.row[3], ld3);
         } else if (can_discard && tid >= 64 && tid < 64 + 34 * 3) {
             const int d = (tid - 64) / 3, k = (tid - 64) % 3;
             if ((root_mask >> d) & 1) {
@@ -1121,7 +1200,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                     sh_new = calc_all(c_mj_tables, root.h, ld3);  // root - d + d
                 } else {
                     int fin;
-                    if (sd == st) fin = sh_final(SU.r3[st], sh_load(c_mj_tables, st, RB.key[st] + sh_pow(t) - sh_pow(d)), ld3);
+                    if (sd == st) fin = sh_final(SU.r3[st], sh_load(ST, st, RB.key_of(st) + sh_pow(t) - sh_pow(d)), ld3);
                     else fin = sh_final(SU.U[d][st - (st > sd)], SU.rowt[t], ld3);
                     sh_new = sh_finish(fin, ld3, RB.pairs - (hd == 2) + (ht == 1), RB.kinds - (hd == 1) + (ht == 0),
                                        RB.kpairs - (yd && hd == 2) + (yt && ht == 1), RB.kkinds - (yd && hd == 1) + (yt && ht == 0));
@@ -1168,7 +1247,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_expand_team(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_expand_team(W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 __syncthreads();
                 if (tid == 0) {
                     X.lvl_begin[lv - 1] = e;
@@ -1183,7 +1262,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
-                    for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_l0_probe(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i]);
+                    for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_l0_probe(W, &X, &s_team[tid >> 5], (int)W->list[i]);
                     __syncthreads();
                     const int n_items = min(X.n_items, SP_ITEMS);
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
@@ -1191,13 +1270,13 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 }
                 if (T <= 8) {
                     for (int i = b + (tid >> 3); i < e; i += SP_THREADS / 8)
-                        sp_eval_team<8, SpQuarter>(c_mj_tables, W, &X, &s_tm.quarter[tid >> 3], (int)W->list[i], lv);
+                        sp_eval_team<8, SpQuarter>(W, &X, &s_tm.quarter[tid >> 3], (int)W->list[i], lv);
                 } else if (T <= 16) {
                     for (int i = b + (tid >> 4); i < e; i += SP_THREADS / 16)
-                        sp_eval_team<16, SpHalf>(c_mj_tables, W, &X, &s_tm.half[tid >> 4], (int)W->list[i], lv);
+                        sp_eval_team<16, SpHalf>(W, &X, &s_tm.half[tid >> 4], (int)W->list[i], lv);
                 } else {
                     for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32)
-                        sp_eval_team<32, SpTeam>(c_mj_tables, W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                        sp_eval_team<32, SpTeam>(W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 }
                 __syncthreads();
                 if (lv == 0) t_3 = wall_clock64();
