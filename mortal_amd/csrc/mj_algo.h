@@ -12,8 +12,10 @@
 
 #include "mj_state.h"
 
+#ifndef MJD  // tests/host_algo_check.hip defines both as __host__ __device__ to run the pure functions on the CPU
 #define MJD __device__ __forceinline__
 #define MJDN __device__ __noinline__
+#endif
 
 typedef uint8_t u8;
 typedef uint32_t u32;
@@ -272,7 +274,26 @@ MJD u64 sh_merge(u64 a, u64 b, int m) {
     for (int j = 0; j < 10; j++) r |= (u64)(v[j] & 15) << (4 * j);
     return r;
 }
-MJD int sh_final(u64 a, u64 b, int m) {  // entry 5+m of merge(a, b): m mentsu + the pair
+// Entry 5+m of merge(a, b) (m mentsu + the pair) = min over x = 0..m of  a[5+x] + b[m-x]  and  a[m-x] + b[5+x]
+// (sh_add_jihai_final with its loop written out).  To keep every nibble index static for a run-time m, the low halves
+// are shifted up by 4-m nibbles and the vacated nibbles filled with 15: term x then reads nibble 4-x, and the terms with
+// x > m read the filler, i.e. are >= 15 and never below the x = m term (a[5+m] + b[0], b[0] = 0 in every row).
+MJD int sh_final(u64 a, u64 b, int m) {
+    const u32 s = 4u * (u32)(4 - m);
+    const u32 fill = (1u << s) - 1u;
+    const u32 as = (((u32)a & 0xFFFFFu) << s) | fill, bs = (((u32)b & 0xFFFFFu) << s) | fill;
+    const u32 ah = (u32)(a >> 20), bh = (u32)(b >> 20);
+    int r = 255;
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        const int f1 = (int)((ah >> (4 * x)) & 15u) + (int)((bs >> (4 * (4 - x))) & 15u);
+        const int f2 = (int)((as >> (4 * (4 - x))) & 15u) + (int)((bh >> (4 * x)) & 15u);
+        r = min(r, min(f1, f2));
+    }
+    return r;
+}
+// the same through the reference-shaped loop (shanten.rs:71-80); kept for the host-side equivalence check
+MJD int sh_final_ref(u64 a, u64 b, int m) {
     int v[10];
     sh_unpack(a, v);
     return sh_add_jihai_final(v, b, m);

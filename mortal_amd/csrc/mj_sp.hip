@@ -470,8 +470,8 @@ __device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const
 // the shanten-keeping discards, insert every child state (level L-1) into the hash set, and leave req / keep / child
 // slots in the node for the evaluation pass.  The work is organised in PHASES whose table / hash-set gathers are
 // independent and in flight together, and nothing is gathered twice:
-//   A  34 "+t" shanten probes, one lane per tile (1 gather each)          -> required set (ballot); rows of h-d
-//   B  (required t, d) "-d" probes over the tile kinds in the hand; only same-suit pairs need a gather -> keep[t]
+//   A  34 "+t" and "-t" shanten probes, one lane per tile                  -> required set, safe-discard set (ballots)
+//   B  (required t, safe d) probes of h + t - d; only same-suit pairs need a gather                      -> keep[t]
 //   C  children (t, variant, keep d): compacted into an LDS list, hash-set insert -> child slots in the pool
 __device__ __noinline__ void sp_expand_team(SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
     SP_ASSUME_LDS(X);
@@ -501,26 +501,38 @@ __device__ __noinline__ void sp_expand_team(SpWork* W, SpCtx* X, SpTeam* TM, int
             rdv[rnd] = sh_load(ST, st, S.h.get(t) > 0 ? kb - pw : kb);
         }
         sp_partial_merges(TM, B, ld3, ln);
+        // `safe`: the tile kinds d in the hand with shanten(h - d) <= L.  Only those can be shanten-keeping discards after a
+        // required draw t: shanten(h + t - d) == L - 1 needs shanten(h - d) <= L, since one more tile lowers a shanten
+        // number (normal, chiitoi and kokushi form alike) by at most one.  Phase B probes (t, d) for these kinds only.
+        u64 safe = 0;
 #pragma unroll
         for (int rnd = 0; rnd < 2; rnd++) {
             const int t = ln + 32 * rnd;
-            bool is_req = false;
+            bool is_req = false, is_safe = false;
             if (t < 34) {
                 const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
                 const bool in_wall = S.w.get(t) > 0;
                 const u64 r = in_wall ? rv[rnd] : 0ull, rd = hc > 0 ? rdv[rnd] : 0ull;
+                const u64 r3 = TM->r3[st];
                 if (in_wall) {
-                    int sh = sh_finish(sh_final(TM->r3[st], r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
+                    int sh = sh_finish(sh_final(r3, r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
                                        B.kpairs + (yao && hc == 1), B.kkinds + (yao && hc == 0));
                     is_req = sh - L == -1;
+                }
+                if (hc > 0) {
+                    int sh = sh_finish(sh_final(r3, rd, ld3), ld3, B.pairs - (hc == 2), B.kinds - (hc == 1),
+                                       B.kpairs - (yao && hc == 2), B.kkinds - (yao && hc == 1));
+                    is_safe = sh <= L;
                 }
                 TM->u.ex.rowt[t] = r;
                 TM->u.ex.rowd[t] = rd;
                 TM->keep[t] = 0;
             }
-            const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull;
+            const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull, bal_s = (__ballot(is_safe) >> sh32) & 0xFFFFFFFFull;
             req |= bal << (32 * rnd);
+            safe |= bal_s << (32 * rnd);
         }
+        safe &= (1ull << 34) - 1;
         req &= (1ull << 34) - 1;
         const int n_tiles = __popcll(req);
 #pragma unroll
@@ -543,11 +555,11 @@ __device__ __noinline__ void sp_expand_team(SpWork* W, SpCtx* X, SpTeam* TM, int
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            // ---- B2: (required t, d) probes over the tile kinds actually in the hand (+ the drawn tile itself), four
-            // items per lane and round so that their gathers overlap:
+            // ---- B2: (required t, d) probes over the `safe` kinds of the hand, two items per lane and round so that their
+            // gathers overlap (d == t never keeps: h + t - t is the state itself, one shanten higher):
             // same suit -> final(r3[suit], gathered row of h+t-d); other suit -> final(U[t][suit d], row of h-d)
-            const u64 hmask = S.h.nonzero_mask();
-            const int n_kinds = __popcll(hmask), stride = n_kinds + 1;
+            const u64 hmask = safe;
+            const int n_kinds = __popcll(hmask);
 #pragma unroll
             for (int rnd = 0; rnd < 2; rnd++) {
                 const int t = ln + 32 * rnd;
@@ -555,35 +567,35 @@ __device__ __noinline__ void sp_expand_team(SpWork* W, SpCtx* X, SpTeam* TM, int
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            const int n_items = n_tiles * stride;
-            for (int base = 0; base < n_items; base += 128) {
-                u64 rdv[4];
-                int tt[4], dd[4], tii[4];
-                bool valid[4];
+            const int n_items = n_tiles * n_kinds;
+            // item / n_kinds by multiply-shift: exact while item * n_kinds < 65536 (item < 34 * 14)
+            const u32 inv = n_kinds > 0 ? (65536u + (u32)n_kinds - 1u) / (u32)n_kinds : 0u;
+            for (int base = 0; base < n_items; base += 64) {
+                u64 rdv[2];
+                int tt[2], dd[2], tii[2];
+                bool valid[2];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int item = base + q * 32 + ln;
-                    valid[q] = item < n_items;
-                    const int ti = min(item, n_items - 1) / stride, ki = min(item, n_items - 1) % stride;
-                    const int t = TM->tiles[ti];
-                    const int d = ki < n_kinds ? TM->kinds[ki] : t;  // last slot: the drawn tile when it is a new kind
+                for (int q = 0; q < 2; q++) {
+                    const int item = base + q * 32 + ln, it = min(item, n_items - 1);
+                    const int ti = (int)(((u32)it * inv) >> 16), ki = it - ti * n_kinds;
+                    const int t = TM->tiles[ti], d = TM->kinds[ki];
                     tii[q] = ti;
                     tt[q] = t;
                     dd[q] = d;
-                    valid[q] = valid[q] && (ki < n_kinds || !((hmask >> t) & 1));
+                    valid[q] = item < n_items && d != t;
                     const int st = sh_suit(t);
-                    const u32 kb = B.key_of(st);  // unconditional load (base row when no gather is needed): 4 in flight per lane
-                    rdv[q] = sh_load(ST, st, (valid[q] && sh_suit(d) == st && d != t) ? kb + sh_pow(t) - sh_pow(d) : kb);
+                    const u32 kb = B.key_of(st);  // unconditional load (base row when no gather is needed)
+                    rdv[q] = sh_load(ST, st, (valid[q] && sh_suit(d) == st) ? kb + sh_pow(t) - sh_pow(d) : kb);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < 2; q++) {
                     if (!valid[q]) continue;
                     const int t = tt[q], d = dd[q];
-                    const int c = S.h.get(d) + (d == t);  // count of d after the draw
+                    const int c = S.h.get(d);  // count of d after the draw (d != t)
                     const int st = sh_suit(t), sd = sh_suit(d);
                     const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
                     int fin;
-                    if (sd == st) fin = sh_final(TM->r3[st], d == t ? B.row_of(st) : rdv[q], ld3);
+                    if (sd == st) fin = sh_final(TM->r3[st], rdv[q], ld3);
                     else fin = sh_final(TM->u.ex.U[tii[q]][sd - (sd > st)], TM->u.ex.rowd[d], ld3);
                     const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
                     const int kpairs = B.kpairs + (yt && hct == 1) - (yd && c == 2), kkinds = B.kkinds + (yt && hct == 0) - (yd && c == 1);

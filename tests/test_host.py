@@ -100,3 +100,23 @@ def test_rankings_reference_vectors():
         for p in range(4):
             st = Stat.from_game(ev, p)
             assert [st.rank_1, st.rank_2, st.rank_3, st.rank_4].index(1) == rank_by_player[p]
+
+
+def test_device_helpers_host_equivalence(tmp_path):
+    """The optimised pure helpers of mj_algo.h (static-index sh_final) against their reference-shaped formulations, compiled
+    for the host by hipcc (tests/host/algo_check.hip; no GPU involved)."""
+    import shutil
+    import subprocess
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        import pytest
+
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "algo_check")
+    src = os.path.join(os.path.dirname(__file__), "host", "algo_check.hip")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-value", "-o", exe, src],
+                          stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sh_final == reference-shaped loop" in out.stdout
