@@ -706,6 +706,287 @@ __device__ __noinline__ void sp_expand_team(SpWork* W, SpCtx* X, SpTeam* TM, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense expansion / level-0 probe: SP_NS states of one level at a time, every phase a THREAD-PER-TASK pass over the whole
+// workgroup (tasks = (state, suit), (state, merge), (state, tile), (state, draw tile, discard kind) ...), separated by
+// workgroup barriers.  The team formulation above spends most of its instruction stream with few lanes busy (6 of 32 in
+// the partial merges, 2 of 32 in the second probe round, ...); here every lane of every wave runs a task, so the
+// instructions issued per state drop by about 4x.  Arithmetic, table probes and the resulting req / keep sets / child
+// order are exactly those of sp_expand_team / sp_l0_probe.
+#define SP_NS 16
+struct SpChunk {
+    u64 k[SP_NS][4];        // state keys (hand.mp, hand.sz | akas, wall.mp, wall.sz | akas)
+    u64 row[SP_NS][4];      // base table rows of the four suits
+    u64 r2[SP_NS][6];       // merges of two base rows (suit pairs 01 02 03 12 13 23)
+    u64 r3[SP_NS][4];       // per suit: merge of the three OTHER base rows
+    u64 rowt[SP_NS][34];    // row of h + t in suit(t) (0 when t is not in the wall)
+    u64 rowd[SP_NS][34];    // row of h - d in suit(d) (0 when d is not in the hand)
+    u64 V[SP_NS][13][3];    // per safe discard kind d and k-th other suit: merge(two untouched suits, row of h - d)
+    u64 keep[SP_NS][34];    // per required tile t: shanten-keeping discards of h + t
+    u64 req[SP_NS], safe[SP_NS];
+    u32 bkey[SP_NS][4];     // base-5 suit keys
+    u32 slot[SP_NS];
+    int cnt[SP_NS][4];      // pairs, kinds, yaokyuu pairs, yaokyuu kinds (shanten.rs:104-137)
+    int item_off[SP_NS + 1];  // prefix sums of n_tiles * n_kinds
+    int child_base[SP_NS];
+    unsigned short coff[SP_NS][34];  // per required tile: offset of its first child inside the state's child list
+    u8 tiles[SP_NS][36], kinds[SP_NS][16];
+    u8 n_tiles[SP_NS], n_kinds[SP_NS];
+};
+
+MJD SpState sp_chunk_state(const SpChunk* C, int s) {
+    SpState S;
+    S.h.mp = C->k[s][0];
+    S.h.sz = C->k[s][1] & 0xFFFFFFFFFFFFull;
+    S.w.mp = C->k[s][2];
+    S.w.sz = C->k[s][3] & 0xFFFFFFFFFFFFull;
+    S.akas = (u32)((C->k[s][1] >> 48) & 7) | ((u32)((C->k[s][3] >> 48) & 7) << 3);
+    return S;
+}
+
+// Passes P0-P3, shared by the expansion (L >= 1) and the level-0 probe (L == 0): state keys, base rows, partial merges
+// and the 34 "+t" (and for L >= 1 "-t") shanten probes of every state of the chunk -> req, safe, rowt, rowd.
+__device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunk* C, const ShTab& ST, int first, int n, int L) {
+    const int tid = threadIdx.x;
+    const int ld3 = X->len_div3;
+    // P0a: keys
+    for (int task = tid; task < n * 4; task += SP_THREADS) {
+        const int s = task >> 2, j = task & 3;
+        const u32 slot = Wg->list[first + s];
+        C->k[s][j] = reinterpret_cast<const SP_HBM u64*>(&Wg->node[slot])[j];  // k0..k3 lead the node
+        if (j == 0) {
+            C->slot[s] = slot;
+            C->req[s] = 0;
+            C->safe[s] = 0;
+        }
+    }
+    __syncthreads();
+    // P0b: suit keys, base rows, chiitoi / kokushi counters
+    for (int task = tid; task < n * 4; task += SP_THREADS) {
+        const int s = task >> 2, i = task & 3;
+        const SpState S = sp_chunk_state(C, s);
+        const u32 key = i == 0 ? suit_key9(S.h.mp) : i == 1 ? suit_key9(S.h.mp >> 27) : i == 2 ? suit_key9(S.h.sz) : suit_key7(S.h.sz >> 27);
+        C->bkey[s][i] = key;
+        C->row[s][i] = sh_load(ST, i, key);
+        C->cnt[s][i] = i == 0 ? S.h.n_pairs() : i == 1 ? S.h.n_kinds() : i == 2 ? S.h.n_yao_pairs() : S.h.n_yao_kinds();
+    }
+    __syncthreads();
+    // P1: merges of two base rows
+    for (int task = tid; task < n * 6; task += SP_THREADS) {
+        const int s = task / 6, p = task % 6;
+        const int a = p < 3 ? 0 : p < 5 ? 1 : 2, b = p < 3 ? p + 1 : p < 5 ? p - 1 : 3;
+        C->r2[s][p] = sh_merge(C->row[s][a], C->row[s][b], ld3);
+    }
+    __syncthreads();
+    // P2: per suit the merge of the three other base rows: 0: (1,2)+3, 1: (0,2)+3, 2: (0,1)+3, 3: (0,1)+2
+    for (int task = tid; task < n * 4; task += SP_THREADS) {
+        const int s = task >> 2, i = task & 3;
+        const u64 pr = i == 0 ? C->r2[s][3] : i == 1 ? C->r2[s][1] : C->r2[s][0];
+        C->r3[s][i] = sh_merge(pr, C->row[s][i == 3 ? 2 : 3], ld3);
+    }
+    __syncthreads();
+    // P3: probes (state, tile)
+    for (int task = tid; task < n * 34; task += SP_THREADS) {
+        const int s = task / 34, t = task % 34;
+        const SpState S = sp_chunk_state(C, s);
+        const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
+        const bool in_wall = S.w.get(t) > 0, in_hand = L > 0 && hc > 0;
+        const u32 kb = C->bkey[s][st], pw = sh_pow(t);
+        const u64 rt = sh_load(ST, st, in_wall ? kb + pw : kb);
+        const u64 rd = sh_load(ST, st, in_hand ? kb - pw : kb);
+        const u64 r3 = C->r3[s][st];
+        const int pairs = C->cnt[s][0], kinds = C->cnt[s][1], kpairs = C->cnt[s][2], kkinds = C->cnt[s][3];
+        if (in_wall) {
+            const int sh = sh_finish(sh_final(r3, rt, ld3), ld3, pairs + (hc == 1), kinds + (hc == 0), kpairs + (yao && hc == 1),
+                                     kkinds + (yao && hc == 0));
+            if (sh - L == -1) atomicOr((unsigned long long*)&C->req[s], 1ull << t);
+        }
+        if (in_hand) {  // see sp_expand_team: only discards with shanten(h - d) <= L can keep shanten after a required draw
+            const int sh = sh_finish(sh_final(r3, rd, ld3), ld3, pairs - (hc == 2), kinds - (hc == 1), kpairs - (yao && hc == 2),
+                                     kkinds - (yao && hc == 1));
+            if (sh <= L) atomicOr((unsigned long long*)&C->safe[s], 1ull << t);
+        }
+        C->rowt[s][t] = in_wall ? rt : 0ull;
+        C->rowd[s][t] = in_hand ? rd : 0ull;
+        C->keep[s][t] = 0;
+    }
+    __syncthreads();
+}
+
+// Level 0: which draws win (node.req) and one scoring work item per draw entry, in the reference's order (plain tile if a
+// non-red copy is left, then the red five).
+__device__ __noinline__ void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, int first, int n) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(C);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const ShTab ST = sh_tab(c_mj_tables);
+    sp_chunk_probe(Wg, X, C, ST, first, n, 0);
+    const int s = threadIdx.x;
+    if (s < n) {
+        const SpState S = sp_chunk_state(C, s);
+        const u64 req = C->req[s];
+        const u32 slot = C->slot[s];
+        int cnt = 0;
+        for (u64 rest = req; rest; rest &= rest - 1) {
+            const int t = __ffsll((long long)rest) - 1;
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            cnt += (!aka_in_wall || S.w.get(t) >= 2) + aka_in_wall;
+        }
+        if (cnt > SP_L0_MAX) { X->overflow = 1; cnt = SP_L0_MAX; }
+        const int base = atomicAdd(&X->n_items, cnt);
+        int e = 0;
+        for (u64 rest = req; rest; rest &= rest - 1) {
+            const int t = __ffsll((long long)rest) - 1;
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            for (int variant = 0; variant < 2; variant++) {
+                if (variant == 0 ? (aka_in_wall && S.w.get(t) < 2) : !aka_in_wall) continue;
+                if (e < cnt) {
+                    if (base + e < SP_ITEMS) Wg->items[base + e] = slot | ((u32)e << 14) | ((u32)t << 19) | ((u32)variant << 25);
+                    else X->overflow = 1;
+                }
+                e++;
+            }
+        }
+        SP_HBM SpNode& node = Wg->node[slot];
+        node.req = req;
+        node.child_off = 0;  // bit i: draw entry i has a yaku (set by sp_l0_score)
+    }
+    __syncthreads();
+}
+
+// Levels >= 1: required draws, shanten-keeping discards and the children of SP_NS states.
+__device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, int first, int n, int L) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(C);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const ShTab ST = sh_tab(c_mj_tables);
+    const int tid = threadIdx.x;
+    const int ld3 = X->len_div3;
+    sp_chunk_probe(Wg, X, C, ST, first, n, L);
+    // P4a: ascending lists of the required tiles and of the safe discard kinds
+    for (int task = tid; task < n * 34; task += SP_THREADS) {
+        const int s = task / 34, t = task % 34;
+        const u64 req = C->req[s], safe = C->safe[s], below = (1ull << t) - 1;
+        if ((req >> t) & 1) C->tiles[s][__popcll(req & below)] = (u8)t;
+        if ((safe >> t) & 1) C->kinds[s][__popcll(safe & below)] = (u8)t;
+        if (t == 0) {
+            C->n_tiles[s] = (u8)__popcll(req);
+            C->n_kinds[s] = (u8)__popcll(safe);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int off = 0;
+        for (int s = 0; s < n; s++) {
+            C->item_off[s] = off;
+            off += (int)C->n_tiles[s] * (int)C->n_kinds[s];
+        }
+        C->item_off[n] = off;
+    }
+    // P4b: per safe discard kind d and each of the three other suits: V = merge(two untouched suits, row of h - d)
+    for (int task = tid; task < n * 39; task += SP_THREADS) {
+        const int s = task / 39, q = task % 39, ki = q / 3, k = q % 3;
+        if (ki >= (int)C->n_kinds[s]) continue;
+        const int d = C->kinds[s][ki], sd = sh_suit(d), st = k + (k >= sd);  // k-th suit != sd
+        int x = -1, y = -1;  // the two suits other than st and sd
+        for (int i = 0; i < 4; i++)
+            if (i != st && i != sd) { if (x < 0) x = i; else y = i; }
+        C->V[s][ki][k] = sh_merge(C->r2[s][sh_pair_idx(x, y)], C->rowd[s][d], ld3);
+    }
+    __syncthreads();
+    // P5: (state, required t, safe d) probes of h + t - d (d == t never keeps: that is the state itself):
+    // same suit -> final(r3[suit], gathered row of h+t-d); other suit -> final(V[d][suit t], row of h+t)
+    const int n_items = C->item_off[n];
+    auto item_decode = [&](int it, int& s, int& t, int& d, int& ki) {
+        s = 0;
+        while (s + 1 < n && C->item_off[s + 1] <= it) s++;
+        const int local = it - C->item_off[s], nk = C->n_kinds[s];
+        const int ti = local / nk;
+        ki = local - ti * nk;
+        t = C->tiles[s][ti];
+        d = C->kinds[s][ki];
+    };
+    for (int it = tid; it < n_items; it += SP_THREADS) {
+        int s, t, d, ki;
+        item_decode(it, s, t, d, ki);
+        if (d == t) continue;
+        const SpState S = sp_chunk_state(C, s);
+        const int st = sh_suit(t), sd = sh_suit(d);
+        const int c = S.h.get(d), hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
+        int fin;
+        if (sd == st) fin = sh_final(C->r3[s][st], sh_load(ST, st, C->bkey[s][st] + sh_pow(t) - sh_pow(d)), ld3);
+        else fin = sh_final(C->V[s][ki][st - (st > sd)], C->rowt[s][t], ld3);
+        const int pairs = C->cnt[s][0] + (hct == 1) - (c == 2), kinds = C->cnt[s][1] + (hct == 0) - (c == 1);
+        const int kpairs = C->cnt[s][2] + (yt && hct == 1) - (yd && c == 2), kkinds = C->cnt[s][3] + (yt && hct == 0) - (yd && c == 1);
+        if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0) atomicOr((unsigned long long*)&C->keep[s][t], 1ull << d);
+    }
+    __syncthreads();
+    // P6: child list layout per state (for each required tile `variants(t) * popcount(keep[t])` slots) + node header
+    if (tid < n) {
+        const int s = tid;
+        const SpState S = sp_chunk_state(C, s);
+        int total = 0;
+        const int nt = C->n_tiles[s];
+        for (int ti = 0; ti < nt; ti++) {
+            const int t = C->tiles[s][ti];
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
+            C->coff[s][t] = (unsigned short)total;
+            total += nvar * __popcll(C->keep[s][t]);
+        }
+        int child_base = atomicAdd(&X->n_pool, total);
+        if (child_base + total > SP_POOL) { X->overflow = 1; child_base = 0; }
+        C->child_base[s] = child_base;
+        SP_HBM SpNode& node = Wg->node[C->slot[s]];
+        node.child_off = (u32)child_base;
+        node.req = C->req[s];
+    }
+    for (int task = tid; task < n * 34; task += SP_THREADS) {
+        const int s = task / 34, t = task % 34;
+        Wg->node[C->slot[s]].keep[t] = C->keep[s][t];
+    }
+    __syncthreads();
+    // P7: children — the kept (t, d) of the same item space; each inserts its child state(s) (one per existing draw variant
+    // of t) into the hash set and leaves the slot at its place of the reference's order (t, variant, d ascending)
+    for (int it = tid; it < n_items; it += SP_THREADS) {
+        int s, t, d, ki;
+        item_decode(it, s, t, d, ki);
+        const u64 keep = C->keep[s][t];
+        if (d == t || !((keep >> d) & 1)) continue;
+        const SpState S = sp_chunk_state(C, s);
+        const int nk = __popcll(keep), rank = __popcll(keep & ((1ull << d) - 1));
+        const int cnt = S.w.get(t);
+        const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+        for (int variant = 0; variant < 2; variant++) {
+            int vidx;  // index of this variant among the tile's existing draw entries
+            if (!aka_in_wall) { if (variant == 1) continue; vidx = 0; }
+            else if (variant == 0) { if (cnt < 2) continue; vidx = 0; }
+            else vidx = cnt >= 2 ? 1 : 0;
+            const int tile = (aka_in_wall && variant == 1) ? akaize(t) : t;
+            SpState S2 = S;
+            sp_deal(S2, tile);
+            const int c = S2.h.get(d);
+            int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+            if (d == T_5M && (S2.akas & 1) && c == 1) dt = T_5MR;
+            else if (d == T_5P && (S2.akas & 2) && c == 1) dt = T_5PR;
+            else if (d == T_5S && (S2.akas & 4) && c == 1) dt = T_5SR;
+            sp_discard(S2, dt);
+            SpIns I;
+            sp_insert_begin(Wg, S2, I);
+            bool fresh;
+            const int cs = sp_insert_finish(Wg, X, I, fresh);
+            if (fresh && cs >= 0) {
+                const int idx = atomicAdd(&X->n_list, 1);
+                if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
+                else X->overflow = 1;
+            }
+            const int pos = C->child_base[s] + (int)C->coff[s][t] + vidx * nk + rank;
+            if (pos < SP_POOL) Wg->pool[pos] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
+        }
+    }
+    __syncthreads();
+}
+
 // Evaluate one state (tenpai/win/ev arrays of its node) with a TEAM of TW lanes, one turn per lane.  TW = 16 whenever the
 // row has at most 16 draws left (always, except during the first go-around of a kyoku): two states then share the 32
 // lanes that one used to occupy, halving the instructions issued per state in the accumulate-bound evaluation pass.
@@ -964,6 +1245,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ int s_row;
     __shared__ union SpTeams {
         SpTeam full[SP_THREADS / 32];
+        SpChunk chunk;
         SpHalf half[SP_THREADS / 16];
         SpQuarter quarter[SP_THREADS / 8];
         struct {                 // row set-up (candidates + their required tiles), before any team runs
@@ -1259,7 +1541,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_expand_team(W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
+                for (int c0 = b; c0 < e; c0 += SP_NS) sp_expand_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0), lv);
                 __syncthreads();
                 if (tid == 0) {
                     X.lvl_begin[lv - 1] = e;
@@ -1274,7 +1556,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
-                    for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32) sp_l0_probe(W, &X, &s_team[tid >> 5], (int)W->list[i]);
+                    for (int c0 = b; c0 < e; c0 += SP_NS) sp_l0_probe_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0));
                     __syncthreads();
                     const int n_items = min(X.n_items, SP_ITEMS);
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);

@@ -29,6 +29,20 @@ int main() {
             n++;
         }
     }
+    // the partial merges may be taken in any order (the SP kernel merges the untouched suits with the row of h - d first and
+    // finishes with the row of h + t, or the other way round)
+    for (int it = 0; it < 1000000; it++) {
+        const u64 a = random_row(g, 14), b = random_row(g, 14), c = random_row(g, 14), d = random_row(g, 14);
+        for (int m = 0; m <= 4; m++) {
+            const u64 ab = sh_merge(a, b, m);
+            const int x = sh_final(sh_merge(ab, c, m), d, m), y = sh_final(sh_merge(ab, d, m), c, m);
+            const int z = sh_final(sh_merge(sh_merge(b, a, m), d, m), c, m);
+            if (x != y || x != z) {
+                printf("merge order mismatch m=%d: %d %d %d\n", m, x, y, z);
+                return 3;
+            }
+        }
+    }
     // all-zero rows (keys past the table, `unwrap_or_default`)
     for (int m = 0; m <= 4; m++)
         if (sh_final(0, 0, m) != sh_final_ref(0, 0, m)) return 2;

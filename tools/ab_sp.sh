@@ -5,8 +5,9 @@
 cd /root/repo; mkdir -p gpurun_out/ab
 ( timeout 60 python __graft_entry__.py smoke && timeout 80 python -m pytest tests/test_gpu_state.py tests/test_gpu_parity.py -m gpu -x -q \
     -k "random_hands or greedy_policy_v4" ) > gpurun_out/ab/parity.log 2>&1
-echo "parity rc=$?" | tee -a gpurun_out/ab/parity.log
+rc=$?; echo "parity rc=$rc" | tee -a gpurun_out/ab/parity.log
 grep -a "smoke\|passed\|failed\|Error" gpurun_out/ab/parity.log | tail -6
+if [ $rc -ne 0 ]; then tail -c 6000 gpurun_out/ab/parity.log; exit 1; fi   # no bench on a library that is not bit-exact
 libs="libmortal_amd.so"; [ "$1" = prev ] && libs="libmortal_amd_prev.so libmortal_amd.so"
 for lib in $libs; do
   [ -f mortal_amd/$lib ] || continue
