@@ -6,9 +6,9 @@
 // states with order-sensitive f32 sums.  On the GPU the same values are produced LEVEL-SYNCHRONOUSLY, one decision row
 // per (persistent) workgroup at a time:
 //   set-up   : candidates and their required tiles as workgroup-parallel incremental shanten probes;
-//   expand   : for shanten level L = s .. 1, every 3n+1 state of level L (a 32-lane team per state, sp_expand_team)
-//              finds its required draws t and the shanten-keeping discards d of h+t and inserts the children h+t-d into
-//              a per-workgroup hash set (64-bit tag claimed by atomicCAS);
+//   expand   : for shanten level L = s .. 1, the 3n+1 states of level L in chunks of 16 (sp_expand_chunk: thread-per-task
+//              passes over the whole workgroup) find their required draws t and the shanten-keeping discards d of h+t and
+//              insert the children h+t-d into a per-workgroup hash set (64-bit tag claimed by atomicCAS);
 //   evaluate : for L = 0 .. s: level 0 in three passes (probe / dense thread-per-item scoring / sum), levels > 0 by
 //              teams of 32, 16 or 8 lanes (one lane per remaining draw, sp_eval_team) that reproduce
 //              draw_without_tegawari (calc.rs:447-561) with the reference's exact loop order (draw tiles ascending, aka
@@ -17,6 +17,8 @@
 // f32 results as long as each state's own accumulation order is kept — it is.  Compiled with -ffp-contract=off
 // (Rust never fuses a*b+c).  DESIGN.md §6 has the cost model and the optimisation history.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "mj_rules.h"
 
@@ -306,24 +308,15 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
     return true;
 }
 
-// Per-team LDS scratch of sp_expand_team / sp_eval_team<32>.
+// Per-team LDS scratch of sp_eval_team<32> (rows with more than 16 draws left).
 #define SP_CH 8      // children gathered per batch in the evaluation pass
 #define SP_CCAP 256  // children staged per super-chunk (a required tile has at most 2 x 14)
 struct SpTeam {
     static constexpr int CH = SP_CH, CCAP = SP_CCAP;
     u64 keep[34];            // per required tile t: set of shanten-keeping discards of h + t
-    u64 r2[6];               // merges of two base rows (suit pairs 01 02 03 12 13 23), see mj_algo.h sh_merge
-    u64 r3[4];               // per suit s: merge of the three OTHER base rows
     int coff[34];            // per required tile t: offset of its first child inside the node's child list
     u8 tiles[36];            // required tiles in ascending order
-    u8 kinds[16];            // tile kinds present in the hand (<= 14), ascending
     union {
-        struct {
-            u64 rowt[34];    // expand: table row of (h + t) in suit(t)
-            u64 rowd[34];    //         table row of (h - d) in suit(d)
-            unsigned short items[SP_CCAP];  // children of the current super-chunk: t | d << 6 | variant << 12
-            u64 U[34][3];    // per required tile t and k-th other suit: merge(two untouched suits, row of h + t)
-        } ex;
         float sc[SP_L0_MAX][4];  // level 0: get_score() of every draw entry (filled by sp_l0_score through the node)
         struct {             // level > 0 evaluation
             float buf[SP_CH][3][SP_T];          // values of the current batch of children, one turn per lane
@@ -364,92 +357,11 @@ struct SpQuarter {  // sp_eval_team<8>: at most 8 draws left, four states per 32
     } u;
 };
 
-// Partial merges of a state's four base rows, shared by all of its probes (lanes 0..5, then 0..3 of the team).
-__device__ __forceinline__ void sp_partial_merges(SpTeam* TM, const ShBase& B, int ld3, int ln) {
-    if (ln < 6) {
-        const int a = ln < 3 ? 0 : ln < 5 ? 1 : 2, b = ln < 3 ? ln + 1 : ln < 5 ? ln - 1 : 3;
-        TM->r2[ln] = sh_merge(B.row_of(a), B.row_of(b), ld3);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    if (ln < 4) {
-        // others of suit 0: (1,2)+3, of 1: (0,2)+3, of 2: (0,1)+3, of 3: (0,1)+2
-        const u64 pr = ln == 0 ? TM->r2[3] : ln == 1 ? TM->r2[1] : TM->r2[0];
-        TM->r3[ln] = sh_merge(pr, ln == 3 ? B.row[2] : B.row[3], ld3);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-}
-
 // ---- Level 0 (tenpai states) is evaluated in three passes so that the expensive, divergent scoring of the winning
-// draws (get_score: agari decomposition + yaku + fu) runs with every lane busy instead of ~3 lanes per 32-lane team:
-//   probe : team per state — which draws win (34 shanten probes)        -> node.req, one work item per draw entry
+// draws (get_score: agari decomposition + yaku + fu) runs with every lane busy:
+//   probe : sp_l0_probe_chunk — which draws win (34 shanten probes per state) -> node.req, one work item per draw entry
 //   score : THREAD per item, dense across the workgroup                  -> 4 scores per item in the node (keep[] area)
 //   sum   : team per state — sp_eval_team(L = 0) accumulates the scores in the reference's order
-__device__ __noinline__ void sp_l0_probe(SpWork* W, SpCtx* X, SpTeam* TM, int slot) {
-    SP_ASSUME_LDS(X);
-    SP_ASSUME_LDS(TM);
-    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const int ln = threadIdx.x & 31;
-    const int sh32 = threadIdx.x & 32;
-    SP_HBM SpNode& node = Wg->node[slot];
-    const SpState S = sp_state_of(node);
-    const int ld3 = X->len_div3;
-    // all table gathers of the state go out first (4 base rows + the two probe rounds; their keys are arithmetic on the base
-    // keys), the partial merges then run while the probe rows are still in flight
-    const ShTab ST = sh_tab(c_mj_tables);
-    const ShBase B = sh_base(ST, S.h);
-    u64 rv[2];
-#pragma unroll
-    for (int rnd = 0; rnd < 2; rnd++) {
-        const int t = min(ln + 32 * rnd, 33), st = sh_suit(t);
-        const u32 kb = B.key_of(st);
-        rv[rnd] = sh_load(ST, st, S.w.get(t) > 0 ? kb + sh_pow(t) : kb);
-    }
-    sp_partial_merges(TM, B, ld3, ln);
-    u64 req = 0;
-#pragma unroll
-    for (int rnd = 0; rnd < 2; rnd++) {
-        const int t = ln + 32 * rnd;
-        bool is_req = false;
-        if (t < 34 && S.w.get(t) > 0) {
-            const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
-            const int sh = sh_finish(sh_final(TM->r3[st], rv[rnd], ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
-                                     B.kpairs + (yao && hc == 1), B.kkinds + (yao && hc == 0));
-            is_req = sh == -1;
-        }
-        const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull;
-        req |= bal << (32 * rnd);
-    }
-    req &= (1ull << 34) - 1;
-    // draw entries in the reference's order: plain tile (if a non-red copy is left), then the red five
-    int cnt = 0;
-    u32 mine = 0;
-    for (u64 rest = req; rest; rest &= rest - 1) {
-        const int t = __ffsll((long long)rest) - 1;
-        const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-        if (!aka_in_wall || S.w.get(t) >= 2) {
-            if (ln == cnt) mine = (u32)t << 19;
-            cnt++;
-        }
-        if (aka_in_wall) {
-            if (ln == cnt) mine = ((u32)t << 19) | (1u << 25);
-            cnt++;
-        }
-    }
-    if (cnt > SP_L0_MAX) { X->overflow = 1; cnt = SP_L0_MAX; }
-    int base = 0;
-    if (ln == 0) {
-        base = atomicAdd(&X->n_items, cnt);
-        node.req = req;
-        node.child_off = 0;  // bit i: draw entry i has a yaku (set by sp_l0_score)
-    }
-    base = __shfl(base, 0, 32);
-    if (ln < cnt) {
-        if (base + ln < SP_ITEMS) Wg->items[base + ln] = (u32)slot | ((u32)ln << 14) | mine;
-        else X->overflow = 1;
-    }
-}
 __device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
     SP_ASSUME_LDS(X);
     const int slot = item & 0x3FFF, idx = (item >> 14) & 31, t = (item >> 19) & 63, variant = (item >> 25) & 1;
@@ -466,253 +378,16 @@ __device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const
     }
 }
 
-// Expand one 3n+1 state of shanten level L >= 1 with a TEAM of 32 lanes (half a wavefront): find the required draws and
-// the shanten-keeping discards, insert every child state (level L-1) into the hash set, and leave req / keep / child
-// slots in the node for the evaluation pass.  The work is organised in PHASES whose table / hash-set gathers are
-// independent and in flight together, and nothing is gathered twice:
-//   A  34 "+t" and "-t" shanten probes, one lane per tile                  -> required set, safe-discard set (ballots)
-//   B  (required t, safe d) probes of h + t - d; only same-suit pairs need a gather                      -> keep[t]
-//   C  children (t, variant, keep d): compacted into an LDS list, hash-set insert -> child slots in the pool
-__device__ __noinline__ void sp_expand_team(SpWork* W, SpCtx* X, SpTeam* TM, int slot, int L) {
-    SP_ASSUME_LDS(X);
-    SP_ASSUME_LDS(TM);
-    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const int ln = threadIdx.x & 31;
-    const int sh32 = threadIdx.x & 32;  // bit offset of this team inside the wave's 64-bit ballot
-    SP_HBM SpNode& node = Wg->node[slot];
-    const SpState S = sp_state_of(node);
-    const int ld3 = X->len_div3;
-    u64 req = 0;
-    int child_base = 0;
-
-    {
-        // ---- A
-        // all table gathers of the phase go out first: 4 base rows + per round the rows of h + t and h - t (their keys are
-        // arithmetic on the base keys; a lane without a probe re-reads its base row, so the loads are unconditional);
-        // the partial merges then run while the probe rows are in flight
-        const ShTab ST = sh_tab(c_mj_tables);
-        const ShBase B = sh_base(ST, S.h);
-        u64 rv[2], rdv[2];
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int t = min(ln + 32 * rnd, 33), st = sh_suit(t);
-            const u32 kb = B.key_of(st), pw = sh_pow(t);
-            rv[rnd] = sh_load(ST, st, S.w.get(t) > 0 ? kb + pw : kb);
-            rdv[rnd] = sh_load(ST, st, S.h.get(t) > 0 ? kb - pw : kb);
-        }
-        sp_partial_merges(TM, B, ld3, ln);
-        // `safe`: the tile kinds d in the hand with shanten(h - d) <= L.  Only those can be shanten-keeping discards after a
-        // required draw t: shanten(h + t - d) == L - 1 needs shanten(h - d) <= L, since one more tile lowers a shanten
-        // number (normal, chiitoi and kokushi form alike) by at most one.  Phase B probes (t, d) for these kinds only.
-        u64 safe = 0;
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int t = ln + 32 * rnd;
-            bool is_req = false, is_safe = false;
-            if (t < 34) {
-                const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
-                const bool in_wall = S.w.get(t) > 0;
-                const u64 r = in_wall ? rv[rnd] : 0ull, rd = hc > 0 ? rdv[rnd] : 0ull;
-                const u64 r3 = TM->r3[st];
-                if (in_wall) {
-                    int sh = sh_finish(sh_final(r3, r, ld3), ld3, B.pairs + (hc == 1), B.kinds + (hc == 0),
-                                       B.kpairs + (yao && hc == 1), B.kkinds + (yao && hc == 0));
-                    is_req = sh - L == -1;
-                }
-                if (hc > 0) {
-                    int sh = sh_finish(sh_final(r3, rd, ld3), ld3, B.pairs - (hc == 2), B.kinds - (hc == 1),
-                                       B.kpairs - (yao && hc == 2), B.kkinds - (yao && hc == 1));
-                    is_safe = sh <= L;
-                }
-                TM->u.ex.rowt[t] = r;
-                TM->u.ex.rowd[t] = rd;
-                TM->keep[t] = 0;
-            }
-            const u64 bal = (__ballot(is_req) >> sh32) & 0xFFFFFFFFull, bal_s = (__ballot(is_safe) >> sh32) & 0xFFFFFFFFull;
-            req |= bal << (32 * rnd);
-            safe |= bal_s << (32 * rnd);
-        }
-        safe &= (1ull << 34) - 1;
-        req &= (1ull << 34) - 1;
-        const int n_tiles = __popcll(req);
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int t = ln + 32 * rnd;
-            if (t < 34 && ((req >> t) & 1)) TM->tiles[__popcll(req & ((1ull << t) - 1))] = (u8)t;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-
-        {
-            // ---- B1: per required tile t and each of the three other suits: U = merge(two untouched suits, row of h+t)
-            for (int item = ln; item < n_tiles * 3; item += 32) {
-                const int ti = item / 3, k = item % 3, t = TM->tiles[ti];
-                const int st = sh_suit(t), sd = k + (k >= st);  // k-th suit != st
-                int x = -1, y = -1;  // the two suits other than st and sd
-                for (int q = 0; q < 4; q++)
-                    if (q != st && q != sd) { if (x < 0) x = q; else y = q; }
-                TM->u.ex.U[ti][k] = sh_merge(TM->r2[sh_pair_idx(x, y)], TM->u.ex.rowt[t], ld3);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            // ---- B2: (required t, d) probes over the `safe` kinds of the hand, two items per lane and round so that their
-            // gathers overlap (d == t never keeps: h + t - t is the state itself, one shanten higher):
-            // same suit -> final(r3[suit], gathered row of h+t-d); other suit -> final(U[t][suit d], row of h-d)
-            const u64 hmask = safe;
-            const int n_kinds = __popcll(hmask);
-#pragma unroll
-            for (int rnd = 0; rnd < 2; rnd++) {
-                const int t = ln + 32 * rnd;
-                if (t < 34 && ((hmask >> t) & 1)) TM->kinds[__popcll(hmask & ((1ull << t) - 1))] = (u8)t;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            const int n_items = n_tiles * n_kinds;
-            // item / n_kinds by multiply-shift: exact while item * n_kinds < 65536 (item < 34 * 14)
-            const u32 inv = n_kinds > 0 ? (65536u + (u32)n_kinds - 1u) / (u32)n_kinds : 0u;
-            for (int base = 0; base < n_items; base += 64) {
-                u64 rdv[2];
-                int tt[2], dd[2], tii[2];
-                bool valid[2];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int item = base + q * 32 + ln, it = min(item, n_items - 1);
-                    const int ti = (int)(((u32)it * inv) >> 16), ki = it - ti * n_kinds;
-                    const int t = TM->tiles[ti], d = TM->kinds[ki];
-                    tii[q] = ti;
-                    tt[q] = t;
-                    dd[q] = d;
-                    valid[q] = item < n_items && d != t;
-                    const int st = sh_suit(t);
-                    const u32 kb = B.key_of(st);  // unconditional load (base row when no gather is needed)
-                    rdv[q] = sh_load(ST, st, (valid[q] && sh_suit(d) == st) ? kb + sh_pow(t) - sh_pow(d) : kb);
-                }
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    if (!valid[q]) continue;
-                    const int t = tt[q], d = dd[q];
-                    const int c = S.h.get(d);  // count of d after the draw (d != t)
-                    const int st = sh_suit(t), sd = sh_suit(d);
-                    const int hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
-                    int fin;
-                    if (sd == st) fin = sh_final(TM->r3[st], rdv[q], ld3);
-                    else fin = sh_final(TM->u.ex.U[tii[q]][sd - (sd > st)], TM->u.ex.rowd[d], ld3);
-                    const int pairs = B.pairs + (hct == 1) - (c == 2), kinds = B.kinds + (hct == 0) - (c == 1);
-                    const int kpairs = B.kpairs + (yt && hct == 1) - (yd && c == 2), kkinds = B.kkinds + (yt && hct == 0) - (yd && c == 1);
-                    if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0)
-                        atomicOr((unsigned long long*)&TM->keep[t], 1ull << d);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            // child list layout: for each required tile, `variants(t) * popcount(keep[t])` slots
-            int total = 0;
-            for (int ti = 0; ti < n_tiles; ti++) {
-                const int t = TM->tiles[ti];
-                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-                const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
-                total += nvar * __popcll(TM->keep[t]);
-            }
-            if (ln == 0) {
-                child_base = atomicAdd(&X->n_pool, total);
-                if (child_base + total > SP_POOL) { X->overflow = 1; child_base = 0; }
-                node.child_off = (u32)child_base;
-                node.req = req;
-            }
-            child_base = __shfl(child_base, 0, 32);
-            if (ln < 2) {
-                for (int t = ln; t < 34; t += 2) node.keep[t] = TM->keep[t];
-            }
-            // ---- C: children, in super-chunks of at most SP_CCAP.  The (t, variant, d) triples are first compacted
-            // into an LDS list (one lane per draw entry), then every lane inserts children i, i+32 with both first
-            // hash probes in flight.
-            int ti_next = 0, cpos = child_base;
-            while (ti_next < n_tiles) {
-                int n_ch = 0, ti_end = ti_next;
-                while (ti_end < n_tiles) {
-                    const int t = TM->tiles[ti_end];
-                    const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-                    const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
-                    const int c = nvar * __popcll(TM->keep[t]);
-                    if (n_ch + c > SP_CCAP) break;
-                    if (ln == 0) TM->coff[t] = n_ch;
-                    n_ch += c;
-                    ti_end++;
-                }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-                for (int g = ln; g < 2 * (ti_end - ti_next); g += 32) {
-                    const int t = TM->tiles[ti_next + (g >> 1)], variant = g & 1;
-                    const int cnt = S.w.get(t);
-                    const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-                    int vidx;  // index of this variant among the tile's existing draw entries
-                    if (!aka_in_wall) { if (variant == 1) continue; vidx = 0; }
-                    else if (variant == 0) { if (cnt < 2) continue; vidx = 0; }
-                    else vidx = cnt >= 2 ? 1 : 0;
-                    u64 rest = TM->keep[t];
-                    const int nk = __popcll(rest);
-                    int pos = TM->coff[t] + vidx * nk;
-                    for (int k = 0; k < nk; k++, pos++) {
-                        const int d = __ffsll((long long)rest) - 1;
-                        rest &= rest - 1;
-                        TM->u.ex.items[pos] = (unsigned short)(t | (d << 6) | (variant << 12));
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-                auto child_state = [&](int i) {
-                    const int it = TM->u.ex.items[i];
-                    const int t = it & 63, d = (it >> 6) & 63, variant = it >> 12;
-                    const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
-                    const int tile = (aka_in_wall && variant == 1) ? akaize(t) : t;
-                    SpState S2 = S;
-                    sp_deal(S2, tile);
-                    const int c = S2.h.get(d);
-                    int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
-                    if (d == T_5M && (S2.akas & 1) && c == 1) dt = T_5MR;
-                    else if (d == T_5P && (S2.akas & 2) && c == 1) dt = T_5PR;
-                    else if (d == T_5S && (S2.akas & 4) && c == 1) dt = T_5SR;
-                    sp_discard(S2, dt);
-                    return S2;
-                };
-                auto child_done = [&](int i, SpIns& I) {
-                    bool fresh;
-                    const int cs = sp_insert_finish(Wg, X, I, fresh);
-                    if (fresh && cs >= 0) {
-                        int idx = atomicAdd(&X->n_list, 1);
-                        if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
-                        else X->overflow = 1;
-                    }
-                    if (cpos + i < SP_POOL) Wg->pool[cpos + i] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
-                };
-                for (int i = ln; i < n_ch; i += 64) {
-                    const bool two = i + 32 < n_ch;
-                    SpIns Ia, Ib;
-                    sp_insert_begin(Wg, child_state(i), Ia);
-                    sp_insert_begin(Wg, child_state(two ? i + 32 : i), Ib, two);
-                    // both atomics are issued before either result is looked at (the empty asm redefines both results, so
-                    // the compiler cannot test the first one — and wait for it — before the second one is on its way)
-                    asm volatile("" : "+v"(Ia.old), "+v"(Ib.old));
-                    child_done(i, Ia);
-                    if (two) child_done(i + 32, Ib);
-                }
-                cpos += n_ch;
-                ti_next = ti_end;
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-            }
-            return;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense expansion / level-0 probe: SP_NS states of one level at a time, every phase a THREAD-PER-TASK pass over the whole
 // workgroup (tasks = (state, suit), (state, merge), (state, tile), (state, draw tile, discard kind) ...), separated by
-// workgroup barriers.  The team formulation above spends most of its instruction stream with few lanes busy (6 of 32 in
-// the partial merges, 2 of 32 in the second probe round, ...); here every lane of every wave runs a task, so the
-// instructions issued per state drop by about 4x.  Arithmetic, table probes and the resulting req / keep sets / child
-// order are exactly those of sp_expand_team / sp_l0_probe.
+// workgroup barriers.  A 32-lane team per state (the first formulation) spends most of its instruction stream with few
+// lanes busy (6 of 32 in the partial merges, 2 of 32 in the second probe round, ...); here every lane of every wave runs a
+// task, so the instructions issued per state drop by about 4x.
+// `safe` = the tile kinds d in the hand with shanten(h - d) <= L.  Only those can be shanten-keeping discards after a
+// required draw t: shanten(h + t - d) == L - 1 needs shanten(h - d) <= L, since one more tile lowers a shanten number
+// (normal, chiitoi and kokushi form alike) by at most one; the (t, d) probes run over these kinds only.  Arithmetic, table probes and the resulting req / keep sets / child
+// order are exactly those of the team formulation (git history: sp_expand_team / sp_l0_probe).
 #define SP_NS 16
 struct SpChunk {
     u64 k[SP_NS][4];        // state keys (hand.mp, hand.sz | akas, wall.mp, wall.sz | akas)
@@ -801,7 +476,7 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
                                      kkinds + (yao && hc == 0));
             if (sh - L == -1) atomicOr((unsigned long long*)&C->req[s], 1ull << t);
         }
-        if (in_hand) {  // see sp_expand_team: only discards with shanten(h - d) <= L can keep shanten after a required draw
+        if (in_hand) {  // `safe` (see below): only discards with shanten(h - d) <= L can keep shanten after a required draw
             const int sh = sh_finish(sh_final(r3, rd, ld3), ld3, pairs - (hc == 2), kinds - (hc == 1), kpairs - (yao && hc == 2),
                                      kkinds - (yao && hc == 1));
             if (sh <= L) atomicOr((unsigned long long*)&C->safe[s], 1ull << t);
@@ -987,6 +662,19 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     __syncthreads();
 }
 
+template <int J, int N, class F>
+MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_constant<N - 1>): the index is a compile-time constant
+    if constexpr (J < N) {
+        f(std::integral_constant<int, J>{});
+        sp_static_for<J + 1, N>(f);
+    }
+}
+// lane N of every 16-lane DPP row to all lanes of that row (v_*_dpp row_newbcast:N, folded into the consuming instruction)
+template <int N>
+MJD float sp_row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xF, 0xF, true));
+}
+
 // Evaluate one state (tenpai/win/ev arrays of its node) with a TEAM of TW lanes, one turn per lane.  TW = 16 whenever the
 // row has at most 16 draws left (always, except during the first go-around of a kyoku): two states then share the 32
 // lanes that one used to occupy, halving the instructions issued per state in the accumulate-bound evaluation pass.
@@ -1043,31 +731,51 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot
 
     // accumulate one draw entry (calc.rs:486-548): lane i runs j = i .. T-1; `break`s become predicates (not_tsumo is
     // monotone).  nx_* = lane i's folded child values at turn i (L > 0) or scores (L == 0).
+    // one (i = lane, j) term of calc.rs:486-548; vt/vw/ve = next[j + 1] of the folded child values, n = not_tsumo[j]
+    auto term = [&](int j, float tpj, float n, float vt, float vw, float ve, bool is_scores, const float* scores) {
+        const float prob = tpj * n / my_m;
+        if (is_scores) {
+            int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
+                           (int)(X->calc_haitei && j == T - 1);
+            acc_w += prob;
+            acc_e += prob * (han_plus == 0 ? scores[0] : han_plus == 1 ? scores[1] : han_plus == 2 ? scores[2] : scores[3]);
+        } else {
+            if (L == 1) acc_t += prob;
+            if (j < T - 1) {
+                if (L > 1) acc_t += prob * vt;
+                acc_w += prob * vw;
+                acc_e += prob * ve;
+            }
+        }
+    };
+    // accumulate one draw entry (calc.rs:486-548): lane i runs j = i .. T-1; `break`s become predicates (not_tsumo is
+    // monotone).  nx_* = lane i's folded child values at turn i (L > 0) or scores (L == 0).
     auto accumulate = [&](int count, float nx_t, float nx_w, float nx_e, bool is_scores, const float* scores) {
         const float* tp = X->tsumo_prob[count - 1];
         const bool lane_on = ln < T && my_m != 0.f;
-        // rolled on purpose: the kernel is latency-bound and occupancy-limited by registers, not by ALU issue
+        if constexpr (TW == 16) {
+            // a 16-lane team is exactly one DPP row: lane j's registers (next[j], not_tsumo[j], tsumo_prob[j]) reach the
+            // whole team through row_newbcast:j operands — no LDS traffic in the loop (unrolled: the lane is an immediate)
+            const float my_tp = ln < T ? tp[ln] : 0.f;
+            sp_static_for<0, 16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j >= T) return;  // uniform
+                const float vt = sp_row_bcast<(j + 1) & 15>(nx_t), vw = sp_row_bcast<(j + 1) & 15>(nx_w), ve = sp_row_bcast<(j + 1) & 15>(nx_e);
+                const float n = sp_row_bcast<j>(my_m), tpj = sp_row_bcast<j>(my_tp);
+                if (!(lane_on && j >= ln && n != 0.f)) return;
+                term(j, tpj, n, vt, vw, ve, is_scores, scores);
+            });
+        } else {
+            // rolled on purpose: the kernel is occupancy-limited by registers, not by code size
 #pragma unroll 1
-        for (int j = 0; j < T; j++) {
-            // next[j + 1] comes from lane j + 1 (only used when j < T - 1)
-            const float vt = __shfl(nx_t, (j + 1) & (TW - 1), TW);
-            const float vw = __shfl(nx_w, (j + 1) & (TW - 1), TW);
-            const float ve = __shfl(nx_e, (j + 1) & (TW - 1), TW);
-            const float n = nt[j];
-            if (!(lane_on && j >= ln && n != 0.f)) continue;
-            const float prob = tp[j] * n / my_m;
-            if (is_scores) {
-                int han_plus = (int)(assume_riichi && X->calc_double_riichi && ln == 0) + (int)(assume_riichi && j == ln) +
-                               (int)(X->calc_haitei && j == T - 1);
-                acc_w += prob;
-                acc_e += prob * (han_plus == 0 ? scores[0] : han_plus == 1 ? scores[1] : han_plus == 2 ? scores[2] : scores[3]);
-            } else {
-                if (L == 1) acc_t += prob;
-                if (j < T - 1) {
-                    if (L > 1) acc_t += prob * vt;
-                    acc_w += prob * vw;
-                    acc_e += prob * ve;
-                }
+            for (int j = 0; j < T; j++) {
+                // next[j + 1] comes from lane j + 1 (only used when j < T - 1)
+                const float vt = __shfl(nx_t, (j + 1) & (TW - 1), TW);
+                const float vw = __shfl(nx_w, (j + 1) & (TW - 1), TW);
+                const float ve = __shfl(nx_e, (j + 1) & (TW - 1), TW);
+                const float n = nt[j];
+                if (!(lane_on && j >= ln && n != 0.f)) continue;
+                term(j, tp[j], n, vt, vw, ve, is_scores, scores);
             }
         }
     };
