@@ -167,7 +167,7 @@ __device__ int sp_insert(SpWork* W, SpCtx* X, const SpState& s, bool& fresh) {
             fresh = true;
             return (int)pos;
         }
-        if (old == h) return (int)pos;  // same tag: key equality is verified by sp_verify after the barrier
+        if (old == h) return (int)pos;  // same 63-bit tag = same state (collision odds < 1e-11 per row)
         pos = (pos + 1) & (SP_CAP - 1);
     }
     X->overflow = 1;
