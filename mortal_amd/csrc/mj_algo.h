@@ -247,18 +247,6 @@ MJD ShBase sh_base(const MjTablesDev& T, Hand h) {
     b.kkinds = h.n_yao_kinds();
     return b;
 }
-MJD int sh_eval(u64 rm, u64 rp, u64 rs, u64 rz, int len_div3, int pairs, int kinds, int kpairs, int kkinds) {
-    int v[10];
-    sh_unpack(rm, v);
-    sh_add_suhai(v, rp, len_div3);
-    sh_add_suhai(v, rs, len_div3);
-    int s = sh_add_jihai_final(v, rz, len_div3) - 1;
-    if (s <= 0 || len_div3 < 4) return s;
-    s = min(s, 7 - pairs + (kinds >= 7 ? 0 : 7 - kinds) - 1);
-    if (s > 0) s = min(s, 14 - kkinds - (kpairs > 0) - 1);
-    return s;
-}
-
 // Min-plus merges of the per-suit rows are commutative and associative (a row = cheapest tile distance for j mentsu
 // without / with the pair; sh_add_suhai is the convolution over (mentsu count, pair flag)), and every merged entry is
 // bounded by the corresponding entry of either operand (row[0] == 0), so merged vectors still fit 10 nibbles.  Hence

@@ -212,24 +212,6 @@ __device__ __forceinline__ int sp_insert_finish(WP W, SpCtx* X, SpIns& I, bool& 
     X->overflow = 1;
     return -1;
 }
-__device__ int sp_lookup(const SpWork* W, const SpState& s) {
-    u64 k[4];
-    sp_key(s, k);
-    const u64 h = sp_hash(k);
-    u32 pos = (u32)(h >> 20) & (SP_CAP - 1);
-    for (int probe = 0; probe < SP_CAP; probe++) {
-        // tags are claimed with L2 atomics; read them at agent scope so a stale L1 line can never be observed
-        u64 t = __hip_atomic_load(&W->tag[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == h) {
-            const SpNode& n = W->node[pos];
-            if (n.k0 == k[0] && n.k1 == k[1] && n.k2 == k[2] && n.k3 == k[3]) return (int)pos;
-        } else if (t == 0ull) {
-            return -1;
-        }
-        pos = (pos + 1) & (SP_CAP - 1);
-    }
-    return -1;
-}
 template <class NodeT>
 MJD SpState sp_state_of(const NodeT& n) {
     SpState s;
@@ -923,23 +905,6 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot
     }
 }
 
-MJD u64 sp_required_tiles(const MjTablesDev& Tb, const SpState& s, int ld3, int& num) {  // state.rs:176-200
-    const int sh = calc_all(Tb, s.h, ld3);
-    u64 m = 0;
-    num = 0;
-    for (int t = 0; t < 34; t++) {
-        int c = s.w.get(t);
-        if (c == 0) continue;
-        Hand g = s.h;
-        g.inc(t);
-        if (calc_all(Tb, g, ld3) < sh) {
-            m |= BIT(t);
-            num += c;
-        }
-    }
-    num &= 0xFF;
-    return m;
-}
 MJD int f32_total_cmp(float a, float b) {
     int x = __float_as_int(a), y = __float_as_int(b);
     x ^= (int)((unsigned)(x >> 31) >> 1);
