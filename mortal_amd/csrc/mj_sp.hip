@@ -23,6 +23,9 @@
 #include "mj_rules.h"
 
 #define SP_THREADS 256
+#ifndef SP_VARIANT
+#define SP_VARIANT 0  // 1: experimental 32-state expansion chunks (see "NEXT" below; round-2 candidate)
+#endif
 #define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
@@ -644,6 +647,286 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     __syncthreads();
 }
 
+#if SP_VARIANT == 1
+// ---------------------------------------------------------------------------------------------------------------------
+// NEXT (experimental, compiled only with -DSP_VARIANT=1; NOT the default and not yet validated on a GPU): the same
+// passes over chunks of 32 states.  Nine workgroup barriers and the gather latencies of a chunk are then shared by twice as
+// many states, and the first passes fill 128-192 of the 256 lanes instead of 64-96.  To fit 32 states into the same LDS
+// the per-state scratch is slimmer: the rows of h + t / h - d are gathered again where they are needed (L2 hits) instead
+// of being kept, and the keep sets are 13-bit masks over the state's safe-discard ordinals until they are written out.
+#define SP_NS2 32
+struct SpChunk2 {
+    u64 k[SP_NS2][4];
+    u64 row[SP_NS2][4];
+    u64 r2[SP_NS2][6];
+    u64 r3[SP_NS2][4];
+    u64 V[SP_NS2][13][3];    // per safe discard kind d and k-th other suit: merge(two untouched suits, row of h - d)
+    u64 req[SP_NS2], safe[SP_NS2];
+    u32 bkey[SP_NS2][4];
+    u32 slot[SP_NS2];
+    u32 keepw[SP_NS2][17];   // per required-tile ORDINAL ti: 16-bit mask over the safe-kind ordinals, two per word
+    int item_off[SP_NS2 + 1];
+    int child_base[SP_NS2];
+    unsigned short coff[SP_NS2][34];  // per required-tile ordinal: offset of its first child inside the state's child list
+    u8 cnt[SP_NS2][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds
+    u8 tiles[SP_NS2][36], kinds[SP_NS2][16];
+    u8 n_tiles[SP_NS2], n_kinds[SP_NS2];
+};
+static_assert(sizeof(SpChunk2) <= sizeof(SpHalf) * (SP_THREADS / 16), "SpChunk2 must not grow the kernel's LDS");
+
+MJD SpState sp_chunk2_state(const SpChunk2* C, int s) {
+    SpState S;
+    S.h.mp = C->k[s][0];
+    S.h.sz = C->k[s][1] & 0xFFFFFFFFFFFFull;
+    S.w.mp = C->k[s][2];
+    S.w.sz = C->k[s][3] & 0xFFFFFFFFFFFFull;
+    S.akas = (u32)((C->k[s][1] >> 48) & 7) | ((u32)((C->k[s][3] >> 48) & 7) << 3);
+    return S;
+}
+MJD u32 sp_chunk2_keep(const SpChunk2* C, int s, int ti) { return (C->keepw[s][ti >> 1] >> (16 * (ti & 1))) & 0xFFFFu; }
+
+// passes P0-P3 (see sp_chunk_probe); req / safe only, no rows kept
+__device__ __forceinline__ void sp_chunk2_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunk2* C, const ShTab& ST, int first, int n, int L) {
+    const int tid = threadIdx.x;
+    const int ld3 = X->len_div3;
+    for (int task = tid; task < n * 4; task += SP_THREADS) {
+        const int s = task >> 2, j = task & 3;
+        const u32 slot = Wg->list[first + s];
+        C->k[s][j] = reinterpret_cast<const SP_HBM u64*>(&Wg->node[slot])[j];
+        if (j == 0) {
+            C->slot[s] = slot;
+            C->req[s] = 0;
+            C->safe[s] = 0;
+        }
+    }
+    __syncthreads();
+    for (int task = tid; task < n * 4; task += SP_THREADS) {
+        const int s = task >> 2, i = task & 3;
+        const SpState S = sp_chunk2_state(C, s);
+        const u32 key = i == 0 ? suit_key9(S.h.mp) : i == 1 ? suit_key9(S.h.mp >> 27) : i == 2 ? suit_key9(S.h.sz) : suit_key7(S.h.sz >> 27);
+        C->bkey[s][i] = key;
+        C->row[s][i] = sh_load(ST, i, key);
+        C->cnt[s][i] = (u8)(i == 0 ? S.h.n_pairs() : i == 1 ? S.h.n_kinds() : i == 2 ? S.h.n_yao_pairs() : S.h.n_yao_kinds());
+    }
+    __syncthreads();
+    for (int task = tid; task < n * 6; task += SP_THREADS) {
+        const int s = task / 6, p = task % 6;
+        const int a = p < 3 ? 0 : p < 5 ? 1 : 2, b = p < 3 ? p + 1 : p < 5 ? p - 1 : 3;
+        C->r2[s][p] = sh_merge(C->row[s][a], C->row[s][b], ld3);
+    }
+    __syncthreads();
+    for (int task = tid; task < n * 4; task += SP_THREADS) {
+        const int s = task >> 2, i = task & 3;
+        const u64 pr = i == 0 ? C->r2[s][3] : i == 1 ? C->r2[s][1] : C->r2[s][0];
+        C->r3[s][i] = sh_merge(pr, C->row[s][i == 3 ? 2 : 3], ld3);
+    }
+    __syncthreads();
+    for (int task = tid; task < n * 34; task += SP_THREADS) {
+        const int s = task / 34, t = task % 34;
+        const SpState S = sp_chunk2_state(C, s);
+        const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
+        const bool in_wall = S.w.get(t) > 0, in_hand = L > 0 && hc > 0;
+        const u32 kb = C->bkey[s][st], pw = sh_pow(t);
+        const u64 rt = sh_load(ST, st, in_wall ? kb + pw : kb);
+        const u64 rd = sh_load(ST, st, in_hand ? kb - pw : kb);
+        const u64 r3 = C->r3[s][st];
+        const int pairs = C->cnt[s][0], kinds = C->cnt[s][1], kpairs = C->cnt[s][2], kkinds = C->cnt[s][3];
+        if (in_wall) {
+            const int sh = sh_finish(sh_final(r3, rt, ld3), ld3, pairs + (hc == 1), kinds + (hc == 0), kpairs + (yao && hc == 1),
+                                     kkinds + (yao && hc == 0));
+            if (sh - L == -1) atomicOr((unsigned long long*)&C->req[s], 1ull << t);
+        }
+        if (in_hand) {
+            const int sh = sh_finish(sh_final(r3, rd, ld3), ld3, pairs - (hc == 2), kinds - (hc == 1), kpairs - (yao && hc == 2),
+                                     kkinds - (yao && hc == 1));
+            if (sh <= L) atomicOr((unsigned long long*)&C->safe[s], 1ull << t);
+        }
+        if (t < 17) C->keepw[s][t] = 0;
+    }
+    __syncthreads();
+}
+
+__device__ __noinline__ void sp_l0_probe_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, int first, int n) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(C);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const ShTab ST = sh_tab(c_mj_tables);
+    sp_chunk2_probe(Wg, X, C, ST, first, n, 0);
+    const int s = threadIdx.x;
+    if (s < n) {
+        const SpState S = sp_chunk2_state(C, s);
+        const u64 req = C->req[s];
+        const u32 slot = C->slot[s];
+        int cnt = 0;
+        for (u64 rest = req; rest; rest &= rest - 1) {
+            const int t = __ffsll((long long)rest) - 1;
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            cnt += (!aka_in_wall || S.w.get(t) >= 2) + aka_in_wall;
+        }
+        if (cnt > SP_L0_MAX) { X->overflow = 1; cnt = SP_L0_MAX; }
+        const int base = atomicAdd(&X->n_items, cnt);
+        int e = 0;
+        for (u64 rest = req; rest; rest &= rest - 1) {
+            const int t = __ffsll((long long)rest) - 1;
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            for (int variant = 0; variant < 2; variant++) {
+                if (variant == 0 ? (aka_in_wall && S.w.get(t) < 2) : !aka_in_wall) continue;
+                if (e < cnt) {
+                    if (base + e < SP_ITEMS) Wg->items[base + e] = slot | ((u32)e << 14) | ((u32)t << 19) | ((u32)variant << 25);
+                    else X->overflow = 1;
+                }
+                e++;
+            }
+        }
+        SP_HBM SpNode& node = Wg->node[slot];
+        node.req = req;
+        node.child_off = 0;
+    }
+    __syncthreads();
+}
+
+__device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, int first, int n, int L) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(C);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const ShTab ST = sh_tab(c_mj_tables);
+    const int tid = threadIdx.x;
+    const int ld3 = X->len_div3;
+    sp_chunk2_probe(Wg, X, C, ST, first, n, L);
+    // P4a: ascending lists of the required tiles and of the safe discard kinds
+    for (int task = tid; task < n * 34; task += SP_THREADS) {
+        const int s = task / 34, t = task % 34;
+        const u64 req = C->req[s], safe = C->safe[s], below = (1ull << t) - 1;
+        if ((req >> t) & 1) C->tiles[s][__popcll(req & below)] = (u8)t;
+        if ((safe >> t) & 1) C->kinds[s][__popcll(safe & below)] = (u8)t;
+        if (t == 0) {
+            C->n_tiles[s] = (u8)__popcll(req);
+            C->n_kinds[s] = (u8)__popcll(safe);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int off = 0;
+        for (int s = 0; s < n; s++) {
+            C->item_off[s] = off;
+            off += (int)C->n_tiles[s] * (int)C->n_kinds[s];
+        }
+        C->item_off[n] = off;
+    }
+    // P4b: V = merge(two untouched suits, row of h - d), the row gathered again (it was probed in P3: an L2 hit)
+    for (int task = tid; task < n * 39; task += SP_THREADS) {
+        const int s = task / 39, q = task % 39, ki = q / 3, k = q % 3;
+        if (ki >= (int)C->n_kinds[s]) continue;
+        const int d = C->kinds[s][ki], sd = sh_suit(d), st = k + (k >= sd);
+        int x = -1, y = -1;
+        for (int i = 0; i < 4; i++)
+            if (i != st && i != sd) { if (x < 0) x = i; else y = i; }
+        const u64 rowd = sh_load(ST, sd, C->bkey[s][sd] - sh_pow(d));
+        C->V[s][ki][k] = sh_merge(C->r2[s][sh_pair_idx(x, y)], rowd, ld3);
+    }
+    __syncthreads();
+    // P5: (state, required t, safe d) probes of h + t - d
+    const int n_items = C->item_off[n];
+    auto item_decode = [&](int it, int& s, int& ti, int& ki) {
+        int lo = 0, hi = n;  // largest s with item_off[s] <= it
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (C->item_off[mid] <= it) lo = mid; else hi = mid;
+        }
+        s = lo;
+        const int local = it - C->item_off[s], nk = C->n_kinds[s];
+        ti = local / nk;
+        ki = local - ti * nk;
+    };
+    for (int it = tid; it < n_items; it += SP_THREADS) {
+        int s, ti, ki;
+        item_decode(it, s, ti, ki);
+        const int t = C->tiles[s][ti], d = C->kinds[s][ki];
+        if (d == t) continue;
+        const SpState S = sp_chunk2_state(C, s);
+        const int st = sh_suit(t), sd = sh_suit(d);
+        const int c = S.h.get(d), hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
+        // one gather either way: the row of h+t-d (same suit) or the row of h+t (other suit)
+        const u64 r = sh_load(ST, st, C->bkey[s][st] + sh_pow(t) - (sd == st ? sh_pow(d) : 0u));
+        const int fin = sh_final(sd == st ? C->r3[s][st] : C->V[s][ki][st - (st > sd)], r, ld3);
+        const int pairs = (int)C->cnt[s][0] + (hct == 1) - (c == 2), kinds = (int)C->cnt[s][1] + (hct == 0) - (c == 1);
+        const int kpairs = (int)C->cnt[s][2] + (yt && hct == 1) - (yd && c == 2), kkinds = (int)C->cnt[s][3] + (yt && hct == 0) - (yd && c == 1);
+        if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0) atomicOr(&C->keepw[s][ti >> 1], 1u << (ki + 16 * (ti & 1)));
+    }
+    __syncthreads();
+    // P6: child list layout per state + node header and keep sets (expanded from ordinals to tile masks)
+    if (tid < n) {
+        const int s = tid;
+        const SpState S = sp_chunk2_state(C, s);
+        int total = 0;
+        const int nt = C->n_tiles[s];
+        for (int ti = 0; ti < nt; ti++) {
+            const int t = C->tiles[s][ti];
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
+            C->coff[s][ti] = (unsigned short)total;
+            total += nvar * __popc(sp_chunk2_keep(C, s, ti));
+        }
+        int child_base = atomicAdd(&X->n_pool, total);
+        if (child_base + total > SP_POOL) { X->overflow = 1; child_base = 0; }
+        C->child_base[s] = child_base;
+        SP_HBM SpNode& node = Wg->node[C->slot[s]];
+        node.child_off = (u32)child_base;
+        node.req = C->req[s];
+    }
+    for (int task = tid; task < n * 34; task += SP_THREADS) {
+        const int s = task / 34, t = task % 34;
+        const u64 req = C->req[s];
+        u64 mask = 0;
+        if ((req >> t) & 1) {
+            for (u32 bits = sp_chunk2_keep(C, s, __popcll(req & ((1ull << t) - 1))); bits; bits &= bits - 1)
+                mask |= 1ull << C->kinds[s][__ffs((int)bits) - 1];
+        }
+        Wg->node[C->slot[s]].keep[t] = mask;
+    }
+    __syncthreads();
+    // P7: children of the kept (t, d)
+    for (int it = tid; it < n_items; it += SP_THREADS) {
+        int s, ti, ki;
+        item_decode(it, s, ti, ki);
+        const u32 bits = sp_chunk2_keep(C, s, ti);
+        const int t = C->tiles[s][ti], d = C->kinds[s][ki];
+        if (d == t || !((bits >> ki) & 1)) continue;
+        const SpState S = sp_chunk2_state(C, s);
+        const int nk = __popc(bits), rank = __popc(bits & ((1u << ki) - 1));
+        const int cnt = S.w.get(t);
+        const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+        for (int variant = 0; variant < 2; variant++) {
+            int vidx;
+            if (!aka_in_wall) { if (variant == 1) continue; vidx = 0; }
+            else if (variant == 0) { if (cnt < 2) continue; vidx = 0; }
+            else vidx = cnt >= 2 ? 1 : 0;
+            const int tile = (aka_in_wall && variant == 1) ? akaize(t) : t;
+            SpState S2 = S;
+            sp_deal(S2, tile);
+            const int c = S2.h.get(d);
+            int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+            if (d == T_5M && (S2.akas & 1) && c == 1) dt = T_5MR;
+            else if (d == T_5P && (S2.akas & 2) && c == 1) dt = T_5PR;
+            else if (d == T_5S && (S2.akas & 4) && c == 1) dt = T_5SR;
+            sp_discard(S2, dt);
+            SpIns I;
+            sp_insert_begin(Wg, S2, I);
+            bool fresh;
+            const int cs = sp_insert_finish(Wg, X, I, fresh);
+            if (fresh && cs >= 0) {
+                const int idx = atomicAdd(&X->n_list, 1);
+                if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
+                else X->overflow = 1;
+            }
+            const int pos = C->child_base[s] + (int)C->coff[s][ti] + vidx * nk + rank;
+            if (pos < SP_POOL) Wg->pool[pos] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
+        }
+    }
+    __syncthreads();
+}
+#endif  // SP_VARIANT == 1
+
 template <int J, int N, class F>
 MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_constant<N - 1>): the index is a compile-time constant
     if constexpr (J < N) {
@@ -919,6 +1202,9 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ union SpTeams {
         SpTeam full[SP_THREADS / 32];
         SpChunk chunk;
+#if SP_VARIANT == 1
+        SpChunk2 chunk2;
+#endif
         SpHalf half[SP_THREADS / 16];
         SpQuarter quarter[SP_THREADS / 8];
         struct {                 // row set-up (candidates + their required tiles), before any team runs
@@ -1214,7 +1500,11 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
+#if SP_VARIANT == 0
                 for (int c0 = b; c0 < e; c0 += SP_NS) sp_expand_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0), lv);
+#else
+                for (int c0 = b; c0 < e; c0 += SP_NS2) sp_expand_chunk2(W, &X, &s_tm.chunk2, c0, min(SP_NS2, e - c0), lv);
+#endif
                 __syncthreads();
                 if (tid == 0) {
                     X.lvl_begin[lv - 1] = e;
@@ -1229,7 +1519,11 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
+#if SP_VARIANT == 0
                     for (int c0 = b; c0 < e; c0 += SP_NS) sp_l0_probe_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0));
+#else
+                    for (int c0 = b; c0 < e; c0 += SP_NS2) sp_l0_probe_chunk2(W, &X, &s_tm.chunk2, c0, min(SP_NS2, e - c0));
+#endif
                     __syncthreads();
                     const int n_items = min(X.n_items, SP_ITEMS);
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
