@@ -24,7 +24,7 @@
 
 #define SP_THREADS 256
 #ifndef SP_VARIANT
-#define SP_VARIANT 0  // 1: experimental 32-state expansion chunks (see "NEXT" below; round-2 candidate)
+#define SP_VARIANT 0  // experimental round-2 candidates (see "NEXT" below): bit 0 = 32-state expansion chunks, bit 1 = two turns per lane
 #endif
 #define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
@@ -647,7 +647,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     __syncthreads();
 }
 
-#if SP_VARIANT == 1
+#if SP_VARIANT & 1
 // ---------------------------------------------------------------------------------------------------------------------
 // NEXT (experimental, compiled only with -DSP_VARIANT=1; NOT the default and not yet validated on a GPU): the same
 // passes over chunks of 32 states.  Nine workgroup barriers and the gather latencies of a chunk are then shared by twice as
@@ -925,7 +925,7 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
     }
     __syncthreads();
 }
-#endif  // SP_VARIANT == 1
+#endif  // SP_VARIANT & 1
 
 template <int J, int N, class F>
 MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_constant<N - 1>): the index is a compile-time constant
@@ -1188,6 +1188,251 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot
     }
 }
 
+#if SP_VARIANT & 2
+// ---------------------------------------------------------------------------------------------------------------------
+// NEXT (experimental, compiled only with -DSP_VARIANT=2 or 3; not yet validated on a GPU): evaluation with TWO turns per
+// lane.  The accumulate of calc.rs:486-548 is triangular (turn i sums j = i .. T-1), so with one turn per lane half of the
+// lane-iterations are masked off.  Here lane p of a TH-lane team owns the turns p and T-1-p: (T - p) + (p + 1) = T + 1
+// terms for every lane, all lanes busy, and a state needs only ceil(T / 2) lanes — twice as many states per wavefront.
+// Each turn still adds its terms in the reference's order (draw entries in order, j ascending), so the f32 results are
+// the same bits.  The folded child values of a draw entry go through a small LDS array (the terms of a lane read next[j+1]
+// for its own j).
+struct SpPair {
+    static constexpr int CH = 2, CCAP = 48;
+    u64 keep[34];
+    unsigned short coff[34];
+    u8 tiles[36];
+    union {
+        float sc[SP_L0_MAX][4];
+        struct {
+            float nxs[3][SP_T + 1];      // next[0 .. T-1] of the current draw entry: tenpai / win / ev
+            unsigned short cs[CCAP];
+            unsigned short meta[CCAP];   // discard order key (9 bits) | last-of-group << 9 | draw count << 10
+        } ev;
+    } u;
+};
+static_assert(sizeof(SpPair) * (SP_THREADS / 8) <= sizeof(SpHalf) * (SP_THREADS / 16), "SpPair must not grow the kernel's LDS");
+
+template <int TH>
+__device__ __noinline__ void sp_eval_pair(SpWork* W, SpCtx* X, SpPair* TM, int slot, int L) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(TM);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const int p = threadIdx.x & (TH - 1);
+    SP_HBM SpNode& node = Wg->node[slot];
+    const SpState S = sp_state_of(node);
+    const int T = X->T;
+    const int i1 = p, i2 = T - 1 - p;          // the two turns of this lane
+    const bool on1 = i1 <= i2, on2 = i2 > i1;  // (the middle turn of an odd T is taken once; lanes past it idle)
+    float a1t = 0.f, a1w = 0.f, a1e = 0.f, a2t = 0.f, a2w = 0.f, a2e = 0.f;
+    u64 req = 0;
+    int child_base = 0;
+    u32 l0_yaku = 0;
+    {
+        constexpr int NR = (34 + TH - 1) / TH;
+        u64 kv[NR];
+#pragma unroll
+        for (int rnd = 0; rnd < NR; rnd++) kv[rnd] = node.keep[min(p + TH * rnd, 33)];
+        req = node.req;
+        if (L > 0) child_base = (int)node.child_off;
+        else l0_yaku = __hip_atomic_load(&node.child_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32* sc32 = reinterpret_cast<u32*>(&TM->u.sc[0][0]);
+#pragma unroll
+        for (int rnd = 0; rnd < NR; rnd++) {
+            const int t = p + TH * rnd;
+            if (t < 34) {
+                if (L > 0) {
+                    TM->keep[t] = kv[rnd];
+                } else {
+                    sc32[2 * t] = (u32)kv[rnd];
+                    sc32[2 * t + 1] = (u32)(kv[rnd] >> 32);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    int sum_required = 0;
+    for (u64 rest = req; rest; rest &= rest - 1) sum_required += S.w.get(__ffsll((long long)rest) - 1);
+    sum_required &= 0xFF;
+    const float* nt = X->not_tsumo[min(sum_required, 123)];
+    const float m1 = on1 ? nt[i1] : 0.f, m2 = on2 ? nt[i2] : 0.f;
+    const bool assume_riichi = X->is_menzen && X->prefer_riichi;
+    const int len1 = on1 ? T - i1 : 0, len2 = on2 ? T - i2 : 0;
+
+    // one draw entry: T + 1 steps, step q of a lane is the term (i1, i1 + q) while q < len1, then (i2, i2 + q - len1)
+    auto accumulate = [&](int count, bool is_scores, const float* scores) {
+        const float* tp = X->tsumo_prob[count - 1];
+#pragma unroll 1
+        for (int q = 0; q <= T; q++) {
+            const bool first = q < len1;
+            const bool act = first || (q - len1) < len2;
+            const int i = first ? i1 : i2;
+            const int j = first ? i1 + q : i2 + (q - len1);
+            const float mm = first ? m1 : m2;
+            if (!(act && mm != 0.f)) continue;
+            const float n = nt[j];
+            if (n == 0.f) continue;
+            const float prob = tp[j] * n / mm;
+            float at = first ? a1t : a2t, aw = first ? a1w : a2w, ae = first ? a1e : a2e;
+            if (is_scores) {
+                const int han_plus = (int)(assume_riichi && X->calc_double_riichi && i == 0) + (int)(assume_riichi && j == i) +
+                                     (int)(X->calc_haitei && j == T - 1);
+                aw += prob;
+                ae += prob * (han_plus == 0 ? scores[0] : han_plus == 1 ? scores[1] : han_plus == 2 ? scores[2] : scores[3]);
+            } else {
+                if (L == 1) at += prob;
+                if (j < T - 1) {
+                    if (L > 1) at += prob * TM->u.ev.nxs[0][j + 1];
+                    aw += prob * TM->u.ev.nxs[1][j + 1];
+                    ae += prob * TM->u.ev.nxs[2][j + 1];
+                }
+            }
+            if (first) { a1t = at; a1w = aw; a1e = ae; }
+            else { a2t = at; a2w = aw; a2e = ae; }
+        }
+    };
+
+    if (L == 0) {
+        int idx = 0;
+        for (u64 rest = req; rest; rest &= rest - 1) {
+            const int t = __ffsll((long long)rest) - 1;
+            const int cnt = S.w.get(t);
+            const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+            for (int variant = 0; variant < 2; variant++) {
+                int count;
+                if (!aka_in_wall) {
+                    if (variant == 1) break;
+                    count = cnt;
+                } else if (variant == 0) {
+                    if (cnt < 2) continue;
+                    count = cnt - 1;
+                } else {
+                    count = 1;
+                }
+                const int e = idx++;
+                if (e >= SP_L0_MAX || !((l0_yaku >> e) & 1)) continue;
+                float scores[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) scores[q] = TM->u.sc[e][q];
+                accumulate(count, true, scores);
+            }
+        }
+    } else {
+        const int n_tiles = __popcll(req);
+#pragma unroll
+        for (int rnd = 0; rnd < (34 + TH - 1) / TH; rnd++) {
+            const int t = p + TH * rnd;
+            if (t < 34 && ((req >> t) & 1)) TM->tiles[__popcll(req & ((1ull << t) - 1))] = (u8)t;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        int ti_next = 0, cpos = child_base;
+        while (ti_next < n_tiles) {
+            int n_ch = 0, ti_end = ti_next;
+            while (ti_end < n_tiles) {
+                const int t = TM->tiles[ti_end];
+                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                const int nvar = aka_in_wall ? (S.w.get(t) >= 2 ? 2 : 1) : 1;
+                const int c = nvar * __popcll(TM->keep[t]);
+                if (n_ch + c > SpPair::CCAP) break;
+                if (p == 0) TM->coff[t] = (unsigned short)n_ch;
+                n_ch += c;
+                ti_end++;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            for (int i = p; i < n_ch; i += TH) TM->u.ev.cs[i] = Wg->pool[min(cpos + i, SP_POOL - 1)];
+            for (int g = p; g < 2 * (ti_end - ti_next); g += TH) {
+                const int t = TM->tiles[ti_next + (g >> 1)], variant = g & 1;
+                const int cnt = S.w.get(t);
+                const bool aka_in_wall = (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
+                int tile, count, vidx;
+                if (!aka_in_wall) { if (variant == 1) continue; tile = t; count = cnt; vidx = 0; }
+                else if (variant == 0) { if (cnt < 2) continue; tile = t; count = cnt - 1; vidx = 0; }
+                else { tile = akaize(t); count = 1; vidx = cnt >= 2 ? 1 : 0; }
+                const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;
+                u64 rest = TM->keep[t];
+                const int nk = __popcll(rest);
+                int pos = (int)TM->coff[t] + vidx * nk;
+                for (int k = 0; k < nk; k++, pos++) {
+                    const int d = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int c = S.h.get(d) + (d == t);
+                    int dt = d;
+                    if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
+                    else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
+                    else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
+                    TM->u.ev.meta[pos] = (unsigned short)(sp_discard_key(dt) | ((k == nk - 1) ? 512 : 0) | (count << 10));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            // discard_slow (calc.rs:570-637) fold state of the current draw entry, one per turn of the lane
+            float n1t = -3.40282347e+38f, n1w = -3.40282347e+38f, n1e = -3.40282347e+38f;
+            float n2t = -3.40282347e+38f, n2w = -3.40282347e+38f, n2e = -3.40282347e+38f;
+            int mv1 = INT_MIN, mk1 = sp_discard_key(T_UNK), mv2 = INT_MIN, mk2 = sp_discard_key(T_UNK);
+            for (int c0 = 0; c0 < n_ch; c0 += SpPair::CH) {
+                float v1[SpPair::CH][3], v2[SpPair::CH][3];
+#pragma unroll
+                for (int q = 0; q < SpPair::CH; q++) {
+                    v1[q][0] = v1[q][1] = v1[q][2] = 0.f;
+                    v2[q][0] = v2[q][1] = v2[q][2] = 0.f;
+                    if (c0 + q < n_ch) {
+                        const int cs = TM->u.ev.cs[c0 + q];
+                        if (cs != 0xFFFF) {
+                            const SP_HBM SpNode& ch = Wg->node[cs];
+                            if (on1) { v1[q][0] = ch.tenpai[i1]; v1[q][1] = ch.win[i1]; v1[q][2] = ch.ev[i1]; }
+                            if (on2) { v2[q][0] = ch.tenpai[i2]; v2[q][1] = ch.win[i2]; v2[q][2] = ch.ev[i2]; }
+                        }
+                    }
+                }
+                const int nq = min(SpPair::CH, n_ch - c0);
+#pragma unroll
+                for (int q = 0; q < SpPair::CH; q++) {
+                    if (q >= nq) break;
+                    const int m = TM->u.ev.meta[c0 + q];
+                    if (TM->u.ev.cs[c0 + q] == 0xFFFF) {
+                        X->overflow = 1;
+                    } else {
+                        const int key = m & 511;
+                        if (on1) {
+                            const int value = (int)v1[q][2];  // `as i32` (maximize_win_prob = false)
+                            if (value > mv1 || (value == mv1 && key > mk1)) { n1t = v1[q][0]; n1w = v1[q][1]; n1e = v1[q][2]; mv1 = value; mk1 = key; }
+                        }
+                        if (on2) {
+                            const int value = (int)v2[q][2];
+                            if (value > mv2 || (value == mv2 && key > mk2)) { n2t = v2[q][0]; n2w = v2[q][1]; n2e = v2[q][2]; mv2 = value; mk2 = key; }
+                        }
+                    }
+                    if (m & 512) {  // last child of this draw entry: publish next[], add the entry's terms
+                        if (on1) { TM->u.ev.nxs[0][i1] = n1t; TM->u.ev.nxs[1][i1] = n1w; TM->u.ev.nxs[2][i1] = n1e; }
+                        if (on2) { TM->u.ev.nxs[0][i2] = n2t; TM->u.ev.nxs[1][i2] = n2w; TM->u.ev.nxs[2][i2] = n2e; }
+                        __builtin_amdgcn_wave_barrier();
+                        __threadfence_block();
+                        accumulate(m >> 10, false, nullptr);
+                        __builtin_amdgcn_wave_barrier();
+                        __threadfence_block();
+                        n1t = n1w = n1e = n2t = n2w = n2e = -3.40282347e+38f;
+                        mv1 = mv2 = INT_MIN;
+                        mk1 = mk2 = sp_discard_key(T_UNK);
+                    }
+                }
+            }
+            cpos += n_ch;
+            ti_next = ti_end;
+        }
+    }
+    if (on1) { node.tenpai[i1] = a1t; node.win[i1] = a1w; node.ev[i1] = a1e; }
+    if (on2) { node.tenpai[i2] = a2t; node.win[i2] = a2w; node.ev[i2] = a2e; }
+    for (int k = T + p; k < SP_T; k += TH) {  // entries past T are zero
+        node.tenpai[k] = 0.f;
+        node.win[k] = 0.f;
+        node.ev[k] = 0.f;
+    }
+}
+#endif  // SP_VARIANT & 2
+
 MJD int f32_total_cmp(float a, float b) {
     int x = __float_as_int(a), y = __float_as_int(b);
     x ^= (int)((unsigned)(x >> 31) >> 1);
@@ -1202,8 +1447,11 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ union SpTeams {
         SpTeam full[SP_THREADS / 32];
         SpChunk chunk;
-#if SP_VARIANT == 1
+#if SP_VARIANT & 1
         SpChunk2 chunk2;
+#endif
+#if SP_VARIANT & 2
+        SpPair pair[SP_THREADS / 8];
 #endif
         SpHalf half[SP_THREADS / 16];
         SpQuarter quarter[SP_THREADS / 8];
@@ -1500,7 +1748,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-#if SP_VARIANT == 0
+#if !(SP_VARIANT & 1)
                 for (int c0 = b; c0 < e; c0 += SP_NS) sp_expand_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0), lv);
 #else
                 for (int c0 = b; c0 < e; c0 += SP_NS2) sp_expand_chunk2(W, &X, &s_tm.chunk2, c0, min(SP_NS2, e - c0), lv);
@@ -1519,7 +1767,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
-#if SP_VARIANT == 0
+#if !(SP_VARIANT & 1)
                     for (int c0 = b; c0 < e; c0 += SP_NS) sp_l0_probe_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0));
 #else
                     for (int c0 = b; c0 < e; c0 += SP_NS2) sp_l0_probe_chunk2(W, &X, &s_tm.chunk2, c0, min(SP_NS2, e - c0));
@@ -1532,6 +1780,15 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 if (T <= 8) {
                     for (int i = b + (tid >> 3); i < e; i += SP_THREADS / 8)
                         sp_eval_team<8, SpQuarter>(W, &X, &s_tm.quarter[tid >> 3], (int)W->list[i], lv);
+#if SP_VARIANT & 2
+                } else if (T <= 16) {
+                    for (int i = b + (tid >> 3); i < e; i += SP_THREADS / 8)
+                        sp_eval_pair<8>(W, &X, &s_tm.pair[tid >> 3], (int)W->list[i], lv);
+                } else {
+                    for (int i = b + (tid >> 4); i < e; i += SP_THREADS / 16)
+                        sp_eval_pair<16>(W, &X, &s_tm.pair[tid >> 4], (int)W->list[i], lv);
+                }
+#else
                 } else if (T <= 16) {
                     for (int i = b + (tid >> 4); i < e; i += SP_THREADS / 16)
                         sp_eval_team<16, SpHalf>(W, &X, &s_tm.half[tid >> 4], (int)W->list[i], lv);
@@ -1539,6 +1796,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                     for (int i = b + (tid >> 5); i < e; i += SP_THREADS / 32)
                         sp_eval_team<32, SpTeam>(W, &X, &s_team[tid >> 5], (int)W->list[i], lv);
                 }
+#endif
                 __syncthreads();
                 if (lv == 0) t_3 = wall_clock64();
             }
