@@ -105,6 +105,15 @@ def cpu_baseline(version, budget_s=12.0, n_tables=16):
                        f"not buildable here (no rustc)")
 
 
+def _phase_ticks(pool):
+    """Optional extra (`sp_phases`): never let it cost the benchmark line."""
+    try:
+        return pool.sp_phase_ticks()
+    except Exception as e:  # noqa: BLE001
+        print(f"sp_phase_ticks unavailable: {e}", file=sys.stderr)
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +196,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     c0 = pool.counters()
+    ph0 = _phase_ticks(pool) if args.version == 4 else None
     pool.encode_timing(True)
     rows_timed = 0
     t0 = time.perf_counter()
@@ -201,6 +211,7 @@ def main():
     c1 = pool.counters()
     enc_ms, enc_launches = pool.encode_timing(False)
     sp_ms, sp_launches = pool.sp_timing()
+    ph1 = _phase_ticks(pool) if ph0 is not None else None
     steps = c1["steps"] - c0["steps"]
     games = c1["games"] - c0["games"]
     code, tbl = pool.first_error()
@@ -285,6 +296,12 @@ def main():
             "kernel_ms_per_step": {"mj_k_encode": enc_ms / args.steps, "mj_k_sp": sp_ms / args.steps,
                                    "everything_else": (dt * 1e3 - enc_ms - sp_ms) / args.steps},
         }
+        if ph0 is not None and ph1 is not None:  # where mj_k_sp spends its workgroup time (shares of the summed phase timers) + states per cycle
+            d = {k: ph1[k] - ph0[k] for k in ph1}
+            tot = max(1, sum(d[k] for k in ("setup", "expand", "level0", "eval", "write")))
+            line["sp_phases"] = {"share": {k: round(d[k] / tot, 4) for k in ("setup", "expand", "level0", "eval", "write")},
+                                 "states_per_step": d["states"] / args.steps, "rows_per_step": d["rows"] / args.steps,
+                                 "overflows": d["overflow"]}
         if not args.no_cpu_baseline and world == 1 and args.policy == "random":  # reported at N=1 only (rank 0)
             line["cpu_baseline"] = cpu_baseline(args.version, args.cpu_budget, args.cpu_tables)
         print(json.dumps(line))

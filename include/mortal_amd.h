@@ -113,6 +113,10 @@ int mj_oracle_obs_rows(int version);
 int mj_encode_timing(MjPool* pool, int enable, double* total_ms_out, int64_t* launches_out);
 /* Same for the SP-table kernel (obs v4 rows 889..1011) launched by mj_encode; collected while encode timing is enabled. */
 int mj_sp_timing(MjPool* pool, double* total_ms_out, int64_t* launches_out);
+/* Cumulative phase timers of mj_k_sp since the pool was created (workgroup wall-clock ticks at 100 MHz, summed over all
+ * workgroups): out[0] hash/pool overflows, [1] rows, [2] set-up, [3] expansion, [4] level 0 (probe + scoring + sum),
+ * [5] evaluation of levels > 0, [6] writing the rows, [7] states visited.  Measurement only (bench.py `sp_phases`). */
+int mj_sp_phase_ticks(MjPool* pool, uint64_t* out8, void* stream);
 
 /* Uniform-random legal action per row, counter-based (seed, game id, seat, kan flag, cycle). */
 int mj_random_policy(MjPool* pool, int agent, const uint8_t* masks_dev, uint64_t seed, uint64_t cycle,

@@ -673,6 +673,17 @@ int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
     return 0;
 }
 
+int mj_sp_phase_ticks(MjPool* P, uint64_t out[8], void* stream) {
+    if (!P) return fail("null pool");
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!P->sp_err) return 0;  // no obs-v4 encode has run yet
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long e2[8];
+    HIP_OK(hipMemcpy(e2, P->sp_err, sizeof e2, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = e2[i];
+    return 0;
+}
+
 int mj_results(MjPool* P, int32_t* scores, uint8_t* done, void* stream) {
     if (!P) return fail("null pool");
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));

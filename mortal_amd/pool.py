@@ -216,6 +216,12 @@ class TablePool:
         check(lib.mj_sp_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def sp_phase_ticks(self):
+        """Cumulative mj_k_sp phase timers (workgroup ticks, 100 MHz) and counts since the pool was created."""
+        out = (C.c_uint64 * 8)()
+        check(lib.mj_sp_phase_ticks(self.h, out, _stream()))
+        return dict(zip(("overflow", "rows", "setup", "expand", "level0", "eval", "write", "states"), (int(x) for x in out)))
+
     def debug_table(self, table):
         size = lib.mj_debug_table_size()
         buf = (C.c_uint8 * size)()
