@@ -3,7 +3,7 @@ the MI355X table pool (mortal_amd).  Put the repository root on PYTHONPATH and t
 (`mortal/one_vs_three.py`, `mortal/player.py`) import this package unchanged.
 
 Implemented: `libriichi.consts`, `libriichi.arena` (OneVsThree/TwoVsTwo `py_vs_py`, incl. `log_dir` mjai dumps),
-`libriichi.stat.Stat`, `libriichi.dataset` (GameplayLoader with oracle=False, Gameplay, Grp), `libriichi.state.PlayerState`
+`libriichi.stat.Stat`, `libriichi.dataset` (GameplayLoader incl. oracle=True, Gameplay, Grp), `libriichi.state.PlayerState`
 (update / validate_reaction / encode_obs / getters), `libriichi.mjai.Bot`.
 """
 import importlib as _il

@@ -1,5 +1,5 @@
 // C-ABI host side (include/mortal_amd.h): pool life-cycle and kernel launches.  One translation unit for the whole
-// library; the kernels live in mj_step.hip / mj_encode.hip.
+// library; the kernels live in mj_step.hip / mj_replay.hip / mj_encode.hip / mj_sp.hip.
 // Host float math below builds bit-exact LUTs: compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
