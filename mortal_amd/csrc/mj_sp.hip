@@ -24,7 +24,7 @@
 
 #define SP_THREADS 256
 #ifndef SP_VARIANT
-#define SP_VARIANT 0  // experimental round-2 candidates (see "NEXT" below): bit 0 = 32-state expansion chunks, bit 1 = two turns per lane
+#define SP_VARIANT 0  // experimental round-2 candidates (see "NEXT" below): bit 0 = 32-state expansion chunks, bit 1 = two turns per lane, bit 2 = per-wavefront 8-state chunks
 #endif
 #define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
@@ -647,34 +647,48 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     __syncthreads();
 }
 
-#if SP_VARIANT & 1
+#if SP_VARIANT & 5
 // ---------------------------------------------------------------------------------------------------------------------
-// NEXT (experimental, compiled only with -DSP_VARIANT=1; NOT the default and not yet validated on a GPU): the same
-// passes over chunks of 32 states.  Nine workgroup barriers and the gather latencies of a chunk are then shared by twice as
-// many states, and the first passes fill 128-192 of the 256 lanes instead of 64-96.  To fit 32 states into the same LDS
-// the per-state scratch is slimmer: the rows of h + t / h - d are gathered again where they are needed (L2 hits) instead
-// of being kept, and the keep sets are 13-bit masks over the state's safe-discard ordinals until they are written out.
-#define SP_NS2 32
-struct SpChunk2 {
-    u64 k[SP_NS2][4];
-    u64 row[SP_NS2][4];
-    u64 r2[SP_NS2][6];
-    u64 r3[SP_NS2][4];
-    u64 V[SP_NS2][13][3];    // per safe discard kind d and k-th other suit: merge(two untouched suits, row of h - d)
-    u64 req[SP_NS2], safe[SP_NS2];
-    u32 bkey[SP_NS2][4];
-    u32 slot[SP_NS2];
-    u32 keepw[SP_NS2][17];   // per required-tile ORDINAL ti: 16-bit mask over the safe-kind ordinals, two per word
-    int item_off[SP_NS2 + 1];
-    int child_base[SP_NS2];
-    unsigned short coff[SP_NS2][34];  // per required-tile ordinal: offset of its first child inside the state's child list
-    u8 cnt[SP_NS2][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds
-    u8 tiles[SP_NS2][36], kinds[SP_NS2][16];
-    u8 n_tiles[SP_NS2], n_kinds[SP_NS2];
+// NEXT (experimental, compiled only with -DSP_VARIANT bit 0 or bit 2; NOT the default and not yet validated on a GPU):
+// the same passes with a slimmer per-state scratch (the rows of h + t / h - d are gathered again where they are needed — L2
+// hits — instead of being kept; the keep sets are 13-bit masks over the state's safe-discard ordinals until they are
+// written out), as a template over the chunk size NS and the number of co-operating threads NT:
+//   bit 0: NS = 32, NT = 256 — nine workgroup barriers and the gather latencies of a chunk are shared by twice as many
+//          states, and the first passes fill 128-192 of the 256 lanes instead of 64-96;
+//   bit 2: NS = 8,  NT = 64  — every wavefront runs its own chunks: no workgroup barrier inside a level at all (the passes
+//          are separated by wave-level fences), four chunks in flight per workgroup.
+template <int NS>
+struct SpChunkT {
+    u64 k[NS][4];
+    u64 row[NS][4];
+    u64 r2[NS][6];
+    u64 r3[NS][4];
+    u64 V[NS][13][3];    // per safe discard kind d and k-th other suit: merge(two untouched suits, row of h - d)
+    u64 req[NS], safe[NS];
+    u32 bkey[NS][4];
+    u32 slot[NS];
+    u32 keepw[NS][17];   // per required-tile ORDINAL ti: 16-bit mask over the safe-kind ordinals, two per word
+    int item_off[NS + 1];
+    int child_base[NS];
+    unsigned short coff[NS][34];  // per required-tile ordinal: offset of its first child inside the state's child list
+    u8 cnt[NS][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds
+    u8 tiles[NS][36], kinds[NS][16];
+    u8 n_tiles[NS], n_kinds[NS];
 };
-static_assert(sizeof(SpChunk2) <= sizeof(SpHalf) * (SP_THREADS / 16), "SpChunk2 must not grow the kernel's LDS");
+static_assert(sizeof(SpChunkT<32>) <= sizeof(SpHalf) * (SP_THREADS / 16) && 4 * sizeof(SpChunkT<8>) <= sizeof(SpHalf) * (SP_THREADS / 16),
+              "the chunk scratch must not grow the kernel's LDS");
+template <int NT>
+MJD void sp_sync() {  // barrier between two passes of NT co-operating threads
+    if constexpr (NT == SP_THREADS) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+}
 
-MJD SpState sp_chunk2_state(const SpChunk2* C, int s) {
+template <class CT>
+MJD SpState sp_chunk2_state(const CT* C, int s) {
     SpState S;
     S.h.mp = C->k[s][0];
     S.h.sz = C->k[s][1] & 0xFFFFFFFFFFFFull;
@@ -683,13 +697,15 @@ MJD SpState sp_chunk2_state(const SpChunk2* C, int s) {
     S.akas = (u32)((C->k[s][1] >> 48) & 7) | ((u32)((C->k[s][3] >> 48) & 7) << 3);
     return S;
 }
-MJD u32 sp_chunk2_keep(const SpChunk2* C, int s, int ti) { return (C->keepw[s][ti >> 1] >> (16 * (ti & 1))) & 0xFFFFu; }
+template <class CT>
+MJD u32 sp_chunk2_keep(const CT* C, int s, int ti) { return (C->keepw[s][ti >> 1] >> (16 * (ti & 1))) & 0xFFFFu; }
 
 // passes P0-P3 (see sp_chunk_probe); req / safe only, no rows kept
-__device__ __forceinline__ void sp_chunk2_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunk2* C, const ShTab& ST, int first, int n, int L) {
-    const int tid = threadIdx.x;
+template <int NS, int NT>
+__device__ __forceinline__ void sp_chunk2_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunkT<NS>* C, const ShTab& ST, int first, int n, int L) {
+    const int tid = threadIdx.x & (NT - 1);
     const int ld3 = X->len_div3;
-    for (int task = tid; task < n * 4; task += SP_THREADS) {
+    for (int task = tid; task < n * 4; task += NT) {
         const int s = task >> 2, j = task & 3;
         const u32 slot = Wg->list[first + s];
         C->k[s][j] = reinterpret_cast<const SP_HBM u64*>(&Wg->node[slot])[j];
@@ -699,8 +715,8 @@ __device__ __forceinline__ void sp_chunk2_probe(SP_HBM SpWork* Wg, SpCtx* X, SpC
             C->safe[s] = 0;
         }
     }
-    __syncthreads();
-    for (int task = tid; task < n * 4; task += SP_THREADS) {
+    sp_sync<NT>();
+    for (int task = tid; task < n * 4; task += NT) {
         const int s = task >> 2, i = task & 3;
         const SpState S = sp_chunk2_state(C, s);
         const u32 key = i == 0 ? suit_key9(S.h.mp) : i == 1 ? suit_key9(S.h.mp >> 27) : i == 2 ? suit_key9(S.h.sz) : suit_key7(S.h.sz >> 27);
@@ -708,20 +724,20 @@ __device__ __forceinline__ void sp_chunk2_probe(SP_HBM SpWork* Wg, SpCtx* X, SpC
         C->row[s][i] = sh_load(ST, i, key);
         C->cnt[s][i] = (u8)(i == 0 ? S.h.n_pairs() : i == 1 ? S.h.n_kinds() : i == 2 ? S.h.n_yao_pairs() : S.h.n_yao_kinds());
     }
-    __syncthreads();
-    for (int task = tid; task < n * 6; task += SP_THREADS) {
+    sp_sync<NT>();
+    for (int task = tid; task < n * 6; task += NT) {
         const int s = task / 6, p = task % 6;
         const int a = p < 3 ? 0 : p < 5 ? 1 : 2, b = p < 3 ? p + 1 : p < 5 ? p - 1 : 3;
         C->r2[s][p] = sh_merge(C->row[s][a], C->row[s][b], ld3);
     }
-    __syncthreads();
-    for (int task = tid; task < n * 4; task += SP_THREADS) {
+    sp_sync<NT>();
+    for (int task = tid; task < n * 4; task += NT) {
         const int s = task >> 2, i = task & 3;
         const u64 pr = i == 0 ? C->r2[s][3] : i == 1 ? C->r2[s][1] : C->r2[s][0];
         C->r3[s][i] = sh_merge(pr, C->row[s][i == 3 ? 2 : 3], ld3);
     }
-    __syncthreads();
-    for (int task = tid; task < n * 34; task += SP_THREADS) {
+    sp_sync<NT>();
+    for (int task = tid; task < n * 34; task += NT) {
         const int s = task / 34, t = task % 34;
         const SpState S = sp_chunk2_state(C, s);
         const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
@@ -743,16 +759,17 @@ __device__ __forceinline__ void sp_chunk2_probe(SP_HBM SpWork* Wg, SpCtx* X, SpC
         }
         if (t < 17) C->keepw[s][t] = 0;
     }
-    __syncthreads();
+    sp_sync<NT>();
 }
 
-__device__ __noinline__ void sp_l0_probe_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, int first, int n) {
+template <int NS, int NT>
+__device__ __noinline__ void sp_l0_probe_chunk2(SpWork* W, SpCtx* X, SpChunkT<NS>* C, int first, int n) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(C);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const ShTab ST = sh_tab(c_mj_tables);
-    sp_chunk2_probe(Wg, X, C, ST, first, n, 0);
-    const int s = threadIdx.x;
+    sp_chunk2_probe<NS, NT>(Wg, X, C, ST, first, n, 0);
+    const int s = threadIdx.x & (NT - 1);
     if (s < n) {
         const SpState S = sp_chunk2_state(C, s);
         const u64 req = C->req[s];
@@ -782,19 +799,20 @@ __device__ __noinline__ void sp_l0_probe_chunk2(SpWork* W, SpCtx* X, SpChunk2* C
         node.req = req;
         node.child_off = 0;
     }
-    __syncthreads();
+    sp_sync<NT>();
 }
 
-__device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, int first, int n, int L) {
+template <int NS, int NT>
+__device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunkT<NS>* C, int first, int n, int L) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(C);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const ShTab ST = sh_tab(c_mj_tables);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & (NT - 1);
     const int ld3 = X->len_div3;
-    sp_chunk2_probe(Wg, X, C, ST, first, n, L);
+    sp_chunk2_probe<NS, NT>(Wg, X, C, ST, first, n, L);
     // P4a: ascending lists of the required tiles and of the safe discard kinds
-    for (int task = tid; task < n * 34; task += SP_THREADS) {
+    for (int task = tid; task < n * 34; task += NT) {
         const int s = task / 34, t = task % 34;
         const u64 req = C->req[s], safe = C->safe[s], below = (1ull << t) - 1;
         if ((req >> t) & 1) C->tiles[s][__popcll(req & below)] = (u8)t;
@@ -804,7 +822,7 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
             C->n_kinds[s] = (u8)__popcll(safe);
         }
     }
-    __syncthreads();
+    sp_sync<NT>();
     if (tid == 0) {
         int off = 0;
         for (int s = 0; s < n; s++) {
@@ -814,7 +832,7 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
         C->item_off[n] = off;
     }
     // P4b: V = merge(two untouched suits, row of h - d), the row gathered again (it was probed in P3: an L2 hit)
-    for (int task = tid; task < n * 39; task += SP_THREADS) {
+    for (int task = tid; task < n * 39; task += NT) {
         const int s = task / 39, q = task % 39, ki = q / 3, k = q % 3;
         if (ki >= (int)C->n_kinds[s]) continue;
         const int d = C->kinds[s][ki], sd = sh_suit(d), st = k + (k >= sd);
@@ -824,7 +842,7 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
         const u64 rowd = sh_load(ST, sd, C->bkey[s][sd] - sh_pow(d));
         C->V[s][ki][k] = sh_merge(C->r2[s][sh_pair_idx(x, y)], rowd, ld3);
     }
-    __syncthreads();
+    sp_sync<NT>();
     // P5: (state, required t, safe d) probes of h + t - d
     const int n_items = C->item_off[n];
     auto item_decode = [&](int it, int& s, int& ti, int& ki) {
@@ -838,7 +856,7 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
         ti = local / nk;
         ki = local - ti * nk;
     };
-    for (int it = tid; it < n_items; it += SP_THREADS) {
+    for (int it = tid; it < n_items; it += NT) {
         int s, ti, ki;
         item_decode(it, s, ti, ki);
         const int t = C->tiles[s][ti], d = C->kinds[s][ki];
@@ -853,7 +871,7 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
         const int kpairs = (int)C->cnt[s][2] + (yt && hct == 1) - (yd && c == 2), kkinds = (int)C->cnt[s][3] + (yt && hct == 0) - (yd && c == 1);
         if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0) atomicOr(&C->keepw[s][ti >> 1], 1u << (ki + 16 * (ti & 1)));
     }
-    __syncthreads();
+    sp_sync<NT>();
     // P6: child list layout per state + node header and keep sets (expanded from ordinals to tile masks)
     if (tid < n) {
         const int s = tid;
@@ -874,7 +892,7 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
         node.child_off = (u32)child_base;
         node.req = C->req[s];
     }
-    for (int task = tid; task < n * 34; task += SP_THREADS) {
+    for (int task = tid; task < n * 34; task += NT) {
         const int s = task / 34, t = task % 34;
         const u64 req = C->req[s];
         u64 mask = 0;
@@ -884,9 +902,9 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
         }
         Wg->node[C->slot[s]].keep[t] = mask;
     }
-    __syncthreads();
+    sp_sync<NT>();
     // P7: children of the kept (t, d)
-    for (int it = tid; it < n_items; it += SP_THREADS) {
+    for (int it = tid; it < n_items; it += NT) {
         int s, ti, ki;
         item_decode(it, s, ti, ki);
         const u32 bits = sp_chunk2_keep(C, s, ti);
@@ -923,9 +941,9 @@ __device__ __noinline__ void sp_expand_chunk2(SpWork* W, SpCtx* X, SpChunk2* C, 
             if (pos < SP_POOL) Wg->pool[pos] = (unsigned short)(cs < 0 ? 0xFFFF : cs);
         }
     }
-    __syncthreads();
+    sp_sync<NT>();
 }
-#endif  // SP_VARIANT & 1
+#endif  // SP_VARIANT & 5
 
 template <int J, int N, class F>
 MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_constant<N - 1>): the index is a compile-time constant
@@ -1447,8 +1465,10 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ union SpTeams {
         SpTeam full[SP_THREADS / 32];
         SpChunk chunk;
-#if SP_VARIANT & 1
-        SpChunk2 chunk2;
+#if SP_VARIANT & 4
+        SpChunkT<8> wchunk[SP_THREADS / 64];
+#elif SP_VARIANT & 1
+        SpChunkT<32> chunk2;
 #endif
 #if SP_VARIANT & 2
         SpPair pair[SP_THREADS / 8];
@@ -1748,10 +1768,13 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-#if !(SP_VARIANT & 1)
-                for (int c0 = b; c0 < e; c0 += SP_NS) sp_expand_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0), lv);
+#if SP_VARIANT & 4
+                for (int c0 = b + 8 * (tid >> 6); c0 < e; c0 += 8 * (SP_THREADS / 64))  // every wavefront its own chunks
+                    sp_expand_chunk2<8, 64>(W, &X, &s_tm.wchunk[tid >> 6], c0, min(8, e - c0), lv);
+#elif SP_VARIANT & 1
+                for (int c0 = b; c0 < e; c0 += 32) sp_expand_chunk2<32, SP_THREADS>(W, &X, &s_tm.chunk2, c0, min(32, e - c0), lv);
 #else
-                for (int c0 = b; c0 < e; c0 += SP_NS2) sp_expand_chunk2(W, &X, &s_tm.chunk2, c0, min(SP_NS2, e - c0), lv);
+                for (int c0 = b; c0 < e; c0 += SP_NS) sp_expand_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0), lv);
 #endif
                 __syncthreads();
                 if (tid == 0) {
@@ -1767,10 +1790,13 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
-#if !(SP_VARIANT & 1)
-                    for (int c0 = b; c0 < e; c0 += SP_NS) sp_l0_probe_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0));
+#if SP_VARIANT & 4
+                    for (int c0 = b + 8 * (tid >> 6); c0 < e; c0 += 8 * (SP_THREADS / 64))
+                        sp_l0_probe_chunk2<8, 64>(W, &X, &s_tm.wchunk[tid >> 6], c0, min(8, e - c0));
+#elif SP_VARIANT & 1
+                    for (int c0 = b; c0 < e; c0 += 32) sp_l0_probe_chunk2<32, SP_THREADS>(W, &X, &s_tm.chunk2, c0, min(32, e - c0));
 #else
-                    for (int c0 = b; c0 < e; c0 += SP_NS2) sp_l0_probe_chunk2(W, &X, &s_tm.chunk2, c0, min(SP_NS2, e - c0));
+                    for (int c0 = b; c0 < e; c0 += SP_NS) sp_l0_probe_chunk(W, &X, &s_tm.chunk, c0, min(SP_NS, e - c0));
 #endif
                     __syncthreads();
                     const int n_items = min(X.n_items, SP_ITEMS);
