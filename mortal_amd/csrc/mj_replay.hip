@@ -82,7 +82,7 @@ template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uin
                 // trust_seed (invisible.rs:36-71): the game came from this engine, rebuild the whole wall from its seed
                 u8 logged[52];
                 for (int i = 0; i < 52; i++) logged[i] = F1(wall, i);
-                deal_wall(&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), F(kyoku), F(honba), deal_algo);
+                deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), F(kyoku), F(honba), deal_algo);
                 bool same = F1(wall, 60) == ev.pai;
                 for (int i = 0; i < 52; i++) same = same && logged[i] == F1(wall, i);
                 if (!same) set_err(L, MJ_ERR_WALL);  // the seed does not reproduce the logged haipai
@@ -167,7 +167,7 @@ template <class LN> MJDN int rp_label(const LN& L, int p, const RpEvent nxt[3], 
 // Apply events until at least one tracked seat has a sample (or the log ends).  One lane per table.
 __global__ __launch_bounds__(64) void mj_k_replay(ReplayParams P) {
     const int table = blockIdx.x * 64 + threadIdx.x;
-    Lane L = {P.blocks + blockIdx.x, (int)threadIdx.x, &c_mj_tables};
+    Lane L = {MJ_POOL_PTR(P.blocks + blockIdx.x), (int)threadIdx.x, &c_mj_tables};
     int nr = 0;
     if (table < P.n_tables) {
         const uint64_t* sc = P.script + P.script_off[table];
@@ -270,7 +270,7 @@ __global__ void mj_k_replay_meta(ReplayMetaParams P) {
 // ================================================================ single-table access for libriichi.state.PlayerState
 // (state/player_state.rs:142-167 pyo3 surface: update / encode_obs / getters; used by tests and debugging)
 __global__ void mj_k_apply_event(TableBlock* blocks, int table, const uint64_t* words) {
-    Lane L = {blocks + (table >> 6), table & 63, &c_mj_tables};
+    Lane L = {MJ_POOL_PTR(blocks + (table >> 6)), table & 63, &c_mj_tables};
     const RpEvent ev = rp_decode(words[0]);
     rp_apply(L, ev, words);
 }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void mj_k_mark_row(TableBlock* blocks, int n_ta
 enum { MJ_Q_AGARI_POINTS = 0, MJ_Q_RULE_BASED_AGARI = 1, MJ_Q_REAL_TIME_SHANTEN = 2, MJ_Q_DORAS_OWNED = 3,
        MJ_Q_ADD_DORA = 4, MJ_Q_SET_SCORES = 5, MJ_Q_SCENE = 6, MJ_Q_DECODE_ACTION = 7 };
 __global__ void mj_k_query(TableBlock* blocks, int table, int seat, int what, const int32_t* args, int32_t* out) {
-    Lane L = {blocks + (table >> 6), table & 63, &c_mj_tables};
+    Lane L = {MJ_POOL_PTR(blocks + (table >> 6)), table & 63, &c_mj_tables};
     const int p = seat;
     switch (what) {
         case MJ_Q_AGARI_POINTS: {  // args: is_ron, n_ura, ura[5]  (agent_helper.rs:377-462)

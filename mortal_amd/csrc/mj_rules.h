@@ -15,9 +15,15 @@
 // thread (160 B x 256 threads per encoded row showed up as +34 % HBM write traffic in the PMC counters).
 __constant__ MjTablesDev c_mj_tables;
 
+// Pointer type of a lane's block.  With -DMJ_POOL_GLOBAL (experimental, not validated) the HBM pool is addressed through
+// a global-address-space pointer, so the out-of-line rule functions use global_load/store instead of flat_* (see mj_sp.hip).
+template <class BlockT> struct LaneBlockPtr { typedef BlockT* type; };
+#ifdef MJ_POOL_GLOBAL
+template <> struct LaneBlockPtr<TableBlock> { typedef __attribute__((address_space(1))) TableBlock* type; };
+#endif
 template <class BlockT>
 struct LaneT {  // a table viewed through lane `l` of a block (pool block in HBM, or the 1-lane LDS copy)
-    BlockT* B;
+    typename LaneBlockPtr<BlockT>::type B;
     int l;
     const MjTablesDev* T;
     uint64_t* log = nullptr;   // this table's event log (NULL = logging off), see mj_state.h LG_*
@@ -25,6 +31,7 @@ struct LaneT {  // a table viewed through lane `l` of a block (pool block in HBM
     uint32_t log_cap = 0;
 };
 typedef LaneT<TableBlock> Lane;
+#define MJ_POOL_PTR(p) ((LaneBlockPtr<TableBlock>::type)(p))
 #define F(f) (L.B->f[L.l])
 #define F1(f, i) (L.B->f[i][L.l])
 #define F2(f, i, j) (L.B->f[i][j][L.l])
@@ -615,7 +622,7 @@ template <class LN> MJDN void kyoku_init(const LN& L) {
 }
 template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
     const int kyoku = F(kyoku), honba = F(honba);
-    deal_wall(&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
+    deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
     kyoku_init(L);
     const int marker = F1(wall, 56 + 4);
     // first tsumo of the oya

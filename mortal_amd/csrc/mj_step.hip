@@ -548,7 +548,7 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
 
 __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
     const int table = blockIdx.x * 64 + threadIdx.x;
-    Lane L = {P.blocks + blockIdx.x, (int)threadIdx.x, &c_mj_tables};
+    Lane L = {MJ_POOL_PTR(P.blocks + blockIdx.x), (int)threadIdx.x, &c_mj_tables};
     if (P.log && table < P.n_tables) {
         L.log = P.log + (size_t)table * P.log_cap;
         L.log_len = P.log_len + table;
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
 // Restart finished tables with fresh seeds (steady-state throughput mode; not used in parity runs).
 __global__ __launch_bounds__(64) void mj_k_refill(StepParams P) {
     const int table = blockIdx.x * 64 + threadIdx.x;
-    Lane L = {P.blocks + blockIdx.x, (int)threadIdx.x, &c_mj_tables};
+    Lane L = {MJ_POOL_PTR(P.blocks + blockIdx.x), (int)threadIdx.x, &c_mj_tables};
     u32 fl = F(flags);
     if (table >= P.n_tables || (fl & TF_INACTIVE) || !(fl & TF_DONE)) return;
     F(seed_nonce) += P.refill_stride;

@@ -7,7 +7,7 @@ cd /root/repo; mkdir -p gpurun_out/ab
 lib=libmortal_amd.so; [ -n "$1" ] && lib=libmortal_amd_$1.so
 export MORTAL_AMD_LIB=/root/repo/mortal_amd/$lib
 ( timeout 60 python __graft_entry__.py smoke && timeout 80 python -m pytest tests/test_gpu_state.py tests/test_gpu_parity.py -m gpu -x -q \
-    -k "random_hands or greedy_policy_v4 or size_independent" ) > gpurun_out/ab/parity.log 2>&1
+    -k "random_hands or greedy_policy_v4 or greedy_policy_v3 or size_independent or tsumogiri" ) > gpurun_out/ab/parity.log 2>&1
 rc=$?; echo "parity of $lib rc=$rc" | tee -a gpurun_out/ab/parity.log
 grep -a "smoke\|passed\|failed\|Error" gpurun_out/ab/parity.log | tail -6
 if [ $rc -ne 0 ]; then tail -c 6000 gpurun_out/ab/parity.log; exit 1; fi   # no bench on a library that is not bit-exact
