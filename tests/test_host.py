@@ -120,3 +120,35 @@ def test_device_helpers_host_equivalence(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "sh_final == reference-shaped loop" in out.stdout
+
+
+def test_sp_kernel_isa_has_no_flat_or_spilled_hot_paths(tmp_path):
+    """Static ISA review of the SP kernel's phase functions (cross-compiled, no GPU): every memory access has a known
+    address space (no flat_* instruction: a flat load counts on both wait counters and serialises LDS reads behind HBM
+    gathers), the dense passes and the evaluation teams do not spill, and the kernel keeps its 4-workgroups-per-CU budget
+    (<= 128 VGPRs, <= 40 KB LDS)."""
+    import shutil
+    import subprocess
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = str(tmp_path / "lib.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
+                           "--cuda-device-only", "-S", "-o", asm, os.path.join(root, "mortal_amd", "csrc", "mj_capi.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    funcs = {}
+    for m in re.finditer(r"^(_Z\d+(?:sp_\w+|mj_k_sp\w*)):.*?^\.Lfunc_end\d+:", text, re.S | re.M):
+        funcs[m.group(1)] = m.group(0)
+    names = " ".join(funcs)
+    for want in ("sp_expand_chunk", "sp_l0_probe_chunk", "sp_l0_score", "sp_eval_teamILi8E", "sp_eval_teamILi16E", "sp_eval_teamILi32E", "mj_k_sp"):
+        assert want in names, (want, sorted(funcs))
+    for name, body in funcs.items():
+        assert "flat_" not in body, name
+        if "sp_eval_team" in name or "chunk" in name:
+            assert body.count("scratch_") <= 8, (name, body.count("scratch_"))  # callee-saved register saves only
+    k = re.search(r"\.amdhsa_kernel _Z7mj_k_sp8SpParams(.*?)\.end_amdhsa_kernel", text, re.S).group(1)
+    assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", k).group(1)) <= 128
+    assert int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", k).group(1)) <= 40960
