@@ -8,7 +8,7 @@ import os
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MORTAL_AMD_LIB") or os.path.join(_DIR, "libmortal_amd.so")  # env override: A/B builds
 
-# Every symbol include/mortal_amd.h declares (tests/test_abi.py checks the library exports all of them).
+# Every symbol include/mortal_amd.h declares (tests/test_host.py checks the library exports all of them).
 SYMBOLS = [
     "mj_last_error", "mj_abi_version", "mj_tables_upload", "mj_pool_create", "mj_pool_destroy", "mj_pool_reset",
     "mj_pool_configure", "mj_pool_set_refill", "mj_table_apply_event", "mj_table_mark_row", "mj_table_query", "mj_replay_load", "mj_replay_step", "mj_replay_meta", "mj_pool_enable_log", "mj_log_lengths", "mj_log_read", "mj_step", "mj_step_q", "mj_rows_count", "mj_rows_dev", "mj_encode",
@@ -21,18 +21,21 @@ class MortalAmdError(RuntimeError):
     pass
 
 
-def _load():
+def _load(path=None):
+    """dlopen the C-ABI library and declare its prototypes.  `path` is for the test suite only (the host emulation of the
+    same sources, tests/host); the product always binds LIB_PATH."""
+    path = path or LIB_PATH
     # torch ships its own libamdhip64; it must be in the process before libmortal_amd.so is opened, otherwise the
     # system copy gets bound first and the two HIP runtimes disagree about the visible devices
     import torch  # noqa: F401
 
 
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise MortalAmdError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). The HIP extension is mandatory; there is no CPU fallback."
         )
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     L.mj_last_error.restype = C.c_char_p
     L.mj_tables_upload.argtypes = [vp, C.c_size_t]

@@ -51,7 +51,7 @@ def _check_engine(engine):
 class BatchRunner:
     """Drives N tables to completion with up to two engines (agent 0 / agent 1)."""
 
-    def __init__(self, engines, seeds, agent_of_seat, device=None, deal_algo=0, keep_log=False):
+    def __init__(self, engines, seeds, agent_of_seat, device=None, deal_algo=None, keep_log=False):
         self.engines = engines
         self.cfg = [_check_engine(e) for e in engines]
         dev = device
@@ -200,9 +200,10 @@ def _rank_by_player(scores):
 class OneVsThree:
     """libriichi.arena.OneVsThree (arena/one_vs_three.rs:17-113)."""
 
-    def __init__(self, *, disable_progress_bar=False, log_dir=None):
+    def __init__(self, *, disable_progress_bar=False, log_dir=None, deal_algo=None):
         self.disable_progress_bar = disable_progress_bar
         self.log_dir = log_dir
+        self.deal_algo = deal_algo  # None = pool.default_deal_algo() (rand 0.9.1 unless MORTAL_AMD_DEAL_ALGO says otherwise)
 
     def py_vs_py(self, challenger, champion, seed_start, seed_count):
         """Returns the rank histogram [1st, 2nd, 3rd, 4th] of the challenger over seed_count*4 hanchan."""
@@ -210,7 +211,7 @@ class OneVsThree:
         seeds = [(int(seed_start[0]) + g // 4, int(seed_start[1])) for g in range(n)]  # one_vs_three.rs:140-142
         # challenger (agent 0) sits at seat g % 4, the champion (agent 1) on the other three (one_vs_three.rs:144-191)
         aos = np.array([0xF & ~(1 << (g % 4)) for g in range(n)], dtype=np.uint8)
-        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None)
+        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None, deal_algo=self.deal_algo)
         try:
             scores = runner.run()
             if self.log_dir is not None:
@@ -232,16 +233,17 @@ class OneVsThree:
 class TwoVsTwo:
     """libriichi.arena.TwoVsTwo (arena/two_vs_two.rs:17-110): seed_count*2 hanchan, returns None."""
 
-    def __init__(self, *, disable_progress_bar=False, log_dir=None):
+    def __init__(self, *, disable_progress_bar=False, log_dir=None, deal_algo=None):
         self.disable_progress_bar = disable_progress_bar
         self.log_dir = log_dir
+        self.deal_algo = deal_algo  # None = pool.default_deal_algo() (rand 0.9.1 unless MORTAL_AMD_DEAL_ALGO says otherwise)
 
     def py_vs_py(self, challenger, champion, seed_start, seed_count):
         n = int(seed_count) * 2
         seeds = [(int(seed_start[0]) + g // 2, int(seed_start[1])) for g in range(n)]  # two_vs_two.rs:138-140
         # split A: challenger at seats 0,2; split B: 1,3 (two_vs_two.rs:142-172)
         aos = np.array([0b1010 if g % 2 == 0 else 0b0101 for g in range(n)], dtype=np.uint8)
-        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None)
+        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None, deal_algo=self.deal_algo)
         try:
             runner.run()
             if self.log_dir is not None:

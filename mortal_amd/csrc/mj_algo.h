@@ -21,6 +21,19 @@ typedef uint8_t u8;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+// Two constructs are spelled through a macro / helper so that the host SIMT emulator of the test suite
+// (tests/host/emu, -DMJ_EMU) can give them their lane-group meaning; on the device they are the plain HIP forms.
+#ifndef MJ_EMU
+#define MJ_DYN_SHARED(T, name) extern __shared__ T name[]
+// LDS hand-off between the W lanes of a team inside one wavefront (lock-step: a scheduling + memory fence suffices)
+template <int W> MJD void mj_team_sync() {
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+}
+#else
+template <int W> inline void mj_team_sync() { emu::group_sync(W); }
+#endif
+
 enum : int { T_5M = 4, T_5P = 13, T_5S = 22, T_E = 27, T_S = 28, T_W = 29, T_N = 30, T_P = 31, T_F = 32, T_C = 33,
              T_5MR = 34, T_5PR = 35, T_5SR = 36, T_UNK = 37 };
 

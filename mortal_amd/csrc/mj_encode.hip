@@ -130,7 +130,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
     typedef Lay<V> O;
     constexpr int C = O::total;
     constexpr int TILE_ROWS = ((C + ENC_PASSES - 1) / ENC_PASSES + 1) & ~1;  // even -> tile bytes % 16 == 0
-    extern __shared__ float4 smem4[];
+    MJ_DYN_SHARED(float4, smem4);
     float* tile = reinterpret_cast<float*>(smem4);
     TableOne* st = reinterpret_cast<TableOne*>(tile + TILE_ROWS * 34);
     EncDerived* D = reinterpret_cast<EncDerived*>(reinterpret_cast<char*>(st) + ((sizeof(TableOne) + 15) & ~(size_t)15));
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode_oracle(OracleEncParam
     constexpr int SEAT_ROWS = V1 ? 15 : 17;
     constexpr int ROWS = 3 * SEAT_ROWS + 138 + 8 + 10 + 10;
     constexpr int TILE_F = (ROWS * 34 + 3) & ~3;
-    extern __shared__ float4 smem4[];
+    MJ_DYN_SHARED(float4, smem4);
     float* tile = reinterpret_cast<float*>(smem4);
     TableOne* st = reinterpret_cast<TableOne*>(tile + TILE_F);
     const int tid = threadIdx.x;

@@ -82,10 +82,15 @@ template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uin
                 // trust_seed (invisible.rs:36-71): the game came from this engine, rebuild the whole wall from its seed
                 u8 logged[52];
                 for (int i = 0; i < 52; i++) logged[i] = F1(wall, i);
-                deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), F(kyoku), F(honba), deal_algo);
-                bool same = F1(wall, 60) == ev.pai;
-                for (int i = 0; i < 52; i++) same = same && logged[i] == F1(wall, i);
-                if (!same) set_err(L, MJ_ERR_WALL);  // the seed does not reproduce the logged haipai
+                // the pool's shuffle first, then the other one: logs of either rand generation of the reference arena load
+                bool same = false;
+                for (int attempt = 0; attempt < 2 && !same; attempt++) {
+                    deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), F(kyoku), F(honba),
+                              attempt == 0 ? deal_algo : 1 - deal_algo);
+                    same = F1(wall, 60) == ev.pai;
+                    for (int i = 0; i < 52; i++) same = same && logged[i] == F1(wall, i);
+                }
+                if (!same) set_err(L, MJ_ERR_WALL);  // the seed does not reproduce the logged haipai under either shuffle
             } else if ((w[0] >> LG_SK_WALL_BIT) & 1) {
                 for (int k = 0; k < 17; k++) {
                     const uint64_t v = w[10 + k];

@@ -162,7 +162,11 @@ struct SpCtx {  // per-decision constants (LDS)
 #else
 #define SP_ASSUME_LDS(p) ((void)0)  // host pass of the single-source compile: the builtin only exists on the device
 #endif
+#ifdef MJ_EMU
+#define SP_HBM
+#else
 #define SP_HBM __attribute__((address_space(1)))
+#endif
 
 // hash-set insert; returns the slot or -1 on overflow.  `fresh` tells whether this call created the slot.
 __device__ int sp_insert(SpWork* W, SpCtx* X, const SpState& s, bool& fresh) {
@@ -691,8 +695,7 @@ MJD void sp_sync() {  // barrier between two passes of NT co-operating threads
     if constexpr (NT == SP_THREADS) {
         __syncthreads();
     } else {
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        mj_team_sync<NT>();
     }
 }
 
@@ -1009,8 +1012,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        mj_team_sync<TW>();
     }
 
     // ---- D
@@ -1107,8 +1109,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot
             const int t = ln + TW * rnd;
             if (t < 34 && ((req >> t) & 1)) TM->tiles[__popcll(req & ((1ull << t) - 1))] = (u8)t;
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        mj_team_sync<TW>();
         int ti_next = 0, cpos = child_base;
         while (ti_next < n_tiles) {
             // tiles [ti_next, ti_end) whose children fit the staging area
@@ -1123,8 +1124,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot
                 n_ch += c;
                 ti_end++;
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            mj_team_sync<TW>();
             for (int i = ln; i < n_ch; i += TW) TM->u.ev.cs[i] = Wg->pool[min(cpos + i, SP_POOL - 1)];
             // per-child metadata, one lane per draw entry (tile, variant)
             for (int g = ln; g < 2 * (ti_end - ti_next); g += TW) {
@@ -1150,8 +1150,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, TMT* TM, int slot
                     TM->u.ev.meta[pos] = (unsigned short)(sp_discard_key(dt) | ((k == nk - 1) ? 512 : 0) | (count << 10));
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            mj_team_sync<TW>();
             // discard_slow (calc.rs:570-637) fold state of the current draw entry
             float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
             int max_value = INT_MIN, max_key = sp_discard_key(T_UNK);
@@ -1276,8 +1275,7 @@ __device__ __noinline__ void sp_eval_pair(SpWork* W, SpCtx* X, SpPair* TM, int s
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        mj_team_sync<TH>();
     }
     int sum_required = 0;
     for (u64 rest = req; rest; rest &= rest - 1) sum_required += S.w.get(__ffsll((long long)rest) - 1);
@@ -1352,8 +1350,7 @@ __device__ __noinline__ void sp_eval_pair(SpWork* W, SpCtx* X, SpPair* TM, int s
             const int t = p + TH * rnd;
             if (t < 34 && ((req >> t) & 1)) TM->tiles[__popcll(req & ((1ull << t) - 1))] = (u8)t;
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        mj_team_sync<TH>();
         int ti_next = 0, cpos = child_base;
         while (ti_next < n_tiles) {
             int n_ch = 0, ti_end = ti_next;
@@ -1367,8 +1364,7 @@ __device__ __noinline__ void sp_eval_pair(SpWork* W, SpCtx* X, SpPair* TM, int s
                 n_ch += c;
                 ti_end++;
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            mj_team_sync<TH>();
             for (int i = p; i < n_ch; i += TH) TM->u.ev.cs[i] = Wg->pool[min(cpos + i, SP_POOL - 1)];
             for (int g = p; g < 2 * (ti_end - ti_next); g += TH) {
                 const int t = TM->tiles[ti_next + (g >> 1)], variant = g & 1;
@@ -1393,8 +1389,7 @@ __device__ __noinline__ void sp_eval_pair(SpWork* W, SpCtx* X, SpPair* TM, int s
                     TM->u.ev.meta[pos] = (unsigned short)(sp_discard_key(dt) | ((k == nk - 1) ? 512 : 0) | (count << 10));
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            mj_team_sync<TH>();
             // discard_slow (calc.rs:570-637) fold state of the current draw entry, one per turn of the lane
             float n1t = -3.40282347e+38f, n1w = -3.40282347e+38f, n1e = -3.40282347e+38f;
             float n2t = -3.40282347e+38f, n2w = -3.40282347e+38f, n2e = -3.40282347e+38f;
@@ -1435,11 +1430,9 @@ __device__ __noinline__ void sp_eval_pair(SpWork* W, SpCtx* X, SpPair* TM, int s
                     if (m & 512) {  // last child of this draw entry: publish next[], add the entry's terms
                         if (on1) { TM->u.ev.nxs[0][i1] = n1t; TM->u.ev.nxs[1][i1] = n1w; TM->u.ev.nxs[2][i1] = n1e; }
                         if (on2) { TM->u.ev.nxs[0][i2] = n2t; TM->u.ev.nxs[1][i2] = n2w; TM->u.ev.nxs[2][i2] = n2e; }
-                        __builtin_amdgcn_wave_barrier();
-                        __threadfence_block();
+                        mj_team_sync<TH>();
                         accumulate(m >> 10, false, nullptr);
-                        __builtin_amdgcn_wave_barrier();
-                        __threadfence_block();
+                        mj_team_sync<TH>();
                         n1t = n1w = n1e = n2t = n2w = n2e = -3.40282347e+38f;
                         mv1 = mv2 = INT_MIN;
                         mk1 = mk2 = sp_discard_key(T_UNK);

@@ -169,7 +169,7 @@ class GameplayLoader:
     """dataset/gameplay.rs:21-165."""
 
     def __init__(self, version, *, oracle=True, player_names=None, excludes=None, trust_seed=False,
-                 always_include_kan_select=True, augmented=False, device="cuda:0"):
+                 always_include_kan_select=True, augmented=False, device="cuda:0", deal_algo=None):
         if version not in OBS_ROWS:
             raise ValueError(f"unsupported obs version {version}")
         self.version = version
@@ -180,6 +180,9 @@ class GameplayLoader:
         self.always_include_kan_select = bool(always_include_kan_select)
         self.augmented = bool(augmented)
         self.device = device
+        # trust_seed: wall shuffle tried first when rebuilding a kyoku from its seed (None = pool.default_deal_algo());
+        # the replay kernel falls back to the other rand generation before reporting MJ_ERR_WALL
+        self.deal_algo = deal_algo
         if self.oracle and self.trust_seed and self.augmented:
             raise NotImplementedError("oracle=True with trust_seed=True and augmented=True: the seed rebuilds the "
                                       "un-augmented wall (the reference mixes the two as well); drop one of the flags")
@@ -314,7 +317,7 @@ class GameplayLoader:
                     scripts.append(mjai_log.encode_events(g["events"], augmented=self.augmented, walls=walls))
         tracked = [sum(1 << p for p in g["wanted"]) for g in games]
         total_events = sum(len(g["events"]) for g in games)
-        pool = TablePool(n, version=self.version, device=self.device, max_rows=8 * n + 64)
+        pool = TablePool(n, version=self.version, device=self.device, max_rows=8 * n + 64, deal_algo=self.deal_algo)
         try:
             pool.replay_load(scripts, tracked, self.always_include_kan_select, nonces, keys)
             obs_parts, mask_parts, meta_parts, inv_parts = [], [], [], []

@@ -13,6 +13,23 @@ from ._lib import MortalAmdError, check, lib
 
 OBS_ROWS = {1: 938, 2: 942, 3: 934, 4: 1012}
 ACTION_SPACE = 46
+DEAL_RAND08, DEAL_RAND09 = 0, 1  # include/mortal_amd.h MJ_DEAL_*
+
+
+def default_deal_algo():
+    """The wall shuffle of `Board::init_from_seed` (arena/board.rs:99-109) depends on the `rand` crate generation.
+    Default = rand 0.9.1, the version the reference's Cargo.lock pins (Cargo.lock:1042-1043), so the same (seed, key)
+    gives today's reference's games; MORTAL_AMD_DEAL_ALGO=rand08 selects the older Fisher-Yates (the shuffle of the
+    reference's published example log)."""
+    import os
+
+    v = os.environ.get("MORTAL_AMD_DEAL_ALGO", "rand09").strip().lower()
+    if v in ("0", "rand08", "rand0.8", "0.8"):
+        return DEAL_RAND08
+    if v in ("1", "rand09", "rand0.9", "0.9", "0.9.1"):
+        return DEAL_RAND09
+    raise ValueError(f"MORTAL_AMD_DEAL_ALGO={v!r}: expected rand08 or rand09")
+
 _tables_ready = False
 
 
@@ -29,26 +46,35 @@ def _stream():
 
 
 class TablePool:
-    def __init__(self, n_tables, version=4, deal_algo=0, device="cuda:0", max_rows=0):
+    _L = lib  # the C-ABI library (tests/host/emu_pool.py substitutes the host emulation of the same sources)
+
+    def _stream(self):
+        return _stream()
+
+    def _bind_device(self, device):
         if not torch.cuda.is_available():
             raise MortalAmdError("TablePool needs a HIP device (torch.cuda.is_available() is False)")
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         _ensure_tables()
+
+    def __init__(self, n_tables, version=4, deal_algo=None, device="cuda:0", max_rows=0):
+        self._bind_device(device)
         self.n_tables = n_tables
         self.version = version
         self.C = OBS_ROWS[version]
         self.max_rows = max_rows or 8 * n_tables
-        self.h = lib.mj_pool_create(n_tables, version, deal_algo, self.max_rows)
+        self.deal_algo = default_deal_algo() if deal_algo is None else int(deal_algo)
+        self.h = self._L.mj_pool_create(n_tables, version, self.deal_algo, self.max_rows)
         if not self.h:
-            raise MortalAmdError(lib.mj_last_error().decode())
+            raise MortalAmdError(self._L.mj_last_error().decode())
         self.n_rows = [0, 0]
         self.n_games_total = n_tables
         self.versions = [version, version]
 
     def close(self):
         if getattr(self, "h", None):
-            lib.mj_pool_destroy(self.h)
+            self._L.mj_pool_destroy(self.h)
             self.h = None
 
     __del__ = close
@@ -62,33 +88,33 @@ class TablePool:
         aos = np.ascontiguousarray(agent_of_seat if agent_of_seat is not None else np.zeros(self.n_tables),
                                    dtype=np.uint8)
         self.n_games_total = int(n_games_total or (int(gid.max()) + 1))
-        check(lib.mj_pool_reset(self.h, nonces.ctypes.data, keys.ctypes.data, gid.ctypes.data, aos.ctypes.data,
+        check(self._L.mj_pool_reset(self.h, nonces.ctypes.data, keys.ctypes.data, gid.ctypes.data, aos.ctypes.data,
                                 self.n_games_total))
         self.n_rows = [0, 0]
 
     def configure(self, agent, enable_quick_eval=True, enable_rule_based_agari_guard=False, version=0):
-        check(lib.mj_pool_configure(self.h, agent, int(version), int(enable_quick_eval),
+        check(self._L.mj_pool_configure(self.h, agent, int(version), int(enable_quick_eval),
                                     int(enable_rule_based_agari_guard)))
         if version:
             self.versions[agent] = version
 
     def enable_log(self, words_per_table=16384):
         """Turn the per-table mjai event log on (call before reset/step).  16384 words cover ~60 kyoku."""
-        check(lib.mj_pool_enable_log(self.h, int(words_per_table)))
+        check(self._L.mj_pool_enable_log(self.h, int(words_per_table)))
         self.log_cap = int(words_per_table)
 
     def read_logs(self, chunk=1024):
         """-> list (one per table) of uint64 arrays holding the event words logged so far."""
         n = self.n_tables
         lens = np.zeros(n, dtype=np.uint32)
-        check(lib.mj_log_lengths(self.h, lens.ctypes.data, _stream()))
+        check(self._L.mj_log_lengths(self.h, lens.ctypes.data, self._stream()))
         if (lens > self.log_cap).any():
             raise MortalAmdError(f"event log overflow on table {int(np.argmax(lens > self.log_cap))}")
         out = []
         for t0 in range(0, n, chunk):
             k = min(chunk, n - t0)
             buf = np.empty((k, self.log_cap), dtype=np.uint64)
-            check(lib.mj_log_read(self.h, t0, k, buf.ctypes.data, _stream()))
+            check(self._L.mj_log_read(self.h, t0, k, buf.ctypes.data, self._stream()))
             out += [buf[i, :lens[t0 + i]].copy() for i in range(k)]
         return out
 
@@ -103,14 +129,14 @@ class TablePool:
         tr = np.ascontiguousarray(tracked, dtype=np.uint8)
         n64 = np.ascontiguousarray(nonces, dtype=np.uint64) if nonces is not None else None
         k64 = np.ascontiguousarray(keys, dtype=np.uint64) if keys is not None else None
-        check(lib.mj_replay_load(self.h, script.ctypes.data, off.ctypes.data, tr.ctypes.data, len(scripts),
+        check(self._L.mj_replay_load(self.h, script.ctypes.data, off.ctypes.data, tr.ctypes.data, len(scripts),
                                  int(always_include_kan_select), n64.ctypes.data if n64 is not None else None,
                                  k64.ctypes.data if k64 is not None else None))
 
     def replay_step(self):
-        check(lib.mj_replay_step(self.h, _stream()))
+        check(self._L.mj_replay_step(self.h, self._stream()))
         out = (C.c_int32 * 2)()
-        check(lib.mj_rows_count(self.h, out, _stream()))
+        check(self._L.mj_rows_count(self.h, out, self._stream()))
         self.n_rows = [out[0], out[1]]
         return out[0]
 
@@ -119,41 +145,44 @@ class TablePool:
         n = self.n_rows[0]
         meta = torch.empty((n, 8), dtype=torch.int32, device=self.device)
         if n:
-            check(lib.mj_replay_meta(self.h, meta.data_ptr(), _stream()))
+            check(self._L.mj_replay_meta(self.h, meta.data_ptr(), self._stream()))
         return meta
 
     def set_refill(self, nonce_stride):
-        check(lib.mj_pool_set_refill(self.h, nonce_stride))
+        check(self._L.mj_pool_set_refill(self.h, nonce_stride))
 
     def step(self, actions0=None, actions1=None, q0=None, q1=None):
         """One arena cycle; actionsN = int32 cuda tensor with one action per row of agent N's last batch; qN = that
         batch's q-values (f32 cuda [n, 46]), needed only by an agent configured with the rule-based agari guard."""
         for a in (actions0, actions1):
             if a is not None:
-                assert a.is_cuda and a.dtype == torch.int32 and a.is_contiguous()
+                assert a.device.type == self.device.type and a.dtype == torch.int32 and a.is_contiguous()
         for q in (q0, q1):
             if q is not None:
-                assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.shape[-1] == 46
+                assert q.device.type == self.device.type and q.dtype == torch.float32 and q.is_contiguous() and q.shape[-1] == 46
         p0 = actions0.data_ptr() if actions0 is not None and actions0.numel() else None
         p1 = actions1.data_ptr() if actions1 is not None and actions1.numel() else None
         pq0 = q0.data_ptr() if q0 is not None and q0.numel() else None
         pq1 = q1.data_ptr() if q1 is not None and q1.numel() else None
-        check(lib.mj_step_q(self.h, p0, p1, pq0, pq1, _stream()))
+        check(self._L.mj_step_q(self.h, p0, p1, pq0, pq1, self._stream()))
         out = (C.c_int32 * 2)()
-        check(lib.mj_rows_count(self.h, out, _stream()))
+        check(self._L.mj_rows_count(self.h, out, self._stream()))
         self.n_rows = [out[0], out[1]]
         return self.n_rows
 
     def rows(self, agent):
         """Row descriptors of the current batch as an int64 cpu array [n, 3] = (table, seat, is_kan)."""
         n = self.n_rows[agent]
-        ptr = lib.mj_rows_dev(self.h, agent)
+        ptr = self._L.mj_rows_dev(self.h, agent)
         d = torch.empty(n, dtype=torch.int32, device=self.device)
         if n:
-            torch.cuda.current_stream().synchronize()
-            _memcpy_d2d(d.data_ptr(), ptr, 4 * n)
+            self._copy_rows(d.data_ptr(), ptr, 4 * n)
         v = d.cpu().numpy().view(np.uint32)
         return np.stack([v & 0x0FFFFFFF, (v >> 28) & 3, v >> 31], axis=1).astype(np.int64)
+
+    def _copy_rows(self, dst, src, nbytes):
+        torch.cuda.current_stream().synchronize()
+        _memcpy_d2d(dst, src, nbytes)
 
     def encode(self, agent, obs=None, masks=None):
         """Encode agent's rows in place into (or into fresh) device tensors. Returns (obs [n,C,34] f32, masks [n,46] bool)."""
@@ -164,18 +193,18 @@ class TablePool:
             masks = torch.empty((n, ACTION_SPACE), dtype=torch.bool, device=self.device)
         assert obs.is_contiguous() and masks.is_contiguous() and obs.shape[0] >= n and masks.shape[0] >= n
         if n:
-            check(lib.mj_encode(self.h, agent, obs.data_ptr(), masks.data_ptr(), _stream()))
+            check(self._L.mj_encode(self.h, agent, obs.data_ptr(), masks.data_ptr(), self._stream()))
         return obs[:n], masks[:n]
 
     def encode_oracle(self, agent, out=None):
         """Invisible ("oracle") obs of agent's rows (board.rs:679-782): f32 cuda [n, 211|217, 34]."""
         n = self.n_rows[agent]
-        R = lib.mj_oracle_obs_rows(self.versions[agent])
+        R = self._L.mj_oracle_obs_rows(self.versions[agent])
         if out is None:
             out = torch.empty((n, R, 34), dtype=torch.float32, device=self.device)
-        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= n
+        assert out.device.type == self.device.type and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= n
         assert tuple(out.shape[1:]) == (R, 34)
-        check(lib.mj_encode_oracle(self.h, agent, out.data_ptr(), _stream()))
+        check(self._L.mj_encode_oracle(self.h, agent, out.data_ptr(), self._stream()))
         return out[:n]
 
     def random_policy(self, agent, masks, seed, cycle, out=None):
@@ -183,52 +212,52 @@ class TablePool:
         if out is None:
             out = torch.empty(n, dtype=torch.int32, device=self.device)
         if n:
-            check(lib.mj_random_policy(self.h, agent, masks.data_ptr(), seed, cycle, out.data_ptr(), _stream()))
+            check(self._L.mj_random_policy(self.h, agent, masks.data_ptr(), seed, cycle, out.data_ptr(), self._stream()))
         return out[:n]
 
     def counters(self):
         out = (C.c_uint64 * 8)()
-        check(lib.mj_counters(self.h, out, _stream()))
+        check(self._L.mj_counters(self.h, out, self._stream()))
         return dict(steps=out[0], games=out[1], errors=out[2], decisions=out[3], quick=out[4], cycles=out[5],
                     sp_overflow=out[6])
 
     def results(self):
         scores = np.zeros((self.n_games_total, 4), dtype=np.int32)
         done = np.zeros(self.n_games_total, dtype=np.uint8)
-        check(lib.mj_results(self.h, scores.ctypes.data, done.ctypes.data, _stream()))
+        check(self._L.mj_results(self.h, scores.ctypes.data, done.ctypes.data, self._stream()))
         return scores, done
 
     def first_error(self):
         t = C.c_int(-1)
-        code = check(lib.mj_pool_first_error(self.h, C.byref(t), _stream()))
+        code = check(self._L.mj_pool_first_error(self.h, C.byref(t), self._stream()))
         return code, t.value
 
     def encode_timing(self, enable=True):
         ms = C.c_double(0)
         n = C.c_int64(0)
-        check(lib.mj_encode_timing(self.h, int(enable), C.byref(ms), C.byref(n)))
+        check(self._L.mj_encode_timing(self.h, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def sp_timing(self):
         """(total ms, launches) of the SP-table kernel since the last call (recorded while encode timing is on)."""
         ms = C.c_double(0)
         n = C.c_int64(0)
-        check(lib.mj_sp_timing(self.h, C.byref(ms), C.byref(n)))
+        check(self._L.mj_sp_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def sp_phase_ticks(self):
         """Cumulative mj_k_sp phase timers (workgroup ticks, 100 MHz) and counts since the pool was created."""
         out = (C.c_uint64 * 8)()
-        check(lib.mj_sp_phase_ticks(self.h, out, _stream()))
+        check(self._L.mj_sp_phase_ticks(self.h, out, self._stream()))
         return dict(zip(("overflow", "rows", "setup", "expand", "level0", "eval", "write", "states"), (int(x) for x in out)))
 
     def debug_table(self, table):
-        size = lib.mj_debug_table_size()
+        size = self._L.mj_debug_table_size()
         buf = (C.c_uint8 * size)()
-        check(lib.mj_debug_table(self.h, table, buf, size, _stream()))
+        check(self._L.mj_debug_table(self.h, table, buf, size, self._stream()))
         raw = bytes(buf)
         out = {}
-        for ent in lib.mj_debug_layout().decode().strip(";").split(";"):
+        for ent in self._L.mj_debug_layout().decode().strip(";").split(";"):
             name, size, count, off = ent.split(":")
             size, count, off = int(size), int(count), int(off)
             dt = {1: np.uint8, 2: np.uint16, 4: np.int32, 8: np.uint64}[size]

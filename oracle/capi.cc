@@ -390,6 +390,24 @@ void* mjo_arena_new(int n_games, const u64* nonces, const u64* keys, int deal_al
     return a;
 }
 void mjo_arena_free(void* h) { delete (Arena*)h; }
+// Steady-state mode of the throughput benchmark (no reference counterpart: BatchGame::run never restarts a game): slot `game`,
+// whose hanchan is finished, starts a fresh hanchan on (nonce, same key) — what the device's mj_k_refill does.
+int mjo_arena_restart(void* h, int game, u64 nonce) {
+    return guard([&] {
+        Arena* a = (Arena*)h;
+        if (!a->done.at(game)) throw std::runtime_error("restart of a game that has not finished");
+        auto gm = std::make_unique<Game>();
+        gm->seed_nonce = nonce;
+        gm->seed_key = a->games[game]->seed_key;
+        gm->deal_algo = a->games[game]->deal_algo;
+        gm->keep_log = a->games[game]->keep_log;
+        a->games[game] = std::move(gm);
+        a->done[game] = 0;
+        for (auto& p : a->pending[game]) p = Arena::Pending();
+        a->live.push_back(game);
+        return 0;
+    });
+}
 
 // Poll phase (game.rs:287-289).  Returns the number of policy rows, -1 on error.
 int mjo_arena_poll(void* h) {

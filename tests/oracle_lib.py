@@ -58,6 +58,7 @@ def lib():
     for name in ["mjo_arena_free", "mjo_arena_poll", "mjo_arena_n_live", "mjo_arena_steps", "mjo_arena_cycles"]:
         getattr(L, name).argtypes = [C.c_void_p]
     L.mjo_arena_rows.argtypes = [C.c_void_p, C.c_void_p]
+    L.mjo_arena_restart.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
     L.mjo_arena_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.mjo_arena_commit.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_arena_encode_oracle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -422,6 +423,10 @@ class Arena:
             lib().mjo_arena_free(self.h)
             self.h = None
 
+    def restart(self, g, nonce):
+        """Finished slot g starts a fresh hanchan on (nonce, same key) — the oracle side of the pool's refill mode."""
+        _check(lib().mjo_arena_restart(self.h, int(g), int(nonce)))
+
     def poll(self):
         n = _check(lib().mjo_arena_poll(self.h))
         rows = np.zeros((n, 3), dtype=np.int32)
@@ -429,13 +434,28 @@ class Arena:
             lib().mjo_arena_rows(self.h, ptr(rows))
         return rows
 
-    def encode(self, row0, row1, want_obs=True):
+    def encode(self, row0, row1, want_obs=True, threads=0):
+        """threads > 1: rows are independent and the encoder is const, so disjoint row ranges are encoded concurrently
+        (ctypes releases the GIL) — keeps the big-pool parity tests inside their time budget."""
         n = row1 - row0
         masks = np.zeros((n, 46), dtype=np.uint8)
         obs = None
         if want_obs:
             rows = {1: 938, 2: 942, 3: 934, 4: 1012}[self.version]
             obs = np.empty((n, rows, 34), dtype=np.float32)
+        if threads > 1 and n >= 4 * threads:
+            from concurrent.futures import ThreadPoolExecutor
+
+            cuts = [row0 + (n * k) // (4 * threads) for k in range(4 * threads + 1)]
+
+            def part(k):
+                a, b = cuts[k], cuts[k + 1]
+                return lib().mjo_arena_encode(self.h, a, b, ptr(obs[a - row0:]) if want_obs else None, ptr(masks[a - row0:]))
+
+            with ThreadPoolExecutor(threads) as ex:
+                for rc in ex.map(part, range(4 * threads)):
+                    _check(rc)
+            return obs, masks
         _check(lib().mjo_arena_encode(self.h, row0, row1, ptr(obs) if want_obs else None, ptr(masks)))
         return obs, masks
 

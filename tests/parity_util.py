@@ -99,18 +99,30 @@ def fake_q_values(masks, rows, cycle, seed):
 
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
                  policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
-                 policy="random", guard=False, oracle_obs=False, compare_logs=False):
-    """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch."""
+                 policy="random", guard=False, oracle_obs=False, compare_logs=False, deal_algo=0, refill=0, min_games=2,
+                 threads=0, obs_cycles=None, pool_cls=None):
+    """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch.
+
+    refill = nonce stride: finished slots restart on (nonce + stride, key) on both sides (the pool's steady-state mode,
+    mj_pool_set_refill / mj_k_refill — what bench.py times) until every slot has finished `min_games` hanchan.
+    obs_cycles: explicit set of cycles whose obs are compared (overrides obs_every); threads: oracle encode threads."""
     import torch
 
-    from mortal_amd.pool import TablePool
+    if pool_cls is None:
+        from mortal_amd.pool import TablePool as pool_cls  # tests/test_emu_*.py pass the host emulation of the same kernels
 
     seeds = seeds or default_seeds(n_tables)
-    arena = oracle.Arena(seeds, deal_algo=0, enable_quick_eval=quick_eval, version=version, keep_log=compare_logs)
-    pool = TablePool(n_tables, version=version, deal_algo=0)
+    arena = oracle.Arena(seeds, deal_algo=deal_algo, enable_quick_eval=quick_eval, version=version, keep_log=compare_logs)
+    pool = pool_cls(n_tables, version=version, deal_algo=deal_algo)
     if compare_logs:
         pool.enable_log()
-    pool.reset(seeds)
+    gens_total = 16 if refill else 1
+    pool.reset(seeds, game_ids=np.arange(n_tables), n_games_total=gens_total * n_tables)
+    if refill:
+        pool.set_refill(refill)
+    gen = [0] * n_tables
+    nonce = [int(s[0]) for s in seeds]
+    gen_scores = {}
     pool.configure(0, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
     pool.configure(1, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
     C = pool.C
@@ -144,8 +156,8 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         if n == 0 and arena.n_live == 0:
             break
         obs_g, masks_g = pool.encode(0)
-        want_obs = compare_obs and (cycle % obs_every == 0)
-        obs_o, masks_o = arena.encode(0, n, want_obs=want_obs)
+        want_obs = compare_obs and ((cycle in obs_cycles) if obs_cycles is not None else (cycle % obs_every == 0))
+        obs_o, masks_o = arena.encode(0, n, want_obs=want_obs, threads=threads)
         mg = masks_g.cpu().numpy().astype(np.uint8)
         if not (mg == masks_o).all():
             r = int(np.argwhere((mg != masks_o).any(axis=1))[0][0])
@@ -212,16 +224,40 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         actions = torch.from_numpy(act).to(pool.device)
         stats["cycles"] += 1
         stats["rows"] += n
+        if refill:
+            for g in range(n_tables):
+                sc, dn = arena.result(g)
+                if dn:
+                    gen_scores[(g, gen[g])] = sc.copy()
+                    gen[g] += 1
+                    nonce[g] += refill
+                    arena.restart(g, nonce[g])
+            if min(gen) >= min_games:
+                break
     code, t = pool.first_error()
     assert code == 0, f"gpu table {t} in error {code}"
     scores_g, done_g = pool.results()
     cnt = pool.counters()
+    if refill:
+        # every hanchan the oracle finished (slot g, generation k) is game id g + k * n_tables on the device
+        assert cnt["steps"] == arena.steps, (cnt["steps"], arena.steps)
+        for (g, k), sc in gen_scores.items():
+            if k < gens_total:
+                gid = g + k * n_tables
+                assert done_g[gid] == 1 and (scores_g[gid] == sc).all(), f"slot {g} generation {k}: {scores_g[gid]} vs {sc}"
+        stats.update(counters=cnt, games_checked=len(gen_scores), generations=(min(gen), max(gen)), oracle_steps=int(arena.steps),
+                     scores_checked=len(gen_scores), done_gpu=int((done_g == 1).sum()), done_oracle=len(gen_scores),
+                     guard_hits=int(arena.guard_hits))
+        if verbose:
+            print("lockstep refill", stats)
+        pool.close()
+        return stats
     scores_o = np.array([arena.result(g)[0] for g in range(n_tables)])
     done_o = np.array([arena.result(g)[1] for g in range(n_tables)])
     stats.update(counters=cnt, done_gpu=int((done_g == 1).sum()), done_oracle=int(done_o.sum()),
                  oracle_steps=int(arena.steps), guard_hits=int(arena.guard_hits))
-    both = (done_g == 1) & done_o
-    assert (scores_g[both] == scores_o[both]).all(), "final scores differ"
+    both = (done_g[:n_tables] == 1) & done_o
+    assert (scores_g[:n_tables][both] == scores_o[both]).all(), "final scores differ"
     stats["scores_checked"] = int(both.sum())
     if compare_logs:
         import json

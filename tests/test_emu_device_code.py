@@ -1,0 +1,65 @@
+"""The DEVICE code on the host: the unchanged HIP sources of mortal_amd/csrc, compiled against the fiber-based SIMT emulator
+of tests/host/emu and driven through the same C-ABI and the same lock-step harness as the `-m gpu` parity tests
+(tests/parity_util.py), against the oracle.  Runs without a GPU, so every kernel change is checked bit for bit before it
+costs GPU time; the `-m gpu` tests remain the parity tests proper (real wavefronts, real memory model).
+
+Small sizes: the emulator executes one work-item at a time (a v4 decision with a large SP state graph takes ~0.1 s)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+HOST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
+if HOST not in sys.path:
+    sys.path.insert(0, HOST)
+
+import parity_util  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import build_emu
+
+    if not (os.path.exists(build_emu.CXX) or shutil.which("g++")):
+        pytest.skip("no host C++ compiler")
+    import emu_pool
+
+    return emu_pool.make_pool_class()
+
+
+def test_emu_lockstep_v3_full_hanchan_with_logs(oracle, emu):
+    """step + row assignment + snapshot + encode<3> + event log kernels: two whole hanchan, every obs, every event."""
+    st = parity_util.run_lockstep(oracle, 2, version=3, max_cycles=3000, obs_every=1, pool_cls=emu, compare_logs=True,
+                                  deal_algo=1, verbose=False)
+    assert st["scores_checked"] == 2 and st["obs_checked"] > 1500 and st["log_events_checked"] > 2500
+
+
+def test_emu_lockstep_v4_sp_rows_greedy(oracle, emu):
+    """mj_k_sp (expansion, level-0 scoring, evaluation) under the tenpai-seeking policy: f32 bit-exact SP rows."""
+    st = parity_util.run_lockstep(oracle, 4, version=4, max_cycles=90, obs_every=1, pool_cls=emu, sp_rows_checked=True,
+                                  policy="greedy", verbose=False)
+    assert st["obs_checked"] > 300 and st["counters"]["sp_overflow"] == 0
+
+
+def test_emu_lockstep_older_obs_versions_and_guard(oracle, emu):
+    for version in (1, 2):
+        st = parity_util.run_lockstep(oracle, 2, version=version, max_cycles=150, obs_every=1, pool_cls=emu, policy="greedy",
+                                      verbose=False)
+        assert st["obs_checked"] > 250
+    st = parity_util.run_lockstep(oracle, 4, version=3, max_cycles=700, obs_every=25, pool_cls=emu, policy="greedy",
+                                  guard=True, quick_eval=False, verbose=False)
+    assert st["cycles"] == 700
+
+
+def test_emu_lockstep_refill(oracle, emu):
+    """mj_k_refill (the benchmark's steady-state mode): slots restart on nonce + stride; >= 2 hanchan per slot."""
+    st = parity_util.run_lockstep(oracle, 2, version=3, max_cycles=20000, obs_every=9, pool_cls=emu, refill=8, min_games=2,
+                                  deal_algo=1, verbose=False)
+    assert st["generations"][0] >= 2 and st["games_checked"] >= 4
+
+
+def test_emu_invisible_obs(oracle, emu):
+    st = parity_util.run_lockstep(oracle, 2, version=3, max_cycles=200, obs_every=2, compare_obs=False, pool_cls=emu,
+                                  policy="greedy", oracle_obs=True, verbose=False)
+    assert st["oracle_obs_checked"] > 150

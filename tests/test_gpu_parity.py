@@ -20,10 +20,49 @@ def test_lockstep_v4_full_obs_with_sp(oracle):
 
 
 def test_lockstep_4096_tables_masks_scores(oracle):
-    """BASELINE configs[1] size: 4096 tables, masks + row lists every cycle, final scores of every game."""
-    st = parity_util.run_lockstep(oracle, 4096, version=3, max_cycles=3000, compare_obs=False)
-    assert st["scores_checked"] == 4096
+    """BASELINE configs[1] size: 4096 tables, masks + row lists every cycle, the whole v3 obs of every decision on a
+    sampled cycle set (every 89th cycle, ~4,100 rows each), final scores of every game."""
+    st = parity_util.run_lockstep(oracle, 4096, version=3, max_cycles=3000, obs_cycles=set(range(3, 3000, 89)), threads=16)
+    assert st["scores_checked"] == 4096 and st["obs_checked"] > 50000
     assert st["counters"]["steps"] == st["oracle_steps"]
+
+
+def test_lockstep_4096_tables_v4_obs_with_sp(oracle):
+    """The same pool size with obs v4: all 1012 rows incl. the SP block on sampled cycles of the first kyoku (the most
+    SP-heavy phase: every table at 17 draws left) and later ones."""
+    st = parity_util.run_lockstep(oracle, 4096, version=4, max_cycles=420, obs_cycles={2, 37, 111, 222, 333, 419},
+                                  sp_rows_checked=True, threads=16)
+    assert st["obs_checked"] > 15000 and st["counters"]["sp_overflow"] == 0
+
+
+def test_lockstep_rand09_deal(oracle):
+    """deal_algo = MJ_DEAL_RAND09 (the shuffle of rand 0.9.1, the generation the reference's Cargo.lock pins and the
+    pool's default): device deal == oracle deal (tests/test_oracle_deal.py pins the oracle against a second
+    implementation), whole hanchan with event logs and obs."""
+    st = parity_util.run_lockstep(oracle, 256, version=3, max_cycles=3000, obs_every=3, deal_algo=1, compare_logs=True)
+    assert st["scores_checked"] == 256 and st["log_events_checked"] > 100000
+    st = parity_util.run_lockstep(oracle, 32, version=4, max_cycles=3000, obs_every=9, deal_algo=1, policy="greedy",
+                                  sp_rows_checked=True)
+    assert st["scores_checked"] == 32 and st["counters"]["sp_overflow"] == 0
+
+
+def test_lockstep_refill_matches_benchmark_mode(oracle):
+    """What bench.py times: mj_pool_set_refill — a finished table restarts on (nonce + stride, key) with game id + N.
+    The oracle arena restarts its slots the same way; rows, masks, v4 obs incl. SP rows, step counter and the final
+    scores of every finished hanchan (>= 2 per slot, i.e. tables in their 2nd / 3rd game like the timed window)."""
+    st = parity_util.run_lockstep(oracle, 48, version=4, max_cycles=20000, obs_every=6, sp_rows_checked=True, refill=12,
+                                  min_games=2, deal_algo=1, threads=8)
+    assert st["generations"][0] >= 2 and st["games_checked"] >= 96 and st["counters"]["sp_overflow"] == 0
+    st = parity_util.run_lockstep(oracle, 256, version=3, max_cycles=20000, obs_every=11, refill=64, min_games=3,
+                                  policy="greedy", threads=8)
+    assert st["generations"][0] >= 3 and st["games_checked"] >= 768
+
+
+def test_lockstep_quick_eval_disabled(oracle):
+    """enable_quick_eval = False (mortal.rs:210-250): single-candidate discards get a row, every ankan/kakan decision
+    gets a kan-select row."""
+    st = parity_util.run_lockstep(oracle, 128, version=3, max_cycles=3000, obs_every=2, quick_eval=False, policy="greedy")
+    assert st["scores_checked"] == 128 and st["counters"]["quick"] == 0
 
 
 def test_lockstep_greedy_policy_v3(oracle):
