@@ -34,6 +34,31 @@ template <int W> MJD void mj_team_sync() {
 template <int W> inline void mj_team_sync() { emu::group_sync(W); }
 #endif
 
+// ---- IEEE f32 division a / b with the divisor's refined reciprocal hoisted.  For operands that need no scaling (neither
+// denormal, quotient not denormal, exponents less than 96 apart — true here: probabilities in [1e-25, 1]) the division
+// sequence of the hardware / of LLVM's lowering is  r0 = rcp(b); e0 = fma(-b, r0, 1); r1 = fma(e0, r0, r0);
+// q0 = a * r1; e1 = fma(-b, q0, a); q1 = fma(e1, r1, q0); e2 = fma(-b, q1, a); q = fma(e2, r1, q1)  — correctly rounded
+// for any r0 within 1 ulp of 1/b.  A lane divides by the same not_tsumo value all the time, so r1 is computed once per
+// state and a division costs 5 instructions instead of 10 (tests/host/algo_check.hip checks q == a / b on 10^8 operands
+// of the domain for r0 = RN(1/b) and both neighbours).
+MJD float sp_rcp_refined(float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(b);
+#else
+    const float r0 = 1.0f / b;
+#endif
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    return __builtin_fmaf(e0, r0, r0);
+}
+MJD float sp_div(float a, float b, float r1) {
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
+
 enum : int { T_5M = 4, T_5P = 13, T_5S = 22, T_E = 27, T_S = 28, T_W = 29, T_N = 30, T_P = 31, T_F = 32, T_C = 33,
              T_5MR = 34, T_5PR = 35, T_5SR = 36, T_UNK = 37 };
 
