@@ -30,8 +30,15 @@ template <int W> MJD void mj_team_sync() {
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
 }
+// the same for teams of `width` consecutive lanes, any width (team k = lanes [k * width, (k + 1) * width) of the wavefront)
+MJD void mj_team_sync_n(int width) {
+    (void)width;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+}
 #else
 template <int W> inline void mj_team_sync() { emu::group_sync(W); }
+inline void mj_team_sync_n(int width) { emu::group_sync(width); }
 #endif
 
 // ---- IEEE f32 division a / b with the divisor's refined reciprocal hoisted.  For operands that need no scaling (neither

@@ -44,6 +44,8 @@ struct SpNode {                 // one 3n+1 state (608 bytes, 16-byte aligned ro
     u8 l0cnt[SP_L0_MAX + 3];    // level 0: copies left in the wall of every draw entry (its tsumo_prob row)
 };
 static_assert(sizeof(SpNode) == 608 && offsetof(SpNode, val) % 16 == 0 && offsetof(SpNode, sc) % 16 == 0, "SpNode layout");
+static_assert(offsetof(SpNode, child_off) % 8 == 0 && offsetof(SpNode, n_ch) == offsetof(SpNode, child_off) + 4 &&
+              offsetof(SpNode, sumreq) == offsetof(SpNode, child_off) + 6, "sp_eval_team reads the header as one u64");
 // A child-list entry: hash slot of the child | discard order key << 14 | last-discard-of-its-draw-entry << 23 |
 // draw count << 24 | invalid (hash set overflow) << 27.  Order: draw tile ascending, plain before red, discard ascending.
 #define SP_ENT_SLOT(e) ((e) & 0x3FFFu)
@@ -352,8 +354,18 @@ struct SpChunk {
     u8 cnt[SP_NS][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds (shanten.rs:104-137)
     u8 tiles[SP_NS][36], kinds[SP_NS][16];
     u8 n_tiles[SP_NS], n_kinds[SP_NS];
+    unsigned short inv[SP_NS];   // ceil(65536 / n_kinds): item index -> (tile ordinal, kind ordinal) without a division
+    unsigned short queue[128];   // ring of kept (state, tile ordinal, kind ordinal) items waiting for the dense insert pass
 };
 #define SP_NT 64  // co-operating threads of a chunk
+constexpr bool sp_item_div_is_exact() {  // (local * ceil(65536 / nk)) >> 16 == local / nk over the whole item space of a state
+    for (int nk = 2; nk <= 16; nk++)
+        for (int local = 0; local < 34 * 16; local++)
+            if (((local * ((65536 + nk - 1) / nk)) >> 16) != local / nk) return false;
+    return true;
+}
+static_assert(sp_item_div_is_exact(), "item index reciprocal");
+static_assert(SP_NS <= 8, "queue entries hold the state in 3 bits");
 
 MJD SpState sp_chunk_state(const SpChunk* C, int s) {
     SpState S;
@@ -493,8 +505,10 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         if ((req >> t) & 1) C->tiles[s][__popcll(req & below)] = (u8)t;
         if ((safe >> t) & 1) C->kinds[s][__popcll(safe & below)] = (u8)t;
         if (t == 0) {
+            const int nk = __popcll(safe);
             C->n_tiles[s] = (u8)__popcll(req);
-            C->n_kinds[s] = (u8)__popcll(safe);
+            C->n_kinds[s] = (u8)nk;
+            C->inv[s] = (unsigned short)(nk > 1 ? (65536 + nk - 1) / nk : 0);  // nk == 1: handled apart (65536 does not fit)
         }
     }
     mj_team_sync<SP_NT>();
@@ -529,7 +543,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         }
         s = lo;
         const int local = it - C->item_off[s], nk = C->n_kinds[s];
-        ti = local / nk;
+        ti = nk > 1 ? (local * (int)C->inv[s]) >> 16 : local;  // local < 34 * 13: exact (sp_item_div_is_exact)
         ki = local - ti * nk;
     };
     for (int it = tid; it < n_items; it += SP_NT) {
@@ -569,14 +583,13 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         node.sumreq = (u8)(sumreq & 0xFF);
     }
     mj_team_sync<SP_NT>();
-    // P7: children — the kept (t, d) of the same item space; each inserts its child state(s) (one per existing draw variant
-    // of t) into the hash set and leaves its child-list entry at its place of the reference's order (t, variant, d ascending)
-    for (int it = tid; it < n_items; it += SP_NT) {
-        int s, ti, ki;
-        item_decode(it, s, ti, ki);
+    // P7: children.  The kept (t, d) of the item space are few (about a third) and an insert is long, so the items are
+    // first compacted through a small ring (wave ballot + prefix), and the inserts run over full wavefronts of kept items:
+    // each inserts its child state(s) (one per existing draw variant of t) into the hash set and leaves its child-list entry
+    // at its place of the reference's order (t, variant, d ascending).
+    auto insert_children = [&](int s, int ti, int ki) {
         const u32 bits = sp_chunk_keep(C, s, ti);
         const int t = C->tiles[s][ti], d = C->kinds[s][ki];
-        if (d == t || !((bits >> ki) & 1)) continue;
         const SpState S = sp_chunk_state(C, s);
         const int nk = __popc(bits), rank = __popc(bits & ((1u << ki) - 1));
         const int cnt = S.w.get(t);
@@ -607,8 +620,33 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
                             ((u32)count << 24);
             if (pos < SP_POOL) Wg->pool[pos] = ent;
         }
+    };
+    int q_head = 0, q_n = 0;  // uniform over the wavefront
+    for (int it0 = 0; it0 < n_items || q_n > 0; it0 += SP_NT) {
+        if (it0 < n_items) {
+            const int it = it0 + tid;
+            bool kept = false;
+            int s = 0, ti = 0, ki = 0;
+            if (it < n_items) {
+                item_decode(it, s, ti, ki);
+                kept = C->tiles[s][ti] != C->kinds[s][ki] && ((sp_chunk_keep(C, s, ti) >> ki) & 1);
+            }
+            const unsigned long long m = __ballot(kept);
+            if (kept) C->queue[(q_head + q_n + __popcll(m & ((1ull << tid) - 1))) & 127] = (unsigned short)(s | (ti << 3) | (ki << 9));
+            q_n += __popcll(m);
+            mj_team_sync<SP_NT>();
+        }
+        if (q_n >= SP_NT || it0 + SP_NT >= n_items) {  // a full wavefront of kept items, or the tail
+            const int take = min(q_n, SP_NT);
+            if (tid < take) {
+                const int e = C->queue[(q_head + tid) & 127];
+                insert_children(e & 7, (e >> 3) & 63, (e >> 9) & 15);
+            }
+            q_head = (q_head + take) & 127;
+            q_n -= take;
+            mj_team_sync<SP_NT>();
+        }
     }
-    mj_team_sync<SP_NT>();
 }
 
 template <int J, int N, class F>
@@ -620,17 +658,15 @@ MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_const
 }
 
 // Per-team LDS of the evaluation: the folded child values of the current draw entry (double buffered: one team hand-off
-// per entry) and the numerators A[c][j] = tsumo_prob[c][j] * not_tsumo[j] of the state's probability table.
-template <int TW>
-struct SpEvalLds {
-    static constexpr int TN = TW > SP_T ? SP_T : TW;  // turns a team covers: 8, 16, 17
-    float nx[2][TN + 1][4];
-    float A[4][TN];
-};
+// per entry) and the numerators A[c][j] = tsumo_prob[c][j] * not_tsumo[j] of the state's probability table.  A team is
+// exactly T lanes wide (T = draws left, a constant of the row): floor(64 / T) teams per wavefront, so rows with 9 draws
+// left run 7 states per wavefront instead of 4.  Team scratch: nx[2][T + 1][4] then A[4][T] floats.
+#define SP_EVAL_LDS_FLOATS (3072 + 2048)            /* (256 / T) teams x (12 T + 8) floats, T >= 1 */
+MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
 #define SP_CH 8  // children (or level-0 draw entries) fetched per round trip
 
-// Evaluate one state with a TEAM of TW lanes, lane i = turn i: tenpai / win / EV of calc.rs:447-561 into node.val[i].
-// LK = min(level, 2).  TW = 8 / 16 / 32 for rows with at most 8 / 16 / 17 draws left.
+// Evaluate one state with a TEAM of T lanes, lane i = turn i: tenpai / win / EV of calc.rs:447-561 into node.val[i].
+// LK = min(level, 2); TN = 8 / 16 / 17 bounds the unrolled turn loop (rows with at most 8 / 16 / 17 draws left).
 //   level 0 : for every draw entry with a yaku, accumulate its scores;
 //   level > 0: walk the state's child list (written by sp_expand_chunk in the reference's order); per turn fold the
 //              children of a draw entry like discard_slow (max of (int)EV, then discard priority), then accumulate.
@@ -638,30 +674,30 @@ struct SpEvalLds {
 // not_tsumo[j] / not_tsumo[i] times next[j + 1] — terms the reference skips (`break` on a zero probability, j < i for a
 // lane that runs all j) are added as +0.0 products instead of being branched over (x + 0.0 == x for the non-negative
 // sums here), so the unrolled j loop has no divergent control flow.
-template <int TW, int LK>
-__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, SpEvalLds<TW>* TM, int slot) {
+template <int TN, int LK>
+__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int slot, int ln) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(TM);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    constexpr int TN = SpEvalLds<TW>::TN;
-    const int ln = threadIdx.x & (TW - 1);
     SP_HBM SpNode& node = Wg->node[slot];
     const int T = X->T;
-    const u32 child_off = LK > 0 ? node.child_off : __hip_atomic_load(&node.child_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int n_ch = node.n_ch;
-    const float* nt = X->not_tsumo[min((int)node.sumreq, 123)];
-    const bool lane_t = ln < T;
-    const float m_raw = lane_t ? nt[min(ln, SP_T - 1)] : 0.f;  // not_tsumo_probs[i] of this lane's turn
-    const bool lane_on = lane_t && m_raw != 0.f;
+    float* const nxb = TM;                  // nx[buf][k][4]
+    float* const Ab = TM + 8 * (T + 1);     // A[c][j]
+    // child_off | n_ch << 32 | sumreq << 48 in one 8-byte load (level 0: past the L1, the yaku bits were set by L2 atomics)
+    SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&node.child_off);
+    const u64 hdr = LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 child_off = (u32)hdr;
+    const int n_ch = (int)((hdr >> 32) & 0xFFFF);
+    const float* nt = X->not_tsumo[min((int)((hdr >> 48) & 0xFF), 123)];
+    const float m_raw = nt[ln];  // not_tsumo_probs[i] of this lane's turn
+    const bool lane_on = m_raw != 0.f;
     const float my_m = lane_on ? m_raw : 1.f;
     const float my_r = sp_rcp_refined(my_m);
     const int eff_ln = lane_on ? ln : 127;  // `eff_ln <= j` == this lane has a term at turn j
-    mj_team_sync<TW>();  // the team's previous state is done with A[] / nx[]
-    if (ln < TN) {
+    mj_team_sync_n(T);  // the team's previous state is done with A[] / nx[]
 #pragma unroll
-        for (int c = 0; c < 4; c++) TM->A[c][ln] = lane_t ? X->tsumo_prob[c][min(ln, SP_T - 1)] * m_raw : 0.f;
-    }
-    mj_team_sync<TW>();
+    for (int c = 0; c < 4; c++) Ab[c * T + ln] = X->tsumo_prob[c][ln] * m_raw;
+    mj_team_sync_n(T);
     const bool assume_riichi = X->is_menzen && X->prefer_riichi;
     const int hp_base = (int)(assume_riichi && X->calc_double_riichi && ln == 0);
     const bool haitei = X->calc_haitei != 0;
@@ -669,7 +705,8 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, SpEvalLds<TW>* TM
 
     // one draw entry: scores (level 0) or the folded child values in nx[buf] (level > 0)
     auto accumulate = [&](int count, int buf, float s0, float s1, float s2, float s3) {
-        const float* Ac = TM->A[count - 1];
+        const float* Ac = Ab + (count - 1) * T;
+        const float* nx = nxb + buf * 4 * (T + 1);
         sp_static_for<0, TN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (j >= T) return;  // uniform (T is a constant of the row)
@@ -682,7 +719,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, SpEvalLds<TW>* TM
             } else {
                 if constexpr (LK == 1) acc_t += prob;
                 if (j < T - 1) {
-                    const float* v = TM->nx[buf][j + 1];
+                    const float* v = nx + 4 * (j + 1);
                     if constexpr (LK > 1) acc_t += prob * v[0];
                     acc_w += prob * v[1];
                     acc_e += prob * v[2];
@@ -721,8 +758,8 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, SpEvalLds<TW>* TM
             float v[SP_CH][4];
 #pragma unroll
             for (int q = 0; q < SP_CH; q++) {
-                const SP_HBM float* src = Wg->node[SP_ENT_SLOT(ent[q])].val[lane_t ? ln : 0];
-                const bool ok = c0 + q < n_ch && lane_t && !(ent[q] & SP_ENT_INVALID);
+                const SP_HBM float* src = Wg->node[SP_ENT_SLOT(ent[q])].val[ln];
+                const bool ok = c0 + q < n_ch && !(ent[q] & SP_ENT_INVALID);
 #pragma unroll
                 for (int k = 0; k < 4; k++) v[q][k] = ok ? src[k] : 0.f;
             }
@@ -732,7 +769,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, SpEvalLds<TW>* TM
                 const u32 e = ent[q];
                 if (e & SP_ENT_INVALID) {
                     X->overflow = 1;
-                } else if (lane_t) {
+                } else {
                     const int value = __float_as_int(v[q][3]);  // `as i32` of the child's EV (maximize_win_prob = false)
                     const int key = (int)SP_ENT_KEY(e);       // cmp_discard_priority(dt, max_tile) > 0  <=>  key > max_key
                     if (value > max_value || (value == max_value && key > max_key)) {
@@ -744,11 +781,9 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, SpEvalLds<TW>* TM
                     }
                 }
                 if (e & SP_ENT_LAST) {  // last child of this draw entry (uniform in the team)
-                    if (ln < TN) {
-                        float* dst = TM->nx[buf][ln];
-                        dst[0] = nx_t; dst[1] = nx_w; dst[2] = nx_e; dst[3] = 0.f;
-                    }
-                    mj_team_sync<TW>();
+                    float* dst = nxb + (buf * (T + 1) + ln) * 4;
+                    dst[0] = nx_t; dst[1] = nx_w; dst[2] = nx_e; dst[3] = 0.f;
+                    mj_team_sync_n(T);
                     accumulate(min(max((int)SP_ENT_COUNT(e), 1), 4), buf, 0.f, 0.f, 0.f, 0.f);
                     buf ^= 1;
                     nx_t = nx_w = nx_e = -3.40282347e+38f;
@@ -758,10 +793,8 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, SpEvalLds<TW>* TM
             }
         }
     }
-    if (lane_t) {
-        SP_HBM float* dst = node.val[ln];
-        dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
-    }
+    SP_HBM float* dst = node.val[ln];
+    dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
 }
 
 MJD int f32_total_cmp(float a, float b) {
@@ -777,9 +810,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
     __shared__ int s_row;
     __shared__ union SpTeams {
         SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
-        SpEvalLds<8> ev8[SP_THREADS / 8];            // evaluation teams (rows with <= 8 / <= 16 / 17 draws left)
-        SpEvalLds<16> ev16[SP_THREADS / 16];
-        SpEvalLds<32> ev32[SP_THREADS / 32];
+        float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
         struct {                 // row set-up (candidates + their required tiles), before any team runs
             u64 r2[6], r3[4];    // partial merges of the root hand's rows (mj_algo.h sh_merge)
             u64 rowt[34];        // row of root + t in suit(t)
@@ -1095,18 +1126,30 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
                     __syncthreads();
                 }
-                auto eval_level = [&](auto tw, auto* lds) {
-                    constexpr int TW = decltype(tw)::value;
-                    for (int i = b + tid / TW; i < e; i += SP_THREADS / TW) {
-                        const int slot = (int)W->list[i];
-                        if (lv == 0) sp_eval_team<TW, 0>(W, &X, &lds[tid / TW], slot);
-                        else if (lv == 1) sp_eval_team<TW, 1>(W, &X, &lds[tid / TW], slot);
-                        else sp_eval_team<TW, 2>(W, &X, &lds[tid / TW], slot);
+                {
+                    // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
+                    const int wl = tid & 63, tpw = 64 / T, tw = wl / T, ln = wl - tw * T;
+                    const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
+                    float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
+                    if (tw < tpw) {
+                        for (int i = b + team; i < e; i += n_teams) {
+                            const int slot = (int)W->list[i];
+                            if (T <= 8) {
+                                if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, slot, ln);
+                                else if (lv == 1) sp_eval_team<8, 1>(W, &X, lds, slot, ln);
+                                else sp_eval_team<8, 2>(W, &X, lds, slot, ln);
+                            } else if (T <= 16) {
+                                if (lv == 0) sp_eval_team<16, 0>(W, &X, lds, slot, ln);
+                                else if (lv == 1) sp_eval_team<16, 1>(W, &X, lds, slot, ln);
+                                else sp_eval_team<16, 2>(W, &X, lds, slot, ln);
+                            } else {
+                                if (lv == 0) sp_eval_team<17, 0>(W, &X, lds, slot, ln);
+                                else if (lv == 1) sp_eval_team<17, 1>(W, &X, lds, slot, ln);
+                                else sp_eval_team<17, 2>(W, &X, lds, slot, ln);
+                            }
+                        }
                     }
-                };
-                if (T <= 8) eval_level(std::integral_constant<int, 8>{}, s_tm.ev8);
-                else if (T <= 16) eval_level(std::integral_constant<int, 16>{}, s_tm.ev16);
-                else eval_level(std::integral_constant<int, 32>{}, s_tm.ev32);
+                }
                 __syncthreads();
                 if (lv == 0) t_3 = wall_clock64();
             }

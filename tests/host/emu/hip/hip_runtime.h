@@ -114,8 +114,8 @@ struct State {
     unsigned bar_gen = 0;
     unsigned long long progress = 0;
     // wave collectives: [wave][log2 width] -> group barriers + exchange buffers (double buffered by generation parity)
-    std::vector<GroupBar> gbar;           // [n_waves][7][64]
-    std::vector<unsigned long long> xbuf;  // [n_waves][7][2][64]
+    std::vector<GroupBar> gbar;           // [n_waves][width 1..64][group]
+    std::vector<unsigned long long> xbuf;  // [n_waves][width][2][64]
     std::vector<char> dyn_shared;
 };
 inline State& S() {
@@ -163,11 +163,7 @@ inline void syncthreads() {
     wait_for_gen(&s.bar_gen, g);
     s.progress++;
 }
-inline int log2i(int w) {
-    int l = 0;
-    while ((1 << l) < w) l++;
-    return l;
-}
+inline int log2i(int w) { return w; }  // lane groups of ANY width (team k = lanes [k * width, (k + 1) * width)): indexed by the width itself
 inline int group_alive(int wave, int width, int grp) {
     State& s = S();
     int n = 0;
@@ -177,7 +173,7 @@ inline int group_alive(int wave, int width, int grp) {
     }
     return n;
 }
-inline GroupBar& gb(int wave, int wl, int grp) { return S().gbar[((size_t)wave * 7 + wl) * WAVE + grp]; }
+inline GroupBar& gb(int wave, int wl, int grp) { return S().gbar[((size_t)wave * 65 + wl) * WAVE + grp]; }
 // rendezvous of the calling lane's `width`-lane group; returns the generation the group had on arrival
 inline unsigned group_sync(int width) {
     State& s = S();
@@ -197,8 +193,8 @@ inline unsigned group_sync(int width) {
 inline void on_exit_lane(int t) {
     State& s = S();
     const int lane = t % WAVE, wave = t / WAVE;
-    for (int wl = 0; wl <= 6; wl++) {
-        const int width = 1 << wl, grp = lane / width;
+    for (int wl = 1; wl <= 64; wl++) {
+        const int width = wl, grp = lane / width;
         GroupBar& b = gb(wave, wl, grp);
         if (b.arrived > 0 && b.arrived >= group_alive(wave, width, grp)) {
             b.arrived = 0;
@@ -214,7 +210,7 @@ inline T exchange(T v, int width, const std::function<int(int lane)>& src_of) {
     State& s = S();
     const int lane = s.cur % WAVE, wave = s.cur / WAVE, wl = log2i(width), grp = lane / width;
     const unsigned g = gb(wave, wl, grp).gen;
-    unsigned long long* buf = &s.xbuf[(((size_t)wave * 7 + wl) * 2 + (g & 1)) * WAVE];
+    unsigned long long* buf = &s.xbuf[(((size_t)wave * 65 + wl) * 2 + (g & 1)) * WAVE];
     unsigned long long raw = 0;
     memcpy(&raw, &v, sizeof(T));
     buf[lane] = raw;
@@ -254,8 +250,8 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
             s.fibers[t].stack = (char*)p;
         }
     const int n_waves = (n + WAVE - 1) / WAVE;
-    s.gbar.assign((size_t)n_waves * 7 * WAVE, GroupBar());
-    s.xbuf.assign((size_t)n_waves * 7 * 2 * WAVE, 0ull);
+    s.gbar.assign((size_t)n_waves * 65 * WAVE, GroupBar());
+    s.xbuf.assign((size_t)n_waves * 65 * 2 * WAVE, 0ull);
     if (s.dyn_shared.size() < shmem + 64) s.dyn_shared.resize(shmem + 64);
     for (unsigned bz = 0; bz < grid.z; bz++)
         for (unsigned by = 0; by < grid.y; by++)
@@ -345,12 +341,15 @@ template <class T> inline T __shfl_xor(T v, int m, int width = 64) {
 }
 inline unsigned long long __ballot(int pred) {
     emu::State& s = emu::S();
-    const int wave = s.cur / emu::WAVE;
+    const int lane = s.cur % emu::WAVE, wave = s.cur / emu::WAVE;
+    const unsigned g = emu::gb(wave, 64, 0).gen;
+    unsigned long long* buf = &s.xbuf[(((size_t)wave * 65 + 64) * 2 + (g & 1)) * emu::WAVE];
+    buf[lane] = pred ? 1 : 0;
+    emu::group_sync(64);
     unsigned long long m = 0;
     for (int l = 0; l < emu::WAVE; l++) {
-        int p = emu::exchange<int>(pred ? 1 : 0, 64, [=](int) { return l; });
         const int t = wave * emu::WAVE + l;
-        if (t < s.n_threads && !s.fibers[t].done && p) m |= 1ull << l;
+        if (t < s.n_threads && !s.fibers[t].done && buf[l]) m |= 1ull << l;
     }
     return m;
 }
