@@ -41,7 +41,8 @@ def _cpu_worker(version, budget_s, n_tables, wid):
     while time.perf_counter() - t0 < budget_s:
         g0 = (wid * 1000 + batches) * n_tables
         seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(n_tables)]
-        arena = O.Arena(seeds, deal_algo=0, enable_quick_eval=True, version=version, keep_log=False)
+        algo = 0 if os.environ.get("MORTAL_AMD_DEAL_ALGO", "rand09").lower() in ("0", "rand08", "rand0.8", "0.8") else 1
+        arena = O.Arena(seeds, deal_algo=algo, enable_quick_eval=True, version=version, keep_log=False)  # pool.default_deal_algo()
         cycle = 0
         while arena.n_live > 0 and time.perf_counter() - t0 < budget_s:
             rows = arena.poll()
@@ -114,6 +115,87 @@ def _phase_ticks(pool):
         return None
 
 
+def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmup, bufs, engine=None, barrier=None,
+             deal_algo=None):
+    """One workload: pool of N tables, `preroll` untimed cycles (cheap v3 encode), `warmup` untimed and `steps` timed cycles
+    of step + encode(+SP) + policy.  Returns the raw measurements (host wall time, HIP-event kernel times, counters)."""
+    import numpy as np
+    import torch
+
+    obs, masks, act = bufs
+    seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(N)]
+    pool = pool_cls(N, version=version, deal_algo=deal_algo, device=str(dev), max_rows=2 * N)
+    pool.reset(seeds, game_ids=np.arange(N), n_games_total=N)
+    pool.set_refill(world * N // 4)  # a finished table restarts on a seed no other table/rank uses
+    C = pool.C
+    obs_v = obs[: 2 * N * C * 34].view(2 * N, C, 34)
+    obs_3 = obs[: 2 * N * 934 * 34].view(2 * N, 934, 34)
+    use_net = [False]
+
+    def cycle(i, a_prev, ob):
+        n, _ = pool.step(a_prev, None)
+        pool.encode(0, ob, masks)
+        if use_net[0]:
+            return engine.react_batch_device(ob[:n], masks[:n]), n
+        if policy == "greedy":
+            pool.greedy_policy(0, masks, ob, 0x9E3779B97F4A7C15, i & 0xFFFFFFFF, act)
+        else:
+            pool.random_policy(0, masks, 0x9E3779B97F4A7C15, i & 0xFFFFFFFF, act)
+        return act[:n], n
+
+    a_prev = None
+    # steady-state mix of game phases: a hanchan lasts a few thousand cycles under the random policy and its kyoku end at
+    # different times, so after 3072 cycles the tables are spread over every phase (SP cost depends strongly on it)
+    if preroll > 0:
+        pool.configure(0, version=3)
+        for i in range(-preroll, 0):
+            a_prev, _ = cycle(i, a_prev, obs_3)
+        pool.configure(0, version=version)
+    use_net[0] = engine is not None
+    for i in range(warmup):
+        a_prev, _ = cycle(i, a_prev, obs_v)
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    c0 = pool.counters()
+    ph0 = _phase_ticks(pool) if version == 4 else None
+    pool.encode_timing(True)
+    rows_timed = 0
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        a_prev, n = cycle(i, a_prev, obs_v)
+        rows_timed += n
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    c1 = pool.counters()
+    enc_ms, enc_launches = pool.encode_timing(False)
+    sp_ms, sp_launches = pool.sp_timing()
+    ph1 = _phase_ticks(pool) if ph0 is not None else None
+    code, tbl = pool.first_error()
+    if code:
+        raise SystemExit(f"table {tbl} in error {code}")
+    res = dict(steps=c1["steps"] - c0["steps"], games=c1["games"] - c0["games"], dt=dt, rows=rows_timed, enc_ms=enc_ms,
+               enc_launches=enc_launches, sp_ms=sp_ms, sp_launches=sp_launches, C=C, n_cycles=steps, sp_overflow=c1["sp_overflow"])
+    if ph0 is not None and ph1 is not None:
+        d = {k: ph1[k] - ph0[k] for k in ph1}
+        tot = max(1, sum(d[k] for k in ("setup", "expand", "level0", "eval", "write")))
+        res["sp_phases"] = {"share": {k: round(d[k] / tot, 4) for k in ("setup", "expand", "level0", "eval", "write")},
+                            "states_per_step": d["states"] / steps, "rows_per_step": d["rows"] / steps, "overflows": d["overflow"]}
+    res["results"] = pool.results() if world > 1 else None
+    pool.close()
+    return res
+
+
+def _brief(r):
+    """A workload-matrix entry: the same quantities as the headline, for another workload (all driver-timed)."""
+    return {"value": r["steps"] / r["dt"], "unit": "env steps/s", "ms_per_step": r["dt"] / r["n_cycles"] * 1e3,
+            "games_per_sec": r["games"] / r["dt"], "decisions_per_step": r["rows"] / r["n_cycles"],
+            "kernel_ms_per_step": {"mj_k_encode": r["enc_ms"] / r["n_cycles"], "mj_k_sp": r["sp_ms"] / r["n_cycles"]},
+            "sp_states_per_step": (r.get("sp_phases") or {}).get("states_per_step"), "steps": r["n_cycles"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,11 +206,13 @@ def main():
     ap.add_argument("--preroll", type=int, default=3072,
                     help="untimed cycles played before the warmup (with the cheap v3 encode) so that the tables are spread "
                          "over all phases of a hanchan instead of all sitting in the first turns of E1")
-    ap.add_argument("--policy", choices=["random", "brain"], default="random",
-                    help="random = uniform-random legal action on device (BASELINE configs[1]); brain = greedy argmax of a "
-                         "random-init network of the reference's Brain/DQN architecture (192 ch x 40 blocks, bf16 autocast), "
-                         "consuming the encoded batch in place (BASELINE configs[2])")
+    ap.add_argument("--policy", choices=["random", "greedy", "brain"], default="random",
+                    help="random = uniform-random legal action on device (BASELINE configs[1]); greedy = tenpai-seeking policy on "
+                         "device (hands at 0..3 shanten: realistic SP load); brain = greedy argmax of a random-init network of "
+                         "the reference's Brain/DQN architecture (192 ch x 40 blocks, bf16 autocast), consuming the encoded "
+                         "batch in place (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-matrix", action="store_true", help="skip the extra workloads (obs v3, no pre-roll, greedy policy)")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-tables", type=int, default=16, help=argparse.SUPPRESS)
@@ -137,7 +221,6 @@ def main():
         print(json.dumps(_cpu_worker(args.version, args.cpu_budget, args.cpu_tables, args.cpu_worker)))
         return
 
-    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", 0))
@@ -150,19 +233,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    from mortal_amd.pool import TablePool
+    from mortal_amd.pool import TablePool, default_deal_algo
 
     N = args.tables
-    # tables shard by contiguous game-index ranges, multiples of 4 so each duplicate-deal set stays on one GPU
-    g0 = rank * N
-    seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(N)]
-    pool = TablePool(N, version=args.version, deal_algo=0, device=str(dev), max_rows=2 * N)
-    pool.reset(seeds, game_ids=np.arange(N), n_games_total=N)
-    pool.set_refill(world * N // 4)  # a finished table restarts on a seed no other table/rank uses
-    C = pool.C
-    obs = torch.empty((2 * N, C, 34), dtype=torch.float32, device=dev)
-    masks = torch.empty((2 * N, 46), dtype=torch.bool, device=dev)
-    act = torch.empty(2 * N, dtype=torch.int32, device=dev)
+    g0 = rank * N  # tables shard by contiguous game-index ranges, multiples of 4: each duplicate-deal set stays on one GPU
+    bufs = (torch.empty(2 * N * 1012 * 34, dtype=torch.float32, device=dev), torch.empty((2 * N, 46), dtype=torch.bool, device=dev),
+            torch.empty(2 * N, dtype=torch.int32, device=dev))
 
     engine = None
     if args.policy == "brain":
@@ -170,53 +246,15 @@ def main():
 
         torch.manual_seed(0)
         engine = DeviceEngine(PolicyNet(version=args.version if args.version >= 2 else 2), args.version, dev, enable_amp=True)
-    use_net = [False]
 
-    def cycle(i, a_prev):
-        n, _ = pool.step(a_prev, None)
-        pool.encode(0, obs, masks)
-        if use_net[0]:
-            return engine.react_batch_device(obs[:n], masks[:n]), n
-        pool.random_policy(0, masks, 0x9E3779B97F4A7C15, i, act)
-        return act[:n], n
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
 
-    a_prev = None
-    # steady-state mix of game phases: a hanchan lasts a few thousand cycles under the random policy and its kyoku end at
-    # different times, so after 3072 cycles the tables are spread over every phase (SP cost depends strongly on it)
-    if args.preroll > 0:
-        pool.configure(0, version=3)
-        for i in range(-args.preroll, 0):
-            a_prev, _ = cycle(i & 0xFFFFFFFF, a_prev)
-        pool.configure(0, version=args.version)
-    use_net[0] = engine is not None
-    for i in range(args.warmup):
-        a_prev, _ = cycle(i, a_prev)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    c0 = pool.counters()
-    ph0 = _phase_ticks(pool) if args.version == 4 else None
-    pool.encode_timing(True)
-    rows_timed = 0
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        a_prev, n = cycle(i, a_prev)
-        rows_timed += n
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    c1 = pool.counters()
-    enc_ms, enc_launches = pool.encode_timing(False)
-    sp_ms, sp_launches = pool.sp_timing()
-    ph1 = _phase_ticks(pool) if ph0 is not None else None
-    steps = c1["steps"] - c0["steps"]
-    games = c1["games"] - c0["games"]
-    code, tbl = pool.first_error()
-    if code:
-        raise SystemExit(f"table {tbl} in error {code}")
+    r = _measure(TablePool, N, g0, world, dev, args.version, args.preroll, args.policy, args.steps, args.warmup, bufs, engine, barrier)
+    steps, games, dt, rows_timed = r["steps"], r["games"], r["dt"], r["rows"]
+    enc_ms, enc_launches, sp_ms, sp_launches, C = r["enc_ms"], r["enc_launches"], r["sp_ms"], r["sp_launches"], r["C"]
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -226,12 +264,25 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         steps, games, rows_all = (float(x) for x in s.tolist())
         # the single collective of the data path: gather of episode returns (final scores of finished games)
-        sc, dn = pool.results()
+        sc, dn = r["results"]
         ret = torch.from_numpy(sc).to(dev)
         out = [torch.empty_like(ret) for _ in range(world)] if rank == 0 else None
         dist.gather(ret, out, dst=0)
     else:
         rows_all = rows_timed
+
+    # the other driver-timed workloads (N = 1 only, a few seconds each): where the headline sits between them
+    matrix = None
+    if world == 1 and not args.no_matrix and args.policy == "random" and args.version == 4:
+        k = max(5, args.steps // 3)
+        matrix = {
+            "obs_v3_random": _brief(_measure(TablePool, N, g0, world, dev, 3, args.preroll, "random", 10 * k, 10, bufs)),
+            "obs_v4_random_no_preroll": _brief(_measure(TablePool, N, g0, world, dev, 4, 0, "random", k, 3, bufs)),
+            "obs_v4_greedy": _brief(_measure(TablePool, N, g0, world, dev, 4, args.preroll, "greedy", k, 3, bufs)),
+            "note": "obs_v3_random = env-step + encode only (no SP block); obs_v4_random_no_preroll = every table in the first "
+                    "turns of E1 (17 draws left: the heaviest SP phase); obs_v4_greedy = tenpai-seeking policy on device "
+                    "(mj_greedy_policy; pre-rolled with the same policy): hands at 0..3 shanten, the largest SP state graphs",
+        }
 
     if rank == 0:
         bytes_per_row = C * 34 * 4 + 46 + STATE_READ_BYTES
@@ -263,10 +314,11 @@ def main():
             "decisions_per_sec": rows_all / dt,
             "config": {
                 "workload": f"{N} tables per GPU, "
-                            + ("uniform-random legal policy on device" if engine is None else
-                               "greedy policy of a random-init Brain/DQN-shaped net (192x40, bf16) on the same device")
+                            + {"random": "uniform-random legal policy on device", "greedy": "tenpai-seeking policy on device",
+                               "brain": "greedy policy of a random-init Brain/DQN-shaped net (192x40, bf16) on the same device"}[args.policy]
                             + f", env-step + obs(v{args.version})"
-                            f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals; "
+                            f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals "
+                            f"(wall shuffle of rand {'0.9.1' if default_deal_algo() else '0.8'}); "
                             f"{args.preroll} untimed pre-roll cycles spread the tables over all game phases",
                 "preroll_cycles": args.preroll,
                 "policy": args.policy,
@@ -296,18 +348,46 @@ def main():
             "kernel_ms_per_step": {"mj_k_encode": enc_ms / args.steps, "mj_k_sp": sp_ms / args.steps,
                                    "everything_else": (dt * 1e3 - enc_ms - sp_ms) / args.steps},
         }
-        if ph0 is not None and ph1 is not None:  # where mj_k_sp spends its workgroup time (shares of the summed phase timers) + states per cycle
-            d = {k: ph1[k] - ph0[k] for k in ph1}
-            tot = max(1, sum(d[k] for k in ("setup", "expand", "level0", "eval", "write")))
-            line["sp_phases"] = {"share": {k: round(d[k] / tot, 4) for k in ("setup", "expand", "level0", "eval", "write")},
-                                 "states_per_step": d["states"] / args.steps, "rows_per_step": d["rows"] / args.steps,
-                                 "overflows": d["overflow"]}
+        if "sp_phases" in r:  # where mj_k_sp spends its workgroup time (shares of the summed phase timers) + states per cycle
+            line["sp_phases"] = r["sp_phases"]
+            line["roofline_sp"] = _roofline_sp(r, sp_ms, sp_launches)
+        if matrix:
+            line["workloads"] = matrix
         if not args.no_cpu_baseline and world == 1 and args.policy == "random":  # reported at N=1 only (rank 0)
             line["cpu_baseline"] = cpu_baseline(args.version, args.cpu_budget, args.cpu_tables)
         print(json.dumps(line))
-    pool.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
+
+
+def _roofline_sp(r, sp_ms, sp_launches):
+    """The cycle's dominant kernel is not HBM- or MFMA-bound: it is integer / f32 VALU work (shanten probes, hashing, IEEE
+    divisions in the reference's summation order).  Model: VALU wave-instructions per state graph node (from the separate
+    rocprofv3 --pmc pass, profiles/r02_sp_pmc.json) x nodes visited in the timed region (counted by the kernel) / kernel time
+    (HIP events on the launch stream), against the chip's VALU issue peak; the PMC pass also gives the VALU-busy share, the
+    lane utilisation and the HBM-side traffic of the kernel."""
+    out = {"kernel": "mj_k_sp", "bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_WAVE_INSTS / 1e9,
+           "avg_launch_ms": sp_ms / max(sp_launches, 1), "launches": sp_launches,
+           "states_per_launch": r["sp_phases"]["states_per_step"]}
+    f = os.path.join(ROOT, "profiles", "r02_sp_pmc.json")
+    if os.path.exists(f) and sp_ms > 0:
+        pmc = json.load(open(f))
+        insts = pmc["valu_insts_per_state"] * r["sp_phases"]["states_per_step"] * r["n_cycles"]
+        out["achieved"] = insts / (sp_ms * 1e-3) / 1e9
+        out["frac"] = out["achieved"] / out["peak"]
+        out["valu_insts_per_state"] = pmc["valu_insts_per_state"]
+        for k in ("valu_busy", "lane_utilisation", "wave_wait_share", "hbm_fetch_bytes_per_state", "hbm_write_bytes_per_state",
+                  "l2_hit_rate", "source"):
+            if k in pmc:
+                out[k] = pmc[k]
+        if "hbm_fetch_bytes_per_state" in pmc:
+            by = (pmc["hbm_fetch_bytes_per_state"] + pmc["hbm_write_bytes_per_state"]) * r["sp_phases"]["states_per_step"] * r["n_cycles"]
+            out["hbm_gbs"] = by / (sp_ms * 1e-3) / 1e9
+            out["hbm_frac_of_peak"] = out["hbm_gbs"] / HBM_PEAK_GBS
+    return out
 
 
 if __name__ == "__main__":

@@ -17,6 +17,7 @@
  *   mj_rows_count         agent/mortal.rs:118-123  batch size of the coming react_batch call
  *   mj_encode             agent/mortal.rs:252-287 -> state/obs_repr.rs:126-630  obs + mask for every row of the batch
  *   mj_random_policy      (no reference counterpart: BASELINE config 2's uniform-random legal policy)
+ *   mj_greedy_policy      (no reference counterpart: tenpai-seeking benchmark / test policy)
  *   mj_results            arena/result.rs:19-30 GameResult.scores; arena/one_vs_three.rs:55-60 ranking input
  *   mj_counters           arena/game.rs:298-311 cycles/actions progress counters
  */
@@ -120,6 +121,12 @@ int mj_sp_phase_ticks(MjPool* pool, uint64_t* out8, void* stream);
 
 /* Uniform-random legal action per row, counter-based (seed, game id, seat, kan flag, cycle). */
 int mj_random_policy(MjPool* pool, int agent, const uint8_t* masks_dev, uint64_t seed, uint64_t cycle,
+                     int32_t* actions_dev, void* stream);
+
+/* Tenpai-seeking policy per row (always agari, mostly riichi, shanten-lowering discards read from the encoded obs' discard
+ * block, occasional calls), counter-based like mj_random_policy but keyed by the table index.  No reference counterpart:
+ * the benchmark's realistic-hand workload and the parity tests' policy (tests/parity_util.py greedy_actions). */
+int mj_greedy_policy(MjPool* pool, int agent, const uint8_t* masks_dev, const float* obs_dev, uint64_t seed, uint64_t cycle,
                      int32_t* actions_dev, void* stream);
 
 /* counters: [0] env steps (live tables summed over cycles), [1] games finished, [2] tables in error,

@@ -51,16 +51,20 @@ def _check_engine(engine):
 class BatchRunner:
     """Drives N tables to completion with up to two engines (agent 0 / agent 1)."""
 
+    pool_cls = TablePool  # the test suite substitutes the host emulation of the same kernels (tests/host/emu_pool.py)
+
     def __init__(self, engines, seeds, agent_of_seat, device=None, deal_algo=None, keep_log=False):
         self.engines = engines
         self.cfg = [_check_engine(e) for e in engines]
         dev = device
         if dev is None:
             d0 = getattr(engines[0], "device", None)
-            dev = d0 if isinstance(d0, torch.device) and d0.type == "cuda" else torch.device("cuda:0")
+            dev = d0 if isinstance(d0, torch.device) and d0.type == "cuda" else torch.device(
+                f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0")
         self.device = torch.device(dev)
         n = len(seeds)
-        self.pool = TablePool(n, version=self.cfg[0]["version"], deal_algo=deal_algo, device=str(self.device))
+        self.pool = self.pool_cls(n, version=self.cfg[0]["version"], deal_algo=deal_algo, device=str(self.device))
+        self.device = self.pool.device
         if keep_log:
             self.pool.enable_log()
         self.seeds = list(seeds)
@@ -81,9 +85,14 @@ class BatchRunner:
         guard = self.cfg[agent]["guard"]
         if hasattr(eng, "react_batch_device"):
             out = eng.react_batch_device(obs, masks, invisible) if invisible is not None else eng.react_batch_device(obs, masks)
-            act, q = out if isinstance(out, tuple) else (out, None)
+            out = out if isinstance(out, tuple) else (out,)
+            act, q, is_greedy = out[0], (out[1] if len(out) > 1 else None), (out[2] if len(out) > 2 else None)
             if guard and q is None:
                 raise RuntimeError("enable_rule_based_agari_guard: react_batch_device must return (actions, q_values)")
+            if self.keep_log and q is not None:  # per-decision metadata of the game logs (agent/mortal.rs:161-186)
+                g = is_greedy if is_greedy is not None else torch.ones(obs.shape[0], dtype=torch.bool)
+                self._last_meta = (q.float().cpu().numpy().reshape(-1, ACTION_SPACE), masks.cpu().numpy().astype(bool),
+                                   g.cpu().numpy().astype(bool).reshape(-1))
             q = q.to(device=self.device, dtype=torch.float32).contiguous() if guard else None
             return act.to(device=self.device, dtype=torch.int32).contiguous(), q
         try:
@@ -99,17 +108,55 @@ class BatchRunner:
         q = torch.as_tensor(q_values, dtype=torch.float32, device=self.device).contiguous() if guard else None
         return torch.as_tensor(actions, dtype=torch.int32, device=self.device), q
 
-    def run(self, max_cycles=1 << 30):
+    def _fail(self, code, tbl):
+        """Illegal action / rule violation on table `tbl`: the reference aborts the whole run with the offending event and
+        the seat's `brief_info()` (arena/board.rs:524-533); here the table's state at the time of the check is dumped."""
+        lines = [f"table {tbl} (seed {self.seeds[tbl] if 0 <= tbl < len(self.seeds) else '?'}): illegal action or rule violation "
+                 f"(error code {code}, include/mortal_amd.h MJ_ERR_*)"]
+        try:
+            d = self.pool.debug_table(tbl)
+            names = "1m 2m 3m 4m 5m 6m 7m 8m 9m 1p 2p 3p 4p 5p 6p 7p 8p 9p 1s 2s 3s 4s 5s 6s 7s 8s 9s E S W N P F C".split()
+            lines.append(f"  kyoku {int(d['kyoku'][0])} honba {int(d['honba'][0])} kyotaku {int(d['kyotaku'][0])} scores "
+                         f"{d['scores'].tolist()} tiles_left {int(d['tiles_left'][0])} pending seats {int(d['pending'][0]):04b}")
+            for seat in range(4):
+                mp, sz = int(d["hand_mp"][seat]), int(d["hand_sz"][seat])
+                cnt = [(mp >> (3 * t)) & 7 for t in range(18)] + [(sz >> (3 * t)) & 7 for t in range(16)]
+                hand = " ".join(names[t] for t in range(34) for _ in range(cnt[t]))
+                lines.append(f"  seat {seat}: shanten {int(d['shanten'][seat])} cans 0x{int(d['cans'][seat]):x} "
+                             f"last_self_tsumo {int(d['last_self_tsumo'][seat])} hand [{hand}]")
+        except Exception as ex:  # noqa: BLE001 - the diagnostic must not hide the error itself
+            lines.append(f"  (state dump unavailable: {ex})")
+        return MortalAmdError("\n".join(lines))
+
+    def run(self, max_cycles=1 << 30, progress=None):
+        """progress: None = silent (disable_progress_bar), else a label: the reference's bar message
+        (`cycles: N (x cycle/s), actions: M (y action/s)`, arena/game.rs:303-311) goes to stderr about once a second."""
+        import sys
+
         pool = self.pool
         acts = [None, None]
         qs = [None, None]
         n_games = pool.n_tables
+        t_start = t_last = time.perf_counter()
+
+        def report(final=False):
+            c = pool.counters()
+            secs = max(time.perf_counter() - t_start, 1e-9)
+            print(f"\r{progress + ' ' if progress else ''}{c['games']}/{n_games} games  cycles: {self.cycles} "
+                  f"({self.cycles / secs:.3f} cycle/s), actions: {c['steps']} ({c['steps'] / secs:.3f} action/s)",
+                  end="\n" if final else "", file=sys.stderr, flush=True)
+
         while True:
+            if self.cycles >= max_cycles:
+                raise MortalAmdError("max_cycles exceeded")
             n = pool.step(acts[0], acts[1], qs[0], qs[1])
             self.cycles += 1
             code, tbl = pool.first_error() if (self.cycles & 63) == 0 else (0, -1)
             if code:
-                raise MortalAmdError(f"table {tbl}: illegal action or rule violation (error code {code})")
+                raise self._fail(code, tbl)
+            if progress is not None and time.perf_counter() - t_last > 1.0:
+                t_last = time.perf_counter()
+                report()
             acts = [None, None]
             qs = [None, None]
             if n[0] == 0 and n[1] == 0:
@@ -125,14 +172,18 @@ class BatchRunner:
                 self._last_meta = None
                 t0 = time.perf_counter_ns()
                 acts[a], qs[a] = self._policy(a, obs, masks, inv)
+                if acts[a].numel() != n[a] or (qs[a] is not None and tuple(qs[a].shape) != (n[a], ACTION_SPACE)):
+                    raise RuntimeError(f"engine returned {acts[a].numel()} actions"
+                                       + (f" / q-values of shape {tuple(qs[a].shape)}" if qs[a] is not None else "")
+                                       + f" for a batch of {n[a]} rows")
                 if self.keep_log and self._last_meta is not None:
                     # these rows are committed by the NEXT mj_step call, whose index the device writes into the log tags
                     self.meta_batches.setdefault(self.cycles, {})[a] = self._last_meta + (time.perf_counter_ns() - t0,)
-            if self.cycles >= max_cycles:
-                raise MortalAmdError("max_cycles exceeded")
+        if progress is not None:
+            report(final=True)
         code, tbl = pool.first_error()
         if code:
-            raise MortalAmdError(f"table {tbl}: illegal action or rule violation (error code {code})")
+            raise self._fail(code, tbl)
         if pool.counters()["sp_overflow"]:
             raise MortalAmdError("obs v4: a decision's single-player state graph exceeded the device scratch capacity "
                                  "(SP_CAP in mortal_amd/csrc/mj_sp.hip); its SP planes would be incomplete")
@@ -207,20 +258,35 @@ class OneVsThree:
 
     def py_vs_py(self, challenger, champion, seed_start, seed_count):
         """Returns the rank histogram [1st, 2nd, 3rd, 4th] of the challenger over seed_count*4 hanchan."""
+        from . import sharding
+
         n = int(seed_count) * 4
-        seeds = [(int(seed_start[0]) + g // 4, int(seed_start[1])) for g in range(n)]  # one_vs_three.rs:140-142
+        # One process per GPU (torch.distributed initialised, e.g. under torchrun): rank r plays the contiguous game range
+        # [g0, g1) — multiples of 4, so the four seat rotations of a seed stay together — with its own pool and its own
+        # copy of the engines; the only collective is the all-reduce of the 4-entry rank histogram (SURVEY.md §8(e)),
+        # so every rank returns the reference's whole-run result (one_vs_three.rs:55-60 sums it in-process).
+        rank, world, backend = sharding.dist_info()
+        g0, g1 = sharding.shard_range(n, rank, world) if world > 1 else (0, n)
+        seeds = [(int(seed_start[0]) + g // 4, int(seed_start[1])) for g in range(g0, g1)]  # one_vs_three.rs:140-142
         # challenger (agent 0) sits at seat g % 4, the champion (agent 1) on the other three (one_vs_three.rs:144-191)
-        aos = np.array([0xF & ~(1 << (g % 4)) for g in range(n)], dtype=np.uint8)
-        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None, deal_algo=self.deal_algo)
-        try:
-            scores = runner.run()
-            if self.log_dir is not None:
-                runner.dump_logs(self.log_dir, 4)
-        finally:
-            runner.close()
+        aos = np.array([0xF & ~(1 << (g % 4)) for g in range(g0, g1)], dtype=np.uint8)
         rankings = [0, 0, 0, 0]
-        for g in range(n):
-            rankings[_rank_by_player(scores[g])[g % 4]] += 1  # one_vs_three.rs:55-60
+        dev = None
+        if g1 > g0:
+            runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None, deal_algo=self.deal_algo)
+            dev = runner.device
+            try:
+                scores = runner.run(progress=None if self.disable_progress_bar else f"rank {rank}" if world > 1 else "")
+                if self.log_dir is not None:
+                    runner.dump_logs(self.log_dir, 4)
+            finally:
+                runner.close()
+            for i, g in enumerate(range(g0, g1)):
+                rankings[_rank_by_player(scores[i])[g % 4]] += 1  # one_vs_three.rs:55-60
+        if world > 1:
+            red_dev = dev if (backend == "nccl" and dev is not None) else torch.device(
+                f"cuda:{torch.cuda.current_device()}") if backend == "nccl" else torch.device("cpu")
+            rankings = sharding.allreduce_rank_histogram(rankings, device=red_dev)
         return rankings
 
     def ako_vs_py(self, engine, seed_start, seed_count):
@@ -239,17 +305,22 @@ class TwoVsTwo:
         self.deal_algo = deal_algo  # None = pool.default_deal_algo() (rand 0.9.1 unless MORTAL_AMD_DEAL_ALGO says otherwise)
 
     def py_vs_py(self, challenger, champion, seed_start, seed_count):
+        from . import sharding
+
         n = int(seed_count) * 2
-        seeds = [(int(seed_start[0]) + g // 2, int(seed_start[1])) for g in range(n)]  # two_vs_two.rs:138-140
+        rank, world, _backend = sharding.dist_info()  # one process per GPU: contiguous seed ranges, nothing to reduce
+        g0, g1 = sharding.shard_range(n, rank, world, group=2) if world > 1 else (0, n)
+        seeds = [(int(seed_start[0]) + g // 2, int(seed_start[1])) for g in range(g0, g1)]  # two_vs_two.rs:138-140
         # split A: challenger at seats 0,2; split B: 1,3 (two_vs_two.rs:142-172)
-        aos = np.array([0b1010 if g % 2 == 0 else 0b0101 for g in range(n)], dtype=np.uint8)
-        runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None, deal_algo=self.deal_algo)
-        try:
-            runner.run()
-            if self.log_dir is not None:
-                runner.dump_logs(self.log_dir, 2)
-        finally:
-            runner.close()
+        aos = np.array([0b1010 if g % 2 == 0 else 0b0101 for g in range(g0, g1)], dtype=np.uint8)
+        if g1 > g0:
+            runner = BatchRunner([challenger, champion], seeds, aos, keep_log=self.log_dir is not None, deal_algo=self.deal_algo)
+            try:
+                self.last_scores = runner.run(progress=None if self.disable_progress_bar else "")
+                if self.log_dir is not None:
+                    runner.dump_logs(self.log_dir, 2)
+            finally:
+                runner.close()
         return None
 
     def ako_vs_py(self, *a, **k):

@@ -654,6 +654,20 @@ int mj_random_policy(MjPool* P, int agent, const uint8_t* masks, uint64_t seed, 
     return 0;
 }
 
+int mj_greedy_policy(MjPool* P, int agent, const uint8_t* masks, const float* obs, uint64_t seed, uint64_t cycle,
+                     int32_t* actions, void* stream) {
+    if (!P) return fail("null pool");
+    if (!P->rows_valid) return fail("mj_rows_count must be called first");
+    int n = P->last_rows[agent & 1];
+    if (n == 0) return 0;
+    const int v = P->version[agent & 1];
+    const int d0 = v == 1 ? 923 : v == 2 ? 927 : v == 3 ? 919 : 874;  // first row of the discard block (obs_repr.rs:431-476)
+    hipLaunchKernelGGL(mj_k_greedy_policy, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, P->rows[agent & 1], masks,
+                       obs, mj_obs_rows(v), d0, n, seed, cycle, actions);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
     if (!P) return fail("null pool");
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));

@@ -5,6 +5,7 @@
 //               new decisions (quick-eval / kan-select, agent/mortal.rs:200-250) and count policy rows.
 //   mj_k_rows   exclusive scan of the per-table row counts -> contiguous row ids per agent + row descriptors.
 //   mj_k_random_policy   uniform-random legal action per row (BASELINE config 2), counter-based.
+//   mj_k_greedy_policy   tenpai-seeking test / benchmark policy per row (always agari, mostly riichi, shanten-lowering discards).
 #include <hip/hip_runtime.h>
 
 #include "mj_rules.h"
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
             const int agent = (F(agent_of_seat) >> s) & 1;
             const int mr = F1(main_row, s), kr = F1(kan_row, s);
             int action = P.actions[agent] ? P.actions[agent][mr] : 45;
-            const int kan_tile = kr >= 0 ? P.actions[agent][kr] : -1;
+            const int kan_tile = (kr >= 0 && P.actions[agent]) ? P.actions[agent][kr] : -1;
             if (P.enable_agari_guard[agent] && action == 43 && !rule_based_agari(L, s)) {
                 // mortal.rs:319-336: take the best alternative; q[43] := f32::MIN, then Iterator::max_by(total_cmp),
                 // which keeps the LAST of equal maxima
@@ -826,6 +827,63 @@ __global__ void mj_k_random_policy(const TableBlock* blocks, const uint32_t* row
         int k = (int)((x >> 33) % (uint64_t)cnt);
         for (int i = 0; i < k; i++) bits &= bits - 1;
         a = __ffsll((long long)bits) - 1;
+    }
+    actions[r] = a;
+}
+
+// ---------------------------------------------------------------- tenpai-seeking policy (benchmark workload / tests)
+// The policy of tests/parity_util.py greedy_actions, on device: always agari, usually riichi, discards that lower (else
+// keep) the shanten number — read from the encoded obs' discard block (obs_repr.rs:431-476: rows d0+1 keep-shanten, d0+2
+// next-shanten) — and occasional calls; choices come from a counter-based hash of (table, seat, kan flag, cycle).  It keeps
+// hands at 0..3 shanten, the regime in which the obs v4 SP tables (mj_sp.hip) carry real state graphs.
+__global__ void mj_k_greedy_policy(const uint32_t* rows, const uint8_t* masks, const float* obs, int C, int d0, int n_rows,
+                                   uint64_t seed, uint64_t cycle, int* actions) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t d = rows[r];
+    uint64_t x = seed ^ ((uint64_t)ROW_TABLE(d) * 0xD1B54A32D192ED03ull) ^ ((uint64_t)ROW_SEAT(d) * 0x8CB92BA72F3D8DD7ull) ^
+                 ((uint64_t)ROW_KAN(d) * 0xAEF17502108EF2D9ull) ^ (cycle * 0x94D049BB133111EBull);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    const uint64_t hv = x >> 20;
+    const uint8_t* mk = masks + (size_t)r * 46;
+    uint64_t m = 0;
+    for (int i = 0; i < 46; i++) m |= (uint64_t)(mk[i] != 0) << i;
+    auto pick = [](uint64_t cands, uint64_t h) {  // the (h mod popcount)-th set bit
+        int k = (int)(h % (uint64_t)__popcll(cands));
+        for (int i = 0; i < k; i++) cands &= cands - 1;
+        return __ffsll((long long)cands) - 1;
+    };
+    const uint64_t tiles = m & ((1ull << 37) - 1);
+    int a = 45;
+    if (ROW_KAN(d)) {
+        a = pick(m, hv);
+    } else if ((m >> 43) & 1) {
+        a = 43;
+    } else if (((m >> 37) & 1) && hv % 8 != 0) {
+        a = 37;
+    } else if (((m >> 44) & 1) && hv % 2 == 0) {
+        a = 44;
+    } else if (((m >> 42) & 1) && tiles && hv % 3 == 0) {
+        a = 42;
+    } else if (tiles) {
+        const float* keep_row = obs + ((size_t)r * C + d0 + 1) * 34;
+        const float* next_row = keep_row + 34;
+        uint64_t nxt = 0, keep = 0;
+        for (int t = 0; t < 37; t++) {
+            if (!((tiles >> t) & 1)) continue;
+            const int k = deaka(t);
+            if (next_row[k] > 0.f) nxt |= 1ull << t;
+            if (keep_row[k] > 0.f) keep |= 1ull << t;
+        }
+        a = pick(nxt ? nxt : keep ? keep : tiles, hv / 7);
+    } else {  // reaction to a discard
+        const uint64_t chi = (m >> 38) & 7;
+        if (((m >> 41) & 1) && hv % 3 == 0) a = 41;
+        else if (chi && hv % 4 == 0) a = 38 + pick(chi, hv / 5);
+        else if (((m >> 42) & 1) && hv % 2 == 0) a = 42;
+        else a = 45;
     }
     actions[r] = a;
 }

@@ -68,14 +68,45 @@ class PolicyNet(nn.Module):
         return (v + a - a_mean).masked_fill(~mask, -torch.inf)  # model.py:225-231
 
 
+def nucleus_sample(logits, top_p, generator=None):
+    """One action per row from softmax(logits) restricted to its top-p nucleus (mortal/engine.py:83-94 `sample_top_p`):
+    p >= 1 samples the whole distribution, p <= 0 is the argmax; otherwise the smallest set of most probable actions whose
+    mass *before* the last member does not exceed p keeps its (unnormalised) probabilities, the rest get zero.
+    -inf logits (illegal actions) have probability exactly 0 and are never drawn.  Stays on `logits.device`."""
+    if top_p <= 0:
+        return logits.argmax(-1)
+    probs = logits.softmax(-1)
+    if top_p < 1:
+        order = probs.argsort(dim=-1, descending=True, stable=True)
+        ranked = probs.gather(-1, order)
+        mass_before = ranked.cumsum(-1) - ranked
+        ranked = torch.where(mass_before > top_p, torch.zeros_like(ranked), ranked)
+        pick = torch.multinomial(ranked, 1, generator=generator)
+        return order.gather(-1, pick).squeeze(-1)
+    return torch.multinomial(probs, 1, generator=generator).squeeze(-1)
+
+
+def boltzmann_actions(q, masks, epsilon, temp, top_p, generator=None):
+    """mortal/engine.py:72-81: with probability 1 - epsilon the greedy action, else a top-p sample of softmax(q / temp) over
+    the legal actions.  Returns (actions int64 [B], is_greedy bool [B]) on q's device."""
+    greedy = q.argmax(-1)
+    if epsilon <= 0:
+        return greedy, torch.ones(q.shape[0], dtype=torch.bool, device=q.device)
+    is_greedy = torch.rand(q.shape[0], device=q.device, generator=generator) < (1 - epsilon)
+    logits = (q.float() / temp).masked_fill(~masks, -torch.inf)
+    return torch.where(is_greedy, greedy, nucleus_sample(logits, top_p, generator)), is_greedy
+
+
 class DeviceEngine:
     """Engine with the reference's duck-typed contract (agent/mortal.rs:53-74, mortal/engine.py:8-81) plus the
-    device fast path `react_batch_device` that keeps actions on the GPU (no `.tolist()` round trip)."""
+    device fast path `react_batch_device` that keeps actions on the GPU (no `.tolist()` round trip): greedy, or the
+    reference's Boltzmann-epsilon / top-p exploration (engine.py:72-94) sampled on the device."""
 
     engine_type = "mortal"
 
     def __init__(self, net, version, device, name="mortal_amd", enable_amp=True, enable_quick_eval=True,
-                 max_batch=16384):
+                 max_batch=16384, boltzmann_epsilon=0, boltzmann_temp=1, top_p=1, enable_rule_based_agari_guard=False,
+                 return_meta=False, seed=None):
         self.net = net.to(device).eval()
         self.version = version
         self.device = torch.device(device)
@@ -83,17 +114,35 @@ class DeviceEngine:
         self.is_oracle = False
         self.enable_amp = enable_amp
         self.enable_quick_eval = enable_quick_eval
-        self.enable_rule_based_agari_guard = False
+        self.enable_rule_based_agari_guard = enable_rule_based_agari_guard
         self.max_batch = max_batch
+        self.boltzmann_epsilon = boltzmann_epsilon
+        self.boltzmann_temp = boltzmann_temp
+        self.top_p = top_p
+        self.return_meta = return_meta  # also return (q_values, is_greedy): the arena's log metadata / agari guard need them
+        self.generator = None
+        if seed is not None:
+            self.generator = torch.Generator(device=self.device)
+            self.generator.manual_seed(seed)
 
     @torch.inference_mode()
     def react_batch_device(self, obs, masks):
-        out = torch.empty(obs.shape[0], dtype=torch.int32, device=obs.device)
-        for i in range(0, obs.shape[0], self.max_batch):  # bounded activation memory at 65k-row batches
-            with torch.autocast("cuda", enabled=self.enable_amp):
+        """-> actions int32 [B] on the device; with return_meta / the agari guard: (actions, q_values f32 [B, 46], is_greedy)."""
+        n = obs.shape[0]
+        out = torch.empty(n, dtype=torch.int32, device=obs.device)
+        want_meta = self.return_meta or self.enable_rule_based_agari_guard
+        q_all = torch.empty((n, ACTION_SPACE), dtype=torch.float32, device=obs.device) if want_meta else None
+        greedy_all = torch.empty(n, dtype=torch.bool, device=obs.device) if want_meta else None
+        for i in range(0, n, self.max_batch):  # bounded activation memory at 65k-row batches
+            with torch.autocast(obs.device.type, enabled=self.enable_amp):
                 q = self.net(obs[i:i + self.max_batch], masks[i:i + self.max_batch])
-            out[i:i + self.max_batch] = q.argmax(-1).to(torch.int32)
-        return out
+            act, is_greedy = boltzmann_actions(q, masks[i:i + self.max_batch], self.boltzmann_epsilon, self.boltzmann_temp,
+                                               self.top_p, self.generator)
+            out[i:i + self.max_batch] = act.to(torch.int32)
+            if want_meta:
+                q_all[i:i + self.max_batch] = q.float()
+                greedy_all[i:i + self.max_batch] = is_greedy
+        return (out, q_all, greedy_all) if want_meta else out
 
     def react_batch(self, obs, masks, invisible_obs):
         import numpy as np

@@ -160,6 +160,14 @@ class TablePool:
         for q in (q0, q1):
             if q is not None:
                 assert q.device.type == self.device.type and q.dtype == torch.float32 and q.is_contiguous() and q.shape[-1] == 46
+        # one action per row of the batch the previous step produced: the step kernel indexes these tensors by row id
+        for ag, (a, q) in enumerate(((actions0, q0), (actions1, q1))):
+            if a is not None and a.numel() != self.n_rows[ag]:
+                raise MortalAmdError(f"agent {ag}: {a.numel()} actions for a batch of {self.n_rows[ag]} rows")
+            if q is not None and q.numel() != self.n_rows[ag] * ACTION_SPACE:
+                raise MortalAmdError(f"agent {ag}: q-values of shape {tuple(q.shape)} for a batch of {self.n_rows[ag]} rows")
+            if a is None and self.n_rows[ag]:
+                raise MortalAmdError(f"agent {ag}: the previous batch had {self.n_rows[ag]} rows but no actions were passed")
         p0 = actions0.data_ptr() if actions0 is not None and actions0.numel() else None
         p1 = actions1.data_ptr() if actions1 is not None and actions1.numel() else None
         pq0 = q0.data_ptr() if q0 is not None and q0.numel() else None
@@ -213,6 +221,16 @@ class TablePool:
             out = torch.empty(n, dtype=torch.int32, device=self.device)
         if n:
             check(self._L.mj_random_policy(self.h, agent, masks.data_ptr(), seed, cycle, out.data_ptr(), self._stream()))
+        return out[:n]
+
+    def greedy_policy(self, agent, masks, obs, seed, cycle, out=None):
+        """Tenpai-seeking policy on device (mj_greedy_policy); obs = the encoded batch of this agent's rows."""
+        n = self.n_rows[agent]
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            check(self._L.mj_greedy_policy(self.h, agent, masks.data_ptr(), obs.data_ptr(), seed, cycle, out.data_ptr(),
+                                           self._stream()))
         return out[:n]
 
     def counters(self):

@@ -10,14 +10,22 @@ import torch
 import torch.distributed as dist
 
 
-def shard_range(n_games, rank, world):
-    """[g0, g1) of `n_games` (a multiple of 4) owned by `rank`."""
-    assert n_games % 4 == 0
-    sets = n_games // 4
+def shard_range(n_games, rank, world, group=4):
+    """[g0, g1) of `n_games` (a multiple of `group`) owned by `rank`; `group` = games per seed (4 seat rotations in
+    OneVsThree, 2 splits in TwoVsTwo), kept together on one rank."""
+    assert n_games % group == 0
+    sets = n_games // group
     base, rem = divmod(sets, world)
     s0 = rank * base + min(rank, rem)
     s1 = s0 + base + (1 if rank < rem else 0)
-    return 4 * s0, 4 * s1
+    return group * s0, group * s1
+
+
+def dist_info():
+    """(rank, world, backend) of the default process group, (0, 1, None) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), dist.get_backend()
+    return 0, 1, None
 
 
 def seeds_for(seed_start, g0, g1):

@@ -211,6 +211,9 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         if policy == "greedy":
             d0 = DISCARD_ROW[version]
             act = greedy_actions(masks_o, rows_o, cycle, obs_g[:, d0:d0 + 3].cpu().numpy(), policy_seed)
+            if n:  # the device-side port of the same policy (mj_k_greedy_policy, the benchmark's realistic-hand workload)
+                act_dev = pool.greedy_policy(0, masks_g, obs_g, policy_seed, cycle).cpu().numpy()
+                assert (act_dev == act).all(), f"cycle {cycle}: device greedy policy differs at rows {np.flatnonzero(act_dev != act)[:8].tolist()}"
         elif policy == "tsumogiri":
             act = tsumogiri_actions(arena, masks_o, rows_o)
         else:

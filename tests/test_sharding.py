@@ -77,3 +77,71 @@ def test_two_rank_gather_matches_single_process(oracle):
         order = sorted(range(4), key=lambda s: -int(ref[g][s]))
         hist[order.index(g % 4)] += 1
     assert total == hist and sum(total) == n_games
+
+
+# ---- the PRODUCT entry point under torch.distributed: libriichi.arena.OneVsThree.py_vs_py shards the games over the ranks
+# and all-reduces the rank histogram (mortal_amd/arena.py); the device kernels run on the host emulator (tests/host/emu).
+class _LowestLegalEngine:
+    """The reference's engine contract (agent/mortal.rs:50-159) with a fixed policy: the lowest legal action id."""
+    engine_type = "mortal"
+    is_oracle = False
+    version = 3
+    enable_quick_eval = True
+    enable_rule_based_agari_guard = False
+
+    def __init__(self, name):
+        self.name = name
+
+    def react_batch(self, obs, masks, invisible_obs):
+        import torch
+
+        m = torch.as_tensor(np.stack(masks, axis=0))
+        a = m.to(torch.uint8).argmax(dim=1)
+        return a.tolist(), torch.zeros(m.shape, dtype=torch.float32).tolist(), m.tolist(), [True] * m.shape[0]
+
+
+def _py_vs_py_worker(rank, world, port, seed_count, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "host")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import emu_pool
+    from libriichi.arena import OneVsThree
+
+    from mortal_amd import arena as A
+
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    A.BatchRunner.pool_cls = emu_pool.make_pool_class()
+    got = OneVsThree(disable_progress_bar=True, deal_algo=0).py_vs_py(_LowestLegalEngine("a"), _LowestLegalEngine("b"),
+                                                                      (10000, KEY), seed_count)
+    q.put((rank, got))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_sharded_py_vs_py_product_entry_point(oracle):
+    """2 gloo ranks x OneVsThree.py_vs_py (8 hanchan): every rank returns the whole-run histogram, equal to the oracle's."""
+    seed_count, world, port = 2, 2, 29531
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_py_vs_py_worker, args=(r, world, port, seed_count, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 4 * seed_count
+    ref = _play([(10000 + g // 4, KEY) for g in range(n)])  # same policy on the oracle (deal_algo 0)
+    hist = [0, 0, 0, 0]
+    for g in range(n):
+        order = sorted(range(4), key=lambda s: -int(ref[g][s]))
+        hist[order.index(g % 4)] += 1
+    assert got[0] == hist and got[1] == hist and sum(hist) == n
