@@ -73,6 +73,13 @@ int mj_step(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_de
 int mj_step_q(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_dev1, const float* q_dev0,
               const float* q_dev1, void* stream);
 
+/* The same with EXPLICIT reactions for an agent: ev_devN = one packed mjai event word per row of agent N's batch (the
+ * header word of the LG_* log format, 0 = {"type":"none"}), applied verbatim instead of an action id — the reference's
+ * MjaiLogBatchAgent (agent/mjai_log.rs:12-150, py_agent.rs:24-37) answers with events.  The host validates them first
+ * (state/action.rs:91-228). */
+int mj_step_ev(MjPool* pool, const int32_t* actions_dev0, const int32_t* actions_dev1, const float* q_dev0,
+               const float* q_dev1, const uint64_t* ev_dev0, const uint64_t* ev_dev1, void* stream);
+
 /* ---- Log replay for the dataset loader (dataset/gameplay.rs:239-443 Gameplay::load_events_by_player).
  * One game log per table, as packed event words (LG_* format, the same words mj_log_read returns; host encoder:
  * mortal_amd/mjai_log.py encode_events).  script = all logs concatenated, off[n_logs + 1] = word offsets, tracked[t] bit s =

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .pool import ACTION_SPACE, OBS_ROWS, TablePool
-from ._lib import MortalAmdError
+from ._lib import MortalAmdError, check
 
 
 class _StackedBatch:
@@ -38,14 +38,43 @@ class _StackedBatch:
 
 
 def _check_engine(engine):
+    """agent/py_agent.rs:24-37: dispatch on `engine_type`."""
     et = getattr(engine, "engine_type")
+    if et == "mjai-log":  # agent/mjai_log.rs:34-63
+        for method in ("react_batch", "start_game", "end_kyoku", "end_game"):
+            if not callable(getattr(engine, method, None)):
+                raise TypeError(f"missing method {method}")
+        # every decision gets a row (no quick-eval), nothing is encoded for it, reactions are explicit mjai events
+        return dict(name=str(engine.name), version=0, quick=False, guard=False, oracle=False, mjai_log=True)
     if et != "mortal":
-        raise NotImplementedError(f"engine_type {et!r}: only 'mortal' engines are supported on the device path "
-                                  "(mjai-log / akochan agents are out of scope, SURVEY.md §2 rows 2)")
+        raise ValueError(f"unknown engine type {et}")
     if not callable(getattr(engine, "react_batch", None)):
         raise TypeError("missing method react_batch")
     return dict(name=str(engine.name), version=int(engine.version), quick=bool(engine.enable_quick_eval),
-                guard=bool(getattr(engine, "enable_rule_based_agari_guard")), oracle=bool(getattr(engine, "is_oracle")))
+                guard=bool(getattr(engine, "enable_rule_based_agari_guard")), oracle=bool(getattr(engine, "is_oracle")),
+                mjai_log=False)
+
+
+class GameState:
+    """What an mjai-log engine's `react_batch` receives per decision (agent/mjai_log.rs:22-32)."""
+
+    def __init__(self, game_index, state, events_json):
+        self.game_index = game_index    # index of this player in the list given to `set_player_ids`
+        self.state = state              # libriichi.state.PlayerState (a copy of the seat's state)
+        self.events_json = events_json  # the current kyoku's log so far, a JSON array of mjai events
+
+
+def pack_reaction(ev):
+    """mjai reaction dict -> the header word of the device's event format (mj_state.h LG_*), 0 for {"type":"none"}."""
+    from . import mjai_log as ML
+
+    t = ev["type"]
+    if t == "none":
+        return 0
+    if t in ("hora", "ryukyoku"):  # header only: deltas / ura markers are the board's business
+        code = ML.LG_HORA if t == "hora" else ML.LG_RYUKYOKU
+        return code | (int(ev.get("actor", 0)) << 4) | (int(ev.get("target", 0)) << 6)
+    return int(ML.encode_events([ev])[0])
 
 
 class BatchRunner:
@@ -63,9 +92,13 @@ class BatchRunner:
                 f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0")
         self.device = torch.device(dev)
         n = len(seeds)
+        versions = [c["version"] for c in self.cfg if c["version"]] or [3]
+        for c in self.cfg:
+            c["version"] = c["version"] or versions[0]  # an mjai-log agent's rows are never encoded
         self.pool = self.pool_cls(n, version=self.cfg[0]["version"], deal_algo=deal_algo, device=str(self.device))
         self.device = self.pool.device
-        if keep_log:
+        self.any_mjai_log = any(c["mjai_log"] for c in self.cfg)
+        if keep_log or self.any_mjai_log:  # mjai-log engines read the kyoku's events from the device log
             self.pool.enable_log()
         self.seeds = list(seeds)
         self.agent_of_seat = np.asarray(agent_of_seat, dtype=np.uint8)
@@ -75,6 +108,22 @@ class BatchRunner:
         if len(engines) == 1:
             self.pool.configure(1, enable_quick_eval=self.cfg[0]["quick"], version=self.cfg[0]["version"],
                                 enable_rule_based_agari_guard=self.cfg[0]["guard"])
+        # player planning of the reference (one_vs_three.rs:140-191, two_vs_two.rs:138-190): per agent the seats it plays,
+        # games in order, seats ascending; an mjai-log engine addresses its players by their index in that list
+        self.player_index = [{}, {}]
+        player_ids = [[], []]
+        for g in range(n):
+            for seat in range(4):
+                a = (int(self.agent_of_seat[g]) >> seat) & 1 if len(engines) > 1 else 0
+                self.player_index[a][(g, seat)] = len(player_ids[a])
+                player_ids[a].append(seat)
+        self._kyoku_ends = {}  # game -> end_kyoku events already reported to the mjai-log engines
+        for a, eng in enumerate(engines):
+            if self.cfg[a]["mjai_log"]:
+                if callable(getattr(eng, "set_player_ids", None)):
+                    eng.set_player_ids(player_ids[a])
+                for idx in range(len(player_ids[a])):
+                    eng.start_game(idx)
         self.cycles = 0
         self.keep_log = keep_log
         self.meta_batches = {}  # step index -> per agent (q_values, masks, is_greedy, eval_time_ns) of the rows it commits
@@ -128,6 +177,67 @@ class BatchRunner:
             lines.append(f"  (state dump unavailable: {ex})")
         return MortalAmdError("\n".join(lines))
 
+    def _game_log(self, g):
+        from . import mjai_log
+
+        lens = np.zeros(self.pool.n_tables, dtype=np.uint32)
+        buf = np.empty((1, self.pool.log_cap), dtype=np.uint64)
+        check(self.pool._L.mj_log_lengths(self.pool.h, lens.ctypes.data, self.pool._stream()))
+        check(self.pool._L.mj_log_read(self.pool.h, int(g), 1, buf.ctypes.data, self.pool._stream()))
+        if lens[g] > self.pool.log_cap:
+            raise MortalAmdError(f"event log overflow on table {g}")
+        return mjai_log.decode_events(buf[0, :lens[g]])
+
+    def _report_kyoku_ends(self, g, events):
+        """end_kyoku(player index) for every kyoku of game g that has ended since the last look (game.rs:113-118)."""
+        n_end = sum(1 for e in events if e["type"] == "end_kyoku")
+        for _ in range(n_end - self._kyoku_ends.get(g, 0)):
+            for a, eng in enumerate(self.engines):
+                if self.cfg[a]["mjai_log"]:
+                    for seat in range(4):
+                        idx = self.player_index[a].get((g, seat))
+                        if idx is not None:
+                            eng.end_kyoku(idx)
+        self._kyoku_ends[g] = n_end
+
+    def _mjai_log_policy(self, agent):
+        """agent/mjai_log.rs:65-150: GameState per acting seat -> engine.react_batch -> validated, packed reactions."""
+        import json
+
+        from .state import PlayerState
+
+        eng = self.engines[agent]
+        rows = self.pool.rows(agent)
+        words = np.zeros(len(rows), dtype=np.int64)
+        states, where = [], []
+        logs = {}
+        for r, (g, seat, is_kan) in enumerate(rows):
+            if is_kan:
+                continue  # kan-select rows belong to the mortal agent's protocol; the event names the tile itself
+            g, seat = int(g), int(seat)
+            if g not in logs:
+                logs[g] = self._game_log(g)
+                self._report_kyoku_ends(g, logs[g])
+            evs = logs[g]
+            start = max(i for i, e in enumerate(evs) if e["type"] == "start_kyoku")
+            st = PlayerState.view(self.pool, g, seat)
+            states.append(GameState(self.player_index[agent][(g, seat)], st, json.dumps(evs[start:], separators=(",", ":"))))
+            where.append((r, st))
+        try:
+            raw = eng.react_batch(states) if states else []
+        except Exception as ex:
+            raise RuntimeError(f"failed to execute `react_batch` on Python engine: {ex}") from ex
+        if len(raw) != len(states):
+            raise RuntimeError("react_batch returned a batch of the wrong size")
+        for (r, st), text in zip(where, raw):
+            ev = json.loads(text)
+            try:  # BoardState::step validates every reaction (board.rs:524-533)
+                st.validate_reaction(ev)
+            except ValueError as ex:
+                raise MortalAmdError(f"invalid action: {ev}: {ex}\nstate:\n{st.brief_info()}") from ex
+            words[r] = pack_reaction(ev)
+        return torch.from_numpy(words).to(self.device)
+
     def run(self, max_cycles=1 << 30, progress=None):
         """progress: None = silent (disable_progress_bar), else a label: the reference's bar message
         (`cycles: N (x cycle/s), actions: M (y action/s)`, arena/game.rs:303-311) goes to stderr about once a second."""
@@ -136,6 +246,7 @@ class BatchRunner:
         pool = self.pool
         acts = [None, None]
         qs = [None, None]
+        evs = [None, None]
         n_games = pool.n_tables
         t_start = t_last = time.perf_counter()
 
@@ -149,7 +260,7 @@ class BatchRunner:
         while True:
             if self.cycles >= max_cycles:
                 raise MortalAmdError("max_cycles exceeded")
-            n = pool.step(acts[0], acts[1], qs[0], qs[1])
+            n = pool.step(acts[0], acts[1], qs[0], qs[1], evs[0], evs[1])
             self.cycles += 1
             code, tbl = pool.first_error() if (self.cycles & 63) == 0 else (0, -1)
             if code:
@@ -159,6 +270,7 @@ class BatchRunner:
                 report()
             acts = [None, None]
             qs = [None, None]
+            evs = [None, None]
             if n[0] == 0 and n[1] == 0:
                 c = pool.counters()
                 if c["games"] >= n_games:
@@ -166,6 +278,9 @@ class BatchRunner:
                 continue
             for a in (0, 1):
                 if n[a] == 0:
+                    continue
+                if self.cfg[min(a, len(self.cfg) - 1)]["mjai_log"]:
+                    evs[a] = self._mjai_log_policy(min(a, len(self.cfg) - 1))
                     continue
                 obs, masks = pool.encode(a)
                 inv = pool.encode_oracle(a) if self.cfg[min(a, len(self.cfg) - 1)]["oracle"] else None
@@ -190,6 +305,15 @@ class BatchRunner:
         scores, done = pool.results()
         if not (done == 1).all():
             raise MortalAmdError("some games did not finish")
+        if self.any_mjai_log:  # the last kyoku's end_kyoku, then end_game(index, scores) (game.rs:113-118,199-201)
+            for g in range(n_games):
+                self._report_kyoku_ends(g, self._game_log(g))
+                for a, eng in enumerate(self.engines):
+                    if self.cfg[a]["mjai_log"]:
+                        for seat in range(4):
+                            idx = self.player_index[a].get((g, seat))
+                            if idx is not None:
+                                eng.end_game(idx, [int(x) for x in scores[g]])
         return scores
 
     @staticmethod

@@ -329,6 +329,10 @@ int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
     return mj_step_q(P, a0, a1, nullptr, nullptr, stream);
 }
 int mj_step_q(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, const float* q1, void* stream) {
+    return mj_step_ev(P, a0, a1, q0, q1, nullptr, nullptr, stream);
+}
+int mj_step_ev(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, const float* q1, const uint64_t* ev0,
+               const uint64_t* ev1, void* stream) {
     if (!P) return fail("null pool");
     if ((P->enable_agari_guard[0] && a0 && !q0) || (P->enable_agari_guard[1] && a1 && !q1))
         return fail("enable_rule_based_agari_guard needs the q-values of the batch (mj_step_q)");
@@ -341,6 +345,8 @@ int mj_step_q(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0, 
     sp.actions[1] = a1;
     sp.q_values[0] = q0;
     sp.q_values[1] = q1;
+    sp.reactions[0] = ev0;
+    sp.reactions[1] = ev1;
     sp.log = P->log;
     sp.log_len = P->log_len;
     sp.log_cap = P->log_cap;

@@ -25,6 +25,8 @@ struct StepParams {
     MjTablesDev tables;
     const int* actions[2];     // per agent, indexed by row id of the previous cycle (NULL on the first cycle)
     const float* q_values[2];  // per agent [rows][46] or NULL (needed only by the agari guard)
+    const uint64_t* reactions[2];  // per agent: explicit mjai reactions (one LG_* event word per row, 0 = none) instead of
+                                   // action ids — mjai-log engines answer with events (agent/mjai_log.rs:65-87)
     uint64_t* log;             // [n_tables][log_cap] event words or NULL (logging off)
     uint32_t* log_len;         // [n_tables]
     uint32_t log_cap;
@@ -63,6 +65,37 @@ template <class LN> MJD u64 discard_candidates_aka(const LN& L, int s) {  // 37-
 }
 
 // ---------------------------------------------------------------- action id -> reaction (mortal.rs:338-573)
+// An explicit reaction of seat s (mjai-log engines): the LG_* header word of the event.  The host has already run
+// PlayerState::validate_reaction on it (state/action.rs:91-228, as BoardState::step does, board.rs:524-533); here only the
+// actor and the reaction type are checked against the seat's candidates.
+template <class LN> MJDN Reaction reaction_from_word(const LN& L, int s, uint64_t w) {
+    Reaction r = {RX_NONE, (u8)s, 0, MJ_NONE, MJ_NONE, MJ_NONE, MJ_NONE, 0, 0ull};
+    const int t = (int)(w & 15);
+    if (t == 0) return r;  // {"type":"none"}
+    const u32 cans = F1(cans, s);
+    const int actor = (int)((w >> 4) & 3), pai = (int)((w >> 8) & 63);
+    const int c0 = (int)((w >> 14) & 63), c1 = (int)((w >> 20) & 63), c2 = (int)((w >> 26) & 63);
+    r.target = (u8)((w >> 6) & 3);
+    bool ok = actor == s || t == LG_RYUKYOKU;
+    switch (t) {
+        case LG_DAHAI: r.type = RX_DAHAI; r.pai = (u8)pai; r.tsumogiri = (u8)((w >> 38) & 1); ok = ok && (cans & CAN_DISCARD); break;
+        case LG_REACH: r.type = RX_REACH; ok = ok && (cans & CAN_RIICHI); break;
+        case LG_CHI: r.type = RX_CHI; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; ok = ok && (cans & (CAN_CHI_LOW | CAN_CHI_MID | CAN_CHI_HIGH)); break;
+        case LG_PON: r.type = RX_PON; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; ok = ok && (cans & CAN_PON); break;
+        case LG_DAIMINKAN: r.type = RX_DAIMINKAN; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; r.c2 = (u8)c2; ok = ok && (cans & CAN_DAIMINKAN); break;
+        case LG_KAKAN: r.type = RX_KAKAN; r.pai = (u8)pai; ok = ok && (cans & CAN_KAKAN); break;
+        case LG_ANKAN: r.type = RX_ANKAN; r.pai = (u8)deaka(c0); ok = ok && (cans & CAN_ANKAN); break;
+        case LG_HORA: r.type = RX_HORA; ok = ok && (r.target == s ? (cans & CAN_TSUMO_AGARI) : (cans & CAN_RON_AGARI)); break;
+        case LG_RYUKYOKU: r.type = RX_RYUKYOKU; ok = ok && (cans & CAN_RYUKYOKU); break;
+        default: ok = false; break;
+    }
+    if (!ok) {
+        set_err(L, MJ_ERR_ILLEGAL_ACTION);
+        r.type = RX_NONE;
+    }
+    return r;
+}
+
 template <class LN> MJDN Reaction decode_action(const LN& L, int s, int action, int kan_tile) {
     Reaction r = {RX_NONE, (u8)s, 0, MJ_NONE, MJ_NONE, MJ_NONE, MJ_NONE, 0, 0ull};
     const u32 cans = F1(cans, s);
@@ -573,6 +606,13 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
             }
             const int agent = (F(agent_of_seat) >> s) & 1;
             const int mr = F1(main_row, s), kr = F1(kan_row, s);
+            if (P.reactions[agent]) {
+                rx[s] = reaction_from_word(L, s, P.reactions[agent][mr]);
+                if (L.log && rx[s].type != RX_NONE)
+                    rx[s].tag = (uint64_t)(P.cycle & 0xFFFFFu) | ((uint64_t)(mr & 0x3FFFF) << 20) |
+                                ((uint64_t)((F1(shanten, s) + 1) & 15) << 56) | ((uint64_t)((F1(pflags, s) & PF_AT_FURITEN) != 0) << 60) | (1ull << 63);
+                continue;
+            }
             int action = P.actions[agent] ? P.actions[agent][mr] : 45;
             const int kan_tile = (kr >= 0 && P.actions[agent]) ? P.actions[agent][kr] : -1;
             if (P.enable_agari_guard[agent] && action == 43 && !rule_based_agari(L, s)) {

@@ -151,7 +151,7 @@ class TablePool:
     def set_refill(self, nonce_stride):
         check(self._L.mj_pool_set_refill(self.h, nonce_stride))
 
-    def step(self, actions0=None, actions1=None, q0=None, q1=None):
+    def step(self, actions0=None, actions1=None, q0=None, q1=None, ev0=None, ev1=None):
         """One arena cycle; actionsN = int32 cuda tensor with one action per row of agent N's last batch; qN = that
         batch's q-values (f32 cuda [n, 46]), needed only by an agent configured with the rule-based agari guard."""
         for a in (actions0, actions1):
@@ -166,13 +166,19 @@ class TablePool:
                 raise MortalAmdError(f"agent {ag}: {a.numel()} actions for a batch of {self.n_rows[ag]} rows")
             if q is not None and q.numel() != self.n_rows[ag] * ACTION_SPACE:
                 raise MortalAmdError(f"agent {ag}: q-values of shape {tuple(q.shape)} for a batch of {self.n_rows[ag]} rows")
-            if a is None and self.n_rows[ag]:
+            ev = (ev0, ev1)[ag]
+            if ev is not None and (ev.dtype != torch.int64 or ev.numel() != self.n_rows[ag] or not ev.is_contiguous()
+                                   or ev.device.type != self.device.type):
+                raise MortalAmdError(f"agent {ag}: reactions must be {self.n_rows[ag]} contiguous int64 event words on the device")
+            if a is None and ev is None and self.n_rows[ag]:
                 raise MortalAmdError(f"agent {ag}: the previous batch had {self.n_rows[ag]} rows but no actions were passed")
         p0 = actions0.data_ptr() if actions0 is not None and actions0.numel() else None
         p1 = actions1.data_ptr() if actions1 is not None and actions1.numel() else None
         pq0 = q0.data_ptr() if q0 is not None and q0.numel() else None
         pq1 = q1.data_ptr() if q1 is not None and q1.numel() else None
-        check(self._L.mj_step_q(self.h, p0, p1, pq0, pq1, self._stream()))
+        pe0 = ev0.data_ptr() if ev0 is not None and ev0.numel() else None
+        pe1 = ev1.data_ptr() if ev1 is not None and ev1.numel() else None
+        check(self._L.mj_step_ev(self.h, p0, p1, pq0, pq1, pe0, pe1, self._stream()))
         out = (C.c_int32 * 2)()
         check(self._L.mj_rows_count(self.h, out, self._stream()))
         self.n_rows = [out[0], out[1]]

@@ -47,12 +47,27 @@ class PlayerState:
         self.player_id = int(player_id)
         self._pool = TablePool(1, version=4, device=device)
         self._pool.reset([(0, 0)])
+        self._tbl = 0
+        self._owns = True
         self._cache = None
 
+    @classmethod
+    def view(cls, pool, table, player_id):
+        """A read-only copy of seat `player_id`'s state on table `table` of an arena pool, taken now — what the reference
+        hands to an mjai-log engine as `GameState.state` (`state.clone()`, agent/mjai_log.rs:104-118).  The getters and
+        `brief_info()` answer from the copy; `update` / `encode_obs` / device queries are not available on it."""
+        self = cls.__new__(cls)
+        self.player_id = int(player_id)
+        self._pool = None
+        self._tbl = int(table)
+        self._owns = False
+        self._cache = pool.debug_table(int(table))
+        return self
+
     def close(self):
-        if self._pool is not None:
+        if self._pool is not None and self._owns:
             self._pool.close()
-            self._pool = None
+        self._pool = None
 
     def __del__(self):
         try:
@@ -66,6 +81,7 @@ class PlayerState:
         if ev["type"] in ("start_game", "end_game"):
             ev = {"type": "end_kyoku"}  # same effect on a PlayerState: only the per-event reset of last_cans
         words = mjai_log.encode_events([ev])
+        self._need_pool()
         check(lib.mj_table_apply_event(self._pool.h, 0, words.ctypes.data, len(words), _stream()))
         self._cache = None
         code, _ = self._pool.first_error()
@@ -133,12 +149,12 @@ class PlayerState:
             in_hand(ev["consumed"])
         elif t == "kakan":
             ensure(cans.can_kakan, "cannot kakan")
-            ensure(deaka(tid[ev["pai"]]) in self.kakan_candidates, f"cannot kakan {ev['pai']}")
+            ensure(deaka(tid[ev["pai"]]) in self._kakan_cand, f"cannot kakan {ev['pai']}")
             in_hand([ev["pai"]])
         elif t == "ankan":
             ensure(cans.can_ankan, "cannot ankan")
             tile = deaka(tid[ev["consumed"][0]])
-            ensure(tile in self.ankan_candidates, f"cannot ankan {mjai_log.TILE_NAMES[tile]}")
+            ensure(tile in self._ankan_cand, f"cannot ankan {mjai_log.TILE_NAMES[tile]}")
             in_hand(ev["consumed"])
         elif t == "hora":
             if ev["target"] == self.player_id:
@@ -149,12 +165,18 @@ class PlayerState:
             raise ValueError(f"unexpected action {ev!r}")
         return None
 
+    def _need_pool(self):
+        if self._pool is None:
+            raise MortalAmdError("this PlayerState is a read-only copy of an arena table (PlayerState.view)")
+
     def _table(self):
         if self._cache is None:
+            self._need_pool()
             self._cache = self._pool.debug_table(0)
         return self._cache
 
     def _query(self, what, args=()):
+        self._need_pool()
         a = np.zeros(8, dtype=np.int32)
         a[:len(args)] = args
         out = np.zeros(8, dtype=np.int32)
@@ -164,6 +186,7 @@ class PlayerState:
 
     # ---- obs (state/obs_repr.rs:776-791)
     def encode_obs(self, version, at_kan_select):
+        self._need_pool()
         self._pool.configure(0, version=int(version))
         check(lib.mj_table_mark_row(self._pool.h, 0, self.player_id, int(bool(at_kan_select)), _stream()))
         import ctypes as C
@@ -200,8 +223,40 @@ class PlayerState:
     honba = property(lambda s: int(s._table()["honba"][0]))
     is_menzen = property(lambda s: bool(int(s._table()["pflags"][s.player_id]) & (1 << 7)))
     akas_in_hand = property(lambda s: [bool((int(s._table()["akas_in_hand"][s.player_id]) >> i) & 1) for i in range(3)])
-    ankan_candidates = property(lambda s: [i for i, b in enumerate(s._bits34("ankan_cand")) if b])
-    kakan_candidates = property(lambda s: [i for i, b in enumerate(s._bits34("kakan_cand")) if b])
+    _ankan_cand = property(lambda s: [i for i, b in enumerate(s._bits34("ankan_cand")) if b])
+    _kakan_cand = property(lambda s: [i for i, b in enumerate(s._bits34("kakan_cand")) if b])
+    # the rest of the pyo3 surface (state/getter.rs:8-156)
+    kyoku = property(lambda s: int(s._table()["kyoku"][0]) & 3)          # within the round (update.rs:151-153)
+    is_oya = property(lambda s: (int(s._table()["kyoku"][0]) & 3) == s.player_id)
+    can_w_riichi = property(lambda s: bool(int(s._table()["pflags"][s.player_id]) & (1 << 1)))
+    self_riichi_declared = property(lambda s: bool((int(s._table()["riichi_declared"][0]) >> s.player_id) & 1))
+    self_riichi_accepted = property(lambda s: bool((int(s._table()["riichi_accepted"][0]) >> s.player_id) & 1))
+
+    def _melds(self, name, kind):
+        t = self._table()
+        n = int(t["n_melds"].reshape(4, 4)[self.player_id][kind])
+        return [int(x) for x in t[name].reshape(4, 4)[self.player_id][:n]]
+
+    chis = property(lambda s: s._melds("chis", 0))
+    pons = property(lambda s: s._melds("pons", 1))
+    minkans = property(lambda s: s._melds("minkans", 2))
+    ankans = property(lambda s: s._melds("ankans", 3))
+
+    def _tile_or_none(self, name):
+        raw = int(self._table()[name][self.player_id])
+        return None if raw >= 38 else mjai_log.TILE_NAMES[raw]
+
+    def last_self_tsumo(self):
+        return self._tile_or_none("last_self_tsumo")
+
+    def last_kawa_tile(self):
+        return self._tile_or_none("last_kawa_tile")
+
+    def ankan_candidates(self):
+        return [mjai_log.TILE_NAMES[t] for t in self._ankan_cand]
+
+    def kakan_candidates(self):
+        return [mjai_log.TILE_NAMES[t] for t in self._kakan_cand]
 
     @property
     def scores(self):

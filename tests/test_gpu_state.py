@@ -268,7 +268,7 @@ def test_random_hands_device_vs_oracle(oracle):
         assert dev.shanten == sn["shanten"] and dev.at_furiten == sn["at_furiten"], (hand.tolist(), draw)
         assert dev.waits == [bool(x) for x in sn["waits"]]
         assert {k: int(getattr(cd, k)) for k in T.O.CANS if k != "target_actor"} == {k: v for k, v in co.items() if k != "target_actor"}
-        assert len(dev.ankan_candidates) == sn["n_ankan_cand"] and len(dev.kakan_candidates) == sn["n_kakan_cand"]
+        assert len(dev.ankan_candidates()) == sn["n_ankan_cand"] and len(dev.kakan_candidates()) == sn["n_kakan_cand"]
         og, mg = dev.encode_obs(4, False)
         oo, mo = ora.encode_obs(4, False)
         assert (mg == mo).all() and (og.view(np.uint32) == oo.view(np.uint32)).all(), (hand.tolist(), draw)
