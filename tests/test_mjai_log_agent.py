@@ -142,7 +142,7 @@ def test_mjai_log_challenger_one_vs_three(oracle, emu_arena):
 def test_mjai_log_two_vs_two_and_validation(oracle, emu_arena):
     from libriichi.arena import TwoVsTwo
 
-    from mortal_amd._lib import MortalAmdError
+    from mortal_amd.arena import MortalAmdError  # the class object the arena raises (test_host reloads mortal_amd._lib)
     from mortal_amd.pool import default_deal_algo
 
     Base = _example_engine_cls()
