@@ -30,6 +30,7 @@ int fail(const std::string& msg) {
 
 struct DevTables {
     bool ready = false;
+    int device = -1;  // the HIP device the tables (and the __constant__ copy of their pointers) live on
     MjTablesDev dev{};
     MjGatherEnt* gather = nullptr;
     int n_gather = 0;
@@ -182,6 +183,7 @@ int mj_tables_upload(const void* payload, size_t size) {
         upload(build_rbf(256, 6, 3), &g_tables.rbf_6) || upload(build_rbf(256, 12, 3), &g_tables.rbf_12) ||
         upload(build_rbf(256, 23, 4), &g_tables.rbf_23))
         return -1;
+    HIP_OK(hipGetDevice(&g_tables.device));
     g_tables.ready = true;
     return 0;
 }
@@ -189,6 +191,12 @@ int mj_tables_upload(const void* payload, size_t size) {
 MjPool* mj_pool_create(int n_tables, int version, int deal_algo, int max_rows) {
     if (!g_tables.ready) {
         fail("mj_tables_upload has not been called");
+        return nullptr;
+    }
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != g_tables.device) {  // one process per GPU: pools live where the tables are
+        fail("the lookup tables were uploaded to HIP device " + std::to_string(g_tables.device) + ", the current device is " +
+             std::to_string(cur) + ": use one process per GPU (tables and pools of a process share one device)");
         return nullptr;
     }
     if (n_tables <= 0 || mj_obs_rows(version) < 0) {
@@ -242,10 +250,11 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->counters);
     hipFree(P->final_scores);
     hipFree(P->final_done);
-    for (auto& e : P->events) {
-        hipEventDestroy(e.first);
-        hipEventDestroy(e.second);
-    }
+    for (auto* v : {&P->events, &P->sp_events})
+        for (auto& e : *v) {
+            hipEventDestroy(e.first);
+            hipEventDestroy(e.second);
+        }
     delete P;
 }
 
@@ -547,7 +556,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         P->events.push_back({e0, e1});
     }
     HIP_OK(hipGetLastError());
-    if (ep.version == 4 && !getenv("MJ_DEBUG_SKIP_SP")) {  // SP block, rows 889..1011 (mj_sp.hip)
+    if (ep.version == 4) {  // SP block, rows 889..1011 (mj_sp.hip)
         if (!P->sp_work) {
             P->sp_grid = 1024;
             HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));

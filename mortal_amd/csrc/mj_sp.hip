@@ -30,6 +30,9 @@
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
 #define SP_NS 8                // states per expansion chunk (one chunk per wavefront)
+#ifndef SP_OPT
+#define SP_OPT 0               // A/B switches of candidate optimisations (tools/build_variant.sh): see the uses below
+#endif
 
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
@@ -419,6 +422,9 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         C->r3[s][i] = sh_merge(pr, C->row[s][i == 3 ? 2 : 3], ld3);
     }
     mj_team_sync<SP_NT>();
+#if SP_OPT & 2
+#pragma unroll 2  // two probes' table gathers in flight per lane
+#endif
     for (int task = tid; task < n * 34; task += SP_NT) {
         const int s = task / 34, t = task % 34;
         const SpState S = sp_chunk_state(C, s);
@@ -521,9 +527,22 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         C->item_off[n] = off;
     }
     // P4b: V = merge(two untouched suits, row of h - d), the row gathered again (it was probed in P3: an L2 hit)
+#if SP_OPT & 4
+    // tasks over the existing (state, safe kind, other suit) triples only: 3 * n_kinds per state, packed
+    int kind_off[SP_NS + 1];
+    kind_off[0] = 0;
+#pragma unroll
+    for (int s = 0; s < SP_NS; s++) kind_off[s + 1] = kind_off[s] + (s < n ? 3 * (int)C->n_kinds[s] : 0);
+    for (int task = tid; task < kind_off[SP_NS]; task += SP_NT) {
+        int s = 0;
+#pragma unroll
+        for (int q = 1; q < SP_NS; q++) s += (int)(task >= kind_off[q]);
+        const int local = task - kind_off[s], ki = (local * 21846) >> 16, k = local - 3 * ki;  // local / 3, local < 39
+#else
     for (int task = tid; task < n * 39; task += SP_NT) {
         const int s = task / 39, q = task % 39, ki = q / 3, k = q % 3;
         if (ki >= (int)C->n_kinds[s]) continue;
+#endif
         const int d = C->kinds[s][ki], sd = sh_suit(d), st = k + (k >= sd);  // k-th suit != sd
         int x = -1, y = -1;  // the two suits other than st and sd
         for (int i = 0; i < 4; i++)
@@ -546,6 +565,9 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         ti = nk > 1 ? (local * (int)C->inv[s]) >> 16 : local;  // local < 34 * 13: exact (sp_item_div_is_exact)
         ki = local - ti * nk;
     };
+#if SP_OPT & 1
+#pragma unroll 2  // two items' table gathers in flight per lane
+#endif
     for (int it = tid; it < n_items; it += SP_NT) {
         int s, ti, ki;
         item_decode(it, s, ti, ki);

@@ -6,7 +6,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(HERE, "_build", "libmortal_amd_emu.so")
+EXTRA = os.environ.get("EMU_EXTRA_FLAGS", "").split()  # e.g. -DSP_OPT=7: validate an experimental kernel variant on the host
+OUT = os.path.join(HERE, "_build", "libmortal_amd_emu" + ("_" + "".join(c for c in "".join(EXTRA) if c.isalnum()) if EXTRA else "") + ".so")
 CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
@@ -19,7 +20,7 @@ def build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cxx = CXX if os.path.exists(CXX) else "g++"
     subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O2", "-g1", "-fPIC", "-shared", "-ffp-contract=off", "-DMJ_EMU",
-                           "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes",
+                           "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes", *EXTRA,
                            "-I", os.path.join(HERE, "emu"), "-o", OUT, os.path.join(csrc, "mj_capi.hip")])
     return OUT
 

@@ -165,8 +165,19 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
                 f"cycle {cycle}: mask mismatch at row {r} {rows_o[r]}:\n oracle {np.flatnonzero(masks_o[r]).tolist()}\n"
                 f" gpu    {np.flatnonzero(mg[r]).tolist()}\n"
                 f" state: {arena.player_state(int(rows_o[r][0]), int(rows_o[r][1])).snapshot()}")
+        if n and not bool(masks_g.any(dim=1).all()):
+            raise AssertionError(f"cycle {cycle}: a decision row without any legal action")
         if want_obs and n:
             og = obs_g.cpu().numpy()
+            # obs_repr.rs:626-628: every plane value lies in [0, 1] (the reference's debug assertion on the finished tensor)
+            if not (np.isfinite(og).all() and og.min() >= 0.0 and og.max() <= 1.0):
+                raise AssertionError(f"cycle {cycle}: obs value outside [0, 1]: min {og.min()} max {og.max()}")
+            # state/test.rs:49-58 (`validate` after every event): shanten bookkeeping of the acting seat is consistent with a
+            # fresh table lookup of its hand, on the oracle's PlayerState (the device agrees with it field by field below)
+            for r in range(0, n, max(1, n // 32)):
+                sn = arena.player_state(int(rows_o[r][0]), int(rows_o[r][1])).snapshot()
+                assert sn["real_time_shanten"] == oracle.calc_shanten(sn["tehai"], sn["tehai_len_div3"]), (cycle, rows_o[r].tolist())
+                assert sn["doras_owned"][0] >= int(sn["akas_in_hand"].sum())
             a = np.ascontiguousarray(og[:, :n_cmp]).view(np.uint32)
             b = np.ascontiguousarray(obs_o[:, :n_cmp]).view(np.uint32)
             if not (a == b).all():

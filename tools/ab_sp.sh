@@ -13,7 +13,7 @@ grep -a "smoke\|passed\|failed\|Error" gpurun_out/ab/parity.log | tail -6
 if [ $rc -ne 0 ]; then tail -c 6000 gpurun_out/ab/parity.log; exit 1; fi   # no bench on a library that is not bit-exact
 libs="$lib"; [ "$lib" != libmortal_amd.so ] && libs="$lib libmortal_amd.so"
 for l in $libs; do
-  MORTAL_AMD_LIB=/root/repo/mortal_amd/$l MJ_SP_PROF=1 timeout 80 python bench.py --no-cpu-baseline --steps 20 --warmup 5 \
+  MORTAL_AMD_LIB=/root/repo/mortal_amd/$l MJ_SP_PROF=1 timeout 80 python bench.py --no-cpu-baseline --no-matrix --steps 20 --warmup 5 \
       > gpurun_out/ab/bench_$l.json 2> gpurun_out/ab/bench_$l.err
   echo "$l rc=$?"; grep -a "sp prof" gpurun_out/ab/bench_$l.err | tail -1; python - <<PY
 import json

@@ -13,8 +13,8 @@ reference embeds as `libriichi/src/algo/data/*.gz`
             u32 key, u32 n_div, u32 div[4]   (unused div = 0)
 
 and xz-compress the lot.  The file travels with the repo (the GPU box has no
-/root/reference).  sha256 of the decompressed payload is printed and pinned in
-tests/test_tables.py.
+/root/reference).  sha256 of the decompressed payload is printed; the payload is exercised by the reference's
+shanten / agari KATs (tests/test_oracle_kats.py, through the oracle's copy of the tables) and by every lock-step test.
 """
 import gzip, hashlib, lzma, struct, sys, os
 

@@ -7,5 +7,5 @@ rc=$?; echo "parity rc=$rc"; tail -3 gpurun_out/fin/parity.log
 lib=libmortal_amd.so; [ $rc -ne 0 ] && { lib=libmortal_amd_prev.so; tail -c 3000 gpurun_out/fin/parity.log; }
 echo "bench on $lib"
 cd /tmp && MJ_SP_PROF=1 MORTAL_AMD_LIB=/root/repo/mortal_amd/$lib timeout 70 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/fin/prof -- \
-    python /root/repo/bench.py --no-cpu-baseline --steps 20 --warmup 5 > /root/repo/gpurun_out/fin/bench.json 2> /root/repo/gpurun_out/fin/bench.err
+    python /root/repo/bench.py --no-cpu-baseline --no-matrix --steps 20 --warmup 5 > /root/repo/gpurun_out/fin/bench.json 2> /root/repo/gpurun_out/fin/bench.err
 echo "bench rc=$?"; cat /root/repo/gpurun_out/fin/bench.json | cut -c1-400; grep -a "sp prof" /root/repo/gpurun_out/fin/bench.err | tail -2

@@ -14,7 +14,7 @@ for set in \
   "WRITE_SIZE TCP_TCC_READ_REQ_sum"; do
   i=$((i+1)); tag=p$i
   timeout 240 rocprofv3 --pmc $set --kernel-include-regex mj_k_sp --output-format csv -d $OUT/$tag -- \
-      python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --version 4 --tables $TABLES "$@" > $OUT/$tag.log 2>&1
+      python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-matrix --version 4 --tables $TABLES "$@" > $OUT/$tag.log 2>&1
   python3 - <<PY | tee $OUT/$tag.txt
 import csv,glob,collections
 fs=glob.glob('$OUT/$tag/*/*counter_collection.csv')

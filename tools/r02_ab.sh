@@ -10,7 +10,7 @@ for tag in "$@"; do
       -k "random_hands or greedy_policy_v4" ) > gpurun_out/ab2/parity_$tag.log 2>&1
   rc=$?; echo "== $lib parity rc=$rc: $(grep -a 'passed\|failed' gpurun_out/ab2/parity_$tag.log | tail -1)"
   if [ $rc -ne 0 ]; then grep -a "Error\|assert\|mismatch" gpurun_out/ab2/parity_$tag.log | head -5; continue; fi
-  MJ_SP_PROF=1 timeout 120 python bench.py --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/ab2/bench_$tag.json 2> gpurun_out/ab2/bench_$tag.err
+  MJ_SP_PROF=1 timeout 120 python bench.py --no-cpu-baseline --no-matrix --steps 10 --warmup 3 > gpurun_out/ab2/bench_$tag.json 2> gpurun_out/ab2/bench_$tag.err
   python - <<PY
 import json
 try:
