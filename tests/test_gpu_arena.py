@@ -37,7 +37,9 @@ def _oracle_rankings(oracle, challenger, champion, seed_start, seed_count, versi
 
     n = seed_count * 4
     seeds = [(seed_start[0] + g // 4, seed_start[1]) for g in range(n)]
-    arena = oracle.Arena(seeds, deal_algo=0, enable_quick_eval=True, version=version, keep_log=False)
+    from mortal_amd.pool import default_deal_algo
+
+    arena = oracle.Arena(seeds, deal_algo=default_deal_algo(), enable_quick_eval=True, version=version, keep_log=False)
     while arena.n_live > 0:
         rows = arena.poll()
         k = len(rows)
