@@ -25,16 +25,21 @@ typedef uint64_t u64;
 // (tests/host/emu, -DMJ_EMU) can give them their lane-group meaning; on the device they are the plain HIP forms.
 #ifndef MJ_EMU
 #define MJ_DYN_SHARED(T, name) extern __shared__ T name[]
-// LDS hand-off between the W lanes of a team inside one wavefront (lock-step: a scheduling + memory fence suffices)
+// LDS hand-off between the W lanes of a team inside one wavefront.  The lanes run in lock-step and the LDS serves a
+// wavefront's accesses in issue order, so a later ds_read sees an earlier ds_write of the same wavefront: all that is needed
+// is that the compiler keeps the order (wavefront-scope fence + scheduling barrier, no instruction).  A workgroup-scope
+// fence (__threadfence_block) would also drain every outstanding HBM load (s_waitcnt vmcnt(0)) at each hand-off.
 template <int W> MJD void mj_team_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 // the same for teams of `width` consecutive lanes, any width (team k = lanes [k * width, (k + 1) * width) of the wavefront)
 MJD void mj_team_sync_n(int width) {
     (void)width;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 #else
 template <int W> inline void mj_team_sync() { emu::group_sync(W); }

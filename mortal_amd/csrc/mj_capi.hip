@@ -558,7 +558,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     HIP_OK(hipGetLastError());
     if (ep.version == 4) {  // SP block, rows 889..1011 (mj_sp.hip)
         if (!P->sp_work) {
-            P->sp_grid = 1024;
+            P->sp_grid = 256 * SP_WGS;  // persistent workgroups: SP_WGS per CU
             HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
             HIP_OK(hipMalloc(&P->sp_queue, sizeof(int)));
             HIP_OK(hipMalloc(&P->sp_err, 24 * sizeof(unsigned long long)));
@@ -696,8 +696,9 @@ int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
         out[6] = e2[0];
         out[7] = e2[1];
         if (getenv("MJ_SP_PROF"))
-            fprintf(stderr, "[sp prof] rows %llu setup %llu expand %llu evalL0 %llu evalL>0 %llu encode %llu states %llu (wall_clock64 ticks, 100 MHz)\n",
-                    e2[1], e2[2], e2[3], e2[4], e2[5], e2[6], e2[7]);
+            fprintf(stderr, "[sp prof] rows %llu setup %llu expand %llu evalL0 %llu evalL>0 %llu encode %llu states %llu (wall_clock64 ticks, 100 MHz) | "
+                    "expand passes: probes %llu lists+V %llu td-probes %llu layout %llu inserts %llu; items %llu expanded %llu edges %llu l0-entries %llu\n",
+                    e2[1], e2[2], e2[3], e2[4], e2[5], e2[6], e2[7], e2[8], e2[9], e2[10], e2[11], e2[12], e2[13], e2[14], e2[15], e2[16]);
     }
     return 0;
 }

@@ -15,12 +15,7 @@
 // thread (160 B x 256 threads per encoded row showed up as +34 % HBM write traffic in the PMC counters).
 __constant__ MjTablesDev c_mj_tables;
 
-// Pointer type of a lane's block.  With -DMJ_POOL_GLOBAL (experimental, not validated) the HBM pool is addressed through
-// a global-address-space pointer, so the out-of-line rule functions use global_load/store instead of flat_* (see mj_sp.hip).
 template <class BlockT> struct LaneBlockPtr { typedef BlockT* type; };
-#ifdef MJ_POOL_GLOBAL
-template <> struct LaneBlockPtr<TableBlock> { typedef __attribute__((address_space(1))) TableBlock* type; };
-#endif
 template <class BlockT>
 struct LaneT {  // a table viewed through lane `l` of a block (pool block in HBM, or the 1-lane LDS copy)
     typename LaneBlockPtr<BlockT>::type B;

@@ -30,8 +30,8 @@
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
 #define SP_NS 8                // states per expansion chunk (one chunk per wavefront)
-#ifndef SP_OPT
-#define SP_OPT 0               // A/B switches of candidate optimisations (tools/build_variant.sh): see the uses below
+#ifndef SP_WGS
+#define SP_WGS 4               // resident workgroups per CU the kernel is compiled for (register budget 512 / SP_WGS per lane)
 #endif
 
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
@@ -72,7 +72,7 @@ struct SpParams {
     float* obs;                // [n_rows][1012][34]; rows 889.. are zero on entry (written by mj_k_encode<4>)
     SpWork* work;              // [gridDim.x]
     int* queue;                // dynamic row queue (zeroed before launch)
-    unsigned long long* prof;  // NULL or [24] phase timers
+    unsigned long long* prof;  // NULL or [24] phase timers / counters (MJ_SP_PROF; mj_counters prints them)
     unsigned long long* err;   // [0] hash-capacity overflows, [1] rows; cycle sums: [2] setup [3] expand [4] eval L0 [5] eval L>0 [6] encode; [7] states
 };
 
@@ -142,6 +142,7 @@ struct SpCtx {  // per-decision constants (LDS)
     int n_items;
     int overflow;
     unsigned long long* prof;  // optional phase timers (MJ_SP_PROF)
+    unsigned long long pt[8];  // per-row sums of the expansion pass timers / counters (flushed once per row)
     // candidates
     int n_cand;
     int cand_tile[SP_MAX_CAND], cand_slot[SP_MAX_CAND], cand_down[SP_MAX_CAND], cand_nreq[SP_MAX_CAND];
@@ -202,10 +203,16 @@ MJD u64 sp_claim_tag(TagP tagp, u64 h, u64 expected = 0ull) {  // atomicCAS(tag,
     __hip_atomic_compare_exchange_strong(tagp, &expected, h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return expected;
 }
-// hash-set insert of state `s` with id `dk`; returns the slot or -1 on overflow.  `fresh`: this call created the slot (and
-// wrote the node's key).
+// hash-set insert of the state `base` + draw `tile` - discard `dt` (either may be -1) with id `dk`; returns the slot or -1 on
+// overflow.  `fresh`: this call created the slot and wrote the node's key — the state itself is built only then (an edge
+// finds its child already present 11 times in 12).
+MJD SpState sp_apply(SpState s, int tile, int dt) {
+    if (tile >= 0) sp_deal(s, tile);
+    if (dt >= 0) sp_discard(s, dt);
+    return s;
+}
 template <class WP>
-__device__ __forceinline__ int sp_insert(WP W, SpCtx* X, const SpState& s, u64 dk, bool& fresh) {
+__device__ __forceinline__ int sp_insert(WP W, SpCtx* X, u64 dk, const SpState& base, int tile, int dt, bool& fresh) {
     const u64 tag = SP_TAG(dk);
     u32 pos = sp_dk_pos(dk);
     fresh = false;
@@ -213,7 +220,7 @@ __device__ __forceinline__ int sp_insert(WP W, SpCtx* X, const SpState& s, u64 d
         const u64 old = sp_claim_tag(&W->tag[pos], tag);
         if (old == 0ull) {
             u64 k[4];
-            sp_key(s, k);
+            sp_key(sp_apply(base, tile, dt), k);
             auto& n = W->node[pos];
             n.k0 = k[0]; n.k1 = k[1]; n.k2 = k[2]; n.k3 = k[3];
             fresh = true;
@@ -222,7 +229,7 @@ __device__ __forceinline__ int sp_insert(WP W, SpCtx* X, const SpState& s, u64 d
         if (old == tag) {
 #ifdef MJ_EMU  // the emulator never pre-empts between the claim and the key write: check the bijection on every hit
             u64 k[4];
-            sp_key(s, k);
+            sp_key(sp_apply(base, tile, dt), k);
             auto& n = W->node[pos];
             if (n.k0 != k[0] || n.k1 != k[1] || n.k2 != k[2] || n.k3 != k[3]) X->overflow = 1;
 #endif
@@ -343,10 +350,12 @@ __device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const
 struct SpChunk {
     u64 k[SP_NS][4];        // state keys (hand.mp, hand.sz | akas, wall.mp, wall.sz | akas)
     u64 dk[SP_NS];          // state ids
-    u64 row[SP_NS][4];      // base table rows of the four suits
     u64 r2[SP_NS][6];       // merges of two base rows (suit pairs 01 02 03 12 13 23)
     u64 r3[SP_NS][4];       // per suit: merge of the three OTHER base rows
-    u64 V[SP_NS][13][3];    // per safe discard kind d and k-th other suit: merge(two untouched suits, row of h - d)
+    union {
+        u64 row[SP_NS][4];      // base table rows of the four suits (dead after the partial merges P1 / P2)
+        u64 V[SP_NS][13][3];    // per safe discard kind d and k-th other suit: merge(two untouched suits, row of h - d) (P4b on)
+    };
     u64 req[SP_NS], safe[SP_NS];
     u32 bkey[SP_NS][4];     // base-5 suit keys
     u32 slot[SP_NS];
@@ -356,7 +365,7 @@ struct SpChunk {
     unsigned short coff[SP_NS][34];  // per required-tile ordinal: offset of its first child inside the state's child list
     u8 cnt[SP_NS][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds (shanten.rs:104-137)
     u8 tiles[SP_NS][36], kinds[SP_NS][16];
-    u8 n_tiles[SP_NS], n_kinds[SP_NS];
+    u8 n_tiles[SP_NS], n_kinds[SP_NS], n_hk[SP_NS];  // required tiles, safe discard kinds, tile kinds in the hand
     unsigned short inv[SP_NS];   // ceil(65536 / n_kinds): item index -> (tile ordinal, kind ordinal) without a division
     unsigned short queue[128];   // ring of kept (state, tile ordinal, kind ordinal) items waiting for the dense insert pass
 };
@@ -408,6 +417,7 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         C->bkey[s][i] = key;
         C->row[s][i] = sh_load(ST, i, key);
         C->cnt[s][i] = (u8)(i == 0 ? S.h.n_pairs() : i == 1 ? S.h.n_kinds() : i == 2 ? S.h.n_yao_pairs() : S.h.n_yao_kinds());
+        if (i == 0) C->n_hk[s] = (u8)__popcll(S.h.nonzero_mask());
     }
     mj_team_sync<SP_NT>();
     for (int task = tid; task < n * 6; task += SP_NT) {
@@ -422,30 +432,39 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         C->r3[s][i] = sh_merge(pr, C->row[s][i == 3 ? 2 : 3], ld3);
     }
     mj_team_sync<SP_NT>();
-#if SP_OPT & 2
-#pragma unroll 2  // two probes' table gathers in flight per lane
-#endif
+    // P3a: "+t" probes over (state, tile): which draws lower the shanten number
     for (int task = tid; task < n * 34; task += SP_NT) {
         const int s = task / 34, t = task % 34;
-        const SpState S = sp_chunk_state(C, s);
-        const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
-        const bool in_wall = S.w.get(t) > 0, in_hand = L > 0 && hc > 0;
-        const u32 kb = C->bkey[s][st], pw = sh_pow(t);
-        const u64 rt = sh_load(ST, st, in_wall ? kb + pw : kb);
-        const u64 rd = sh_load(ST, st, in_hand ? kb - pw : kb);
-        const u64 r3 = C->r3[s][st];
-        const int pairs = C->cnt[s][0], kinds = C->cnt[s][1], kpairs = C->cnt[s][2], kkinds = C->cnt[s][3];
-        if (in_wall) {
-            const int sh = sh_finish(sh_final(r3, rt, ld3), ld3, pairs + (hc == 1), kinds + (hc == 0), kpairs + (yao && hc == 1),
-                                     kkinds + (yao && hc == 0));
-            if (sh - L == -1) atomicOr((unsigned long long*)&C->req[s], 1ull << t);
-        }
-        if (in_hand) {  // `safe`: only discards with shanten(h - d) <= L can keep shanten after a required draw
-            const int sh = sh_finish(sh_final(r3, rd, ld3), ld3, pairs - (hc == 2), kinds - (hc == 1), kpairs - (yao && hc == 2),
-                                     kkinds - (yao && hc == 1));
-            if (sh <= L) atomicOr((unsigned long long*)&C->safe[s], 1ull << t);
-        }
         if (t < 17) C->keepw[s][t] = 0;
+        const SpState S = sp_chunk_state(C, s);
+        if (S.w.get(t) == 0) continue;
+        const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
+        const u64 rt = sh_load(ST, st, C->bkey[s][st] + sh_pow(t));
+        const int sh = sh_finish(sh_final(C->r3[s][st], rt, ld3), ld3, (int)C->cnt[s][0] + (hc == 1), (int)C->cnt[s][1] + (hc == 0),
+                                 (int)C->cnt[s][2] + (yao && hc == 1), (int)C->cnt[s][3] + (yao && hc == 0));
+        if (sh - L == -1) atomicOr((unsigned long long*)&C->req[s], 1ull << t);
+    }
+    // P3b (L >= 1): "-d" probes over the tile kinds of each hand only (packed tasks: a hand has ~9 of the 34 kinds) -> `safe`:
+    // only discards with shanten(h - d) <= L can keep shanten after a required draw
+    if (L > 0) {
+        int hk_off[SP_NS + 1];
+        hk_off[0] = 0;
+#pragma unroll
+        for (int s = 0; s < SP_NS; s++) hk_off[s + 1] = hk_off[s] + (s < n ? (int)C->n_hk[s] : 0);
+        for (int task = tid; task < hk_off[SP_NS]; task += SP_NT) {
+            int s = 0, base = 0;
+#pragma unroll
+            for (int q = 1; q < SP_NS; q++)
+                if (task >= hk_off[q]) { s = q; base = hk_off[q]; }
+            const SpState S = sp_chunk_state(C, s);
+            u64 m = S.h.nonzero_mask();
+            for (int k = task - base; k > 0; k--) m &= m - 1;
+            const int d = __ffsll((long long)m) - 1, sd = sh_suit(d), hc = S.h.get(d), yao = (int)((YAOKYUU_MASK >> d) & 1);
+            const u64 rd = sh_load(ST, sd, C->bkey[s][sd] - sh_pow(d));
+            const int sh = sh_finish(sh_final(C->r3[s][sd], rd, ld3), ld3, (int)C->cnt[s][0] - (hc == 2), (int)C->cnt[s][1] - (hc == 1),
+                                     (int)C->cnt[s][2] - (yao && hc == 2), (int)C->cnt[s][3] - (yao && hc == 1));
+            if (sh <= L) atomicOr((unsigned long long*)&C->safe[s], 1ull << d);
+        }
     }
     mj_team_sync<SP_NT>();
 }
@@ -503,19 +522,21 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     const ShTab ST = sh_tab(c_mj_tables);
     const int tid = threadIdx.x & (SP_NT - 1);
     const int ld3 = X->len_div3;
+    // optional pass timers (MJ_SP_PROF): wave wall-clock per pass, summed into prof[8..13] by lane 0
+    const bool prof = X->prof != nullptr;
+    long long tp0 = prof ? wall_clock64() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0, tp5 = 0;
     sp_chunk_probe(Wg, X, C, ST, first, n, L);
-    // P4a: ascending lists of the required tiles and of the safe discard kinds
-    for (int task = tid; task < n * 34; task += SP_NT) {
-        const int s = task / 34, t = task % 34;
-        const u64 req = C->req[s], safe = C->safe[s], below = (1ull << t) - 1;
-        if ((req >> t) & 1) C->tiles[s][__popcll(req & below)] = (u8)t;
-        if ((safe >> t) & 1) C->kinds[s][__popcll(safe & below)] = (u8)t;
-        if (t == 0) {
-            const int nk = __popcll(safe);
-            C->n_tiles[s] = (u8)__popcll(req);
-            C->n_kinds[s] = (u8)nk;
-            C->inv[s] = (unsigned short)(nk > 1 ? (65536 + nk - 1) / nk : 0);  // nk == 1: handled apart (65536 does not fit)
-        }
+    if (prof) tp1 = wall_clock64();
+    // P4a: ascending lists of the required tiles and of the safe discard kinds — one lane per state walks the two bit sets
+    // (~16 short iterations on 8 lanes issue fewer instructions than 34 tasks per state over the whole wavefront)
+    if (tid < n) {
+        const int s = tid;
+        int nt = 0, nk = 0;
+        for (u64 rest = C->req[s]; rest; rest &= rest - 1) C->tiles[s][nt++] = (u8)(__ffsll((long long)rest) - 1);
+        for (u64 rest = C->safe[s]; rest; rest &= rest - 1) C->kinds[s][nk++] = (u8)(__ffsll((long long)rest) - 1);
+        C->n_tiles[s] = (u8)nt;
+        C->n_kinds[s] = (u8)nk;
+        C->inv[s] = (unsigned short)(nk > 1 ? (65536 + nk - 1) / nk : 0);  // nk == 1: handled apart (65536 does not fit)
     }
     mj_team_sync<SP_NT>();
     if (tid == 0) {
@@ -527,22 +548,17 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         C->item_off[n] = off;
     }
     // P4b: V = merge(two untouched suits, row of h - d), the row gathered again (it was probed in P3: an L2 hit)
-#if SP_OPT & 4
     // tasks over the existing (state, safe kind, other suit) triples only: 3 * n_kinds per state, packed
     int kind_off[SP_NS + 1];
     kind_off[0] = 0;
 #pragma unroll
     for (int s = 0; s < SP_NS; s++) kind_off[s + 1] = kind_off[s] + (s < n ? 3 * (int)C->n_kinds[s] : 0);
     for (int task = tid; task < kind_off[SP_NS]; task += SP_NT) {
-        int s = 0;
+        int s = 0, base = 0;  // static indices only: a dynamically indexed local array would live in scratch
 #pragma unroll
-        for (int q = 1; q < SP_NS; q++) s += (int)(task >= kind_off[q]);
-        const int local = task - kind_off[s], ki = (local * 21846) >> 16, k = local - 3 * ki;  // local / 3, local < 39
-#else
-    for (int task = tid; task < n * 39; task += SP_NT) {
-        const int s = task / 39, q = task % 39, ki = q / 3, k = q % 3;
-        if (ki >= (int)C->n_kinds[s]) continue;
-#endif
+        for (int q = 1; q < SP_NS; q++)
+            if (task >= kind_off[q]) { s = q; base = kind_off[q]; }
+        const int local = task - base, ki = (local * 21846) >> 16, k = local - 3 * ki;  // local / 3, local < 39
         const int d = C->kinds[s][ki], sd = sh_suit(d), st = k + (k >= sd);  // k-th suit != sd
         int x = -1, y = -1;  // the two suits other than st and sd
         for (int i = 0; i < 4; i++)
@@ -551,6 +567,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         C->V[s][ki][k] = sh_merge(C->r2[s][sh_pair_idx(x, y)], rowd, ld3);
     }
     mj_team_sync<SP_NT>();
+    if (prof) tp2 = wall_clock64();
     // P5: (state, required t, safe d) probes of h + t - d (d == t never keeps: that is the state itself):
     // same suit -> final(r3[suit], gathered row of h+t-d); other suit -> final(V[d][suit t], gathered row of h+t)
     const int n_items = C->item_off[n];
@@ -565,9 +582,6 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         ti = nk > 1 ? (local * (int)C->inv[s]) >> 16 : local;  // local < 34 * 13: exact (sp_item_div_is_exact)
         ki = local - ti * nk;
     };
-#if SP_OPT & 1
-#pragma unroll 2  // two items' table gathers in flight per lane
-#endif
     for (int it = tid; it < n_items; it += SP_NT) {
         int s, ti, ki;
         item_decode(it, s, ti, ki);
@@ -583,6 +597,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0) atomicOr(&C->keepw[s][ti >> 1], 1u << (ki + 16 * (ti & 1)));
     }
     mj_team_sync<SP_NT>();
+    if (prof) tp3 = wall_clock64();
     // P6: child list layout per state (for each required tile `variants(t) * popcount(keep[t])` entries) + node header
     if (tid < n) {
         const int s = tid;
@@ -605,6 +620,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         node.sumreq = (u8)(sumreq & 0xFF);
     }
     mj_team_sync<SP_NT>();
+    if (prof) tp4 = wall_clock64();
     // P7: children.  The kept (t, d) of the item space are few (about a third) and an insert is long, so the items are
     // first compacted through a small ring (wave ballot + prefix), and the inserts run over full wavefronts of kept items:
     // each inserts its child state(s) (one per existing draw variant of t) into the hash set and leaves its child-list entry
@@ -622,16 +638,14 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             else if (variant == 0) { if (cnt < 2) continue; vidx = 0; count = cnt - 1; }
             else { vidx = cnt >= 2 ? 1 : 0; count = 1; }
             const int tile = (aka && variant == 1) ? akaize(t) : t;
-            SpState S2 = S;
-            sp_deal(S2, tile);
-            const int c = S2.h.get(d);
+            const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;  // akas_in_hand after the draw
+            const int c = S.h.get(d);  // d != t: the draw does not change its count
             int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
-            if (d == T_5M && (S2.akas & 1) && c == 1) dt = T_5MR;
-            else if (d == T_5P && (S2.akas & 2) && c == 1) dt = T_5PR;
-            else if (d == T_5S && (S2.akas & 4) && c == 1) dt = T_5SR;
-            sp_discard(S2, dt);
+            if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
+            else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
+            else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
             bool fresh;
-            const int cs = sp_insert(Wg, X, S2, sp_dk_add(C->dk[s], tile, dt), fresh);
+            const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), S, tile, dt, fresh);
             if (fresh && cs >= 0) {
                 const int idx = atomicAdd(&X->n_list, 1);
                 if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
@@ -669,6 +683,16 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             mj_team_sync<SP_NT>();
         }
     }
+    if (prof && tid == 0) {
+        tp5 = wall_clock64();
+        atomicAdd(&X->pt[0], (unsigned long long)(tp1 - tp0));  // P0-P3 keys, base rows, merges, +t / -d probes
+        atomicAdd(&X->pt[1], (unsigned long long)(tp2 - tp1));  // P4 lists, V merges
+        atomicAdd(&X->pt[2], (unsigned long long)(tp3 - tp2));  // P5 (t, d) probes
+        atomicAdd(&X->pt[3], (unsigned long long)(tp4 - tp3));  // P6 layout
+        atomicAdd(&X->pt[4], (unsigned long long)(tp5 - tp4));  // P7 scan + inserts
+        atomicAdd(&X->pt[5], (unsigned long long)n_items);     // (t, d) items
+        atomicAdd(&X->pt[6], (unsigned long long)n);           // states expanded
+    }
 }
 
 template <int J, int N, class F>
@@ -685,10 +709,13 @@ MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_const
 // left run 7 states per wavefront instead of 4.  Team scratch: nx[2][T + 1][4] then A[4][T] floats.
 #define SP_EVAL_LDS_FLOATS (3072 + 2048)            /* (256 / T) teams x (12 T + 8) floats, T >= 1 */
 MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
-#define SP_CH 8  // children (or level-0 draw entries) fetched per round trip
+#ifndef SP_CH
+#define SP_CH (SP_WGS > 4 ? 4 : 8)  // children (or level-0 draw entries) fetched per round trip
+#endif
 
-// Evaluate one state with a TEAM of T lanes, lane i = turn i: tenpai / win / EV of calc.rs:447-561 into node.val[i].
-// LK = min(level, 2); TN = 8 / 16 / 17 bounds the unrolled turn loop (rows with at most 8 / 16 / 17 draws left).
+// Evaluate the states list[first], list[first + stride], ... (< end) of one level with a TEAM of T lanes, lane i = turn i:
+// tenpai / win / EV of calc.rs:447-561 into node.val[i].  LK = min(level, 2); TN = 8 / 16 / 17 bounds the unrolled turn loop
+// (rows with at most 8 / 16 / 17 draws left).
 //   level 0 : for every draw entry with a yaku, accumulate its scores;
 //   level > 0: walk the state's child list (written by sp_expand_chunk in the reference's order); per turn fold the
 //              children of a draw entry like discard_slow (max of (int)EV, then discard priority), then accumulate.
@@ -696,127 +723,184 @@ MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
 // not_tsumo[j] / not_tsumo[i] times next[j + 1] — terms the reference skips (`break` on a zero probability, j < i for a
 // lane that runs all j) are added as +0.0 products instead of being branched over (x + 0.0 == x for the non-negative
 // sums here), so the unrolled j loop has no divergent control flow.
+// A state costs three DEPENDENT round trips to HBM / L2 (list -> node header -> child list -> child values) and little
+// arithmetic, so the loop is software-pipelined: while state k is being folded, the child list (level 0: scores) of state
+// k + 1 and the header of state k + 2 are already in flight.
+struct SpEvalFetch {  // what is prefetched per state
+    u32 slot;
+    u64 hdr;              // child_off | n_ch << 32 | sumreq << 48
+    u32 ent[SP_CH];       // level > 0: first SP_CH child-list entries
+};
 template <int TN, int LK>
-__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int slot, int ln) {
+__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int first, int end, int stride, int ln) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(TM);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    SP_HBM SpNode& node = Wg->node[slot];
     const int T = X->T;
     float* const nxb = TM;                  // nx[buf][k][4]
     float* const Ab = TM + 8 * (T + 1);     // A[c][j]
-    // child_off | n_ch << 32 | sumreq << 48 in one 8-byte load (level 0: past the L1, the yaku bits were set by L2 atomics)
-    SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&node.child_off);
-    const u64 hdr = LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u32 child_off = (u32)hdr;
-    const int n_ch = (int)((hdr >> 32) & 0xFFFF);
-    const float* nt = X->not_tsumo[min((int)((hdr >> 48) & 0xFF), 123)];
-    const float m_raw = nt[ln];  // not_tsumo_probs[i] of this lane's turn
-    const bool lane_on = m_raw != 0.f;
-    const float my_m = lane_on ? m_raw : 1.f;
-    const float my_r = sp_rcp_refined(my_m);
-    const int eff_ln = lane_on ? ln : 127;  // `eff_ln <= j` == this lane has a term at turn j
-    mj_team_sync_n(T);  // the team's previous state is done with A[] / nx[]
-#pragma unroll
-    for (int c = 0; c < 4; c++) Ab[c * T + ln] = X->tsumo_prob[c][ln] * m_raw;
-    mj_team_sync_n(T);
     const bool assume_riichi = X->is_menzen && X->prefer_riichi;
     const int hp_base = (int)(assume_riichi && X->calc_double_riichi && ln == 0);
     const bool haitei = X->calc_haitei != 0;
-    float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
+    const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
 
-    // one draw entry: scores (level 0) or the folded child values in nx[buf] (level > 0)
-    auto accumulate = [&](int count, int buf, float s0, float s1, float s2, float s3) {
-        const float* Ac = Ab + (count - 1) * T;
-        const float* nx = nxb + buf * 4 * (T + 1);
-        sp_static_for<0, TN>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if (j >= T) return;  // uniform (T is a constant of the row)
-            float prob = sp_div(Ac[j], my_m, my_r);
-            prob = eff_ln <= j ? prob : 0.f;
-            if constexpr (LK == 0) {
-                const int hp = hp_base + (int)(assume_riichi && j == ln) + (int)(haitei && j == T - 1);
-                acc_w += prob;
-                acc_e += prob * (hp == 0 ? s0 : hp == 1 ? s1 : hp == 2 ? s2 : s3);
-            } else {
-                if constexpr (LK == 1) acc_t += prob;
-                if (j < T - 1) {
-                    const float* v = nx + 4 * (j + 1);
-                    if constexpr (LK > 1) acc_t += prob * v[0];
-                    acc_w += prob * v[1];
-                    acc_e += prob * v[2];
-                }
-            }
-        });
+    auto fetch_slot = [&](int i) -> u32 { return Wg->list[min(i, end - 1)]; };
+    auto fetch_hdr = [&](u32 slot) -> u64 {
+        // one 8-byte load (level 0: past the L1 — the yaku bits were set by L2 atomics of the scoring pass)
+        SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off);
+        return LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-
-    if constexpr (LK == 0) {
-        const u32 yaku = child_off;  // bit e: draw entry e has a yaku
-        for (int e0 = 0; e0 < n_ch; e0 += SP_CH) {
-            float sc[SP_CH][4];
-            int cnt[SP_CH];
+    auto fetch_ent = [&](SpEvalFetch& f) {
+        if constexpr (LK > 0) {
 #pragma unroll
-            for (int q = 0; q < SP_CH; q++) {
-                const int e = min(e0 + q, SP_L0_MAX - 1);
-                cnt[q] = node.l0cnt[e];
-#pragma unroll
-                for (int k = 0; k < 4; k++) sc[q][k] = node.sc[e][k];
-            }
-#pragma unroll
-            for (int q = 0; q < SP_CH; q++) {
-                if (e0 + q >= n_ch) break;
-                if (!((yaku >> (e0 + q)) & 1)) continue;  // no yaku with this tile
-                accumulate(min(max(cnt[q], 1), 4), 0, sc[q][0], sc[q][1], sc[q][2], sc[q][3]);
-            }
+            for (int q = 0; q < SP_CH; q++) f.ent[q] = Wg->pool[min((int)(u32)f.hdr + q, SP_POOL - 1)];
         }
-    } else {
-        // discard_slow (calc.rs:570-637) fold state of the current draw entry, per turn
-        float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
-        int max_value = INT_MIN, max_key = sp_discard_key(T_UNK), buf = 0;
-        for (int c0 = 0; c0 < n_ch; c0 += SP_CH) {
-            u32 ent[SP_CH];
-#pragma unroll
-            for (int q = 0; q < SP_CH; q++) ent[q] = Wg->pool[min((int)child_off + c0 + q, SP_POOL - 1)];
-            float v[SP_CH][4];
+    };
+    SpEvalFetch cur, nxt;
+    cur.slot = fetch_slot(first);
+    nxt.slot = fetch_slot(first + stride);
+    cur.hdr = fetch_hdr(cur.slot);
+    nxt.hdr = fetch_hdr(nxt.slot);
+    fetch_ent(cur);
+
+    for (int i = first; i < end; i += stride) {
+        SP_HBM SpNode& node = Wg->node[cur.slot];
+        const u32 child_off = (u32)cur.hdr;
+        const int n_ch = (int)((cur.hdr >> 32) & 0xFFFF);
+        // level > 0: the child values of the first batch; level 0: the scores / counts of the first draw entries
+        float v[SP_CH][4];
+        int cnt0[SP_CH];
+        if constexpr (LK > 0) {
 #pragma unroll
             for (int q = 0; q < SP_CH; q++) {
-                const SP_HBM float* src = Wg->node[SP_ENT_SLOT(ent[q])].val[ln];
-                const bool ok = c0 + q < n_ch && !(ent[q] & SP_ENT_INVALID);
+                const SP_HBM float* src = Wg->node[SP_ENT_SLOT(cur.ent[q])].val[ln];
+                const bool ok = q < n_ch && !(cur.ent[q] & SP_ENT_INVALID);
 #pragma unroll
                 for (int k = 0; k < 4; k++) v[q][k] = ok ? src[k] : 0.f;
             }
+        } else {
 #pragma unroll
             for (int q = 0; q < SP_CH; q++) {
-                if (c0 + q >= n_ch) break;
-                const u32 e = ent[q];
-                if (e & SP_ENT_INVALID) {
-                    X->overflow = 1;
+                cnt0[q] = node.l0cnt[q];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[q][k] = node.sc[q][k];
+            }
+        }
+        // in flight behind them: the next state's child list and the header of the state after it
+        SpEvalFetch nn;
+        nn.slot = fetch_slot(i + 2 * stride);
+        fetch_ent(nxt);
+        nn.hdr = fetch_hdr(nn.slot);
+
+        const float* nt = X->not_tsumo[min((int)((cur.hdr >> 48) & 0xFF), 123)];
+        const float m_raw = nt[ln];  // not_tsumo_probs[i] of this lane's turn
+        const bool lane_on = m_raw != 0.f;
+        const float my_m = lane_on ? m_raw : 1.f;
+        const float my_r = sp_rcp_refined(my_m);
+        const int eff_ln = lane_on ? ln : 127;  // `eff_ln <= j` == this lane has a term at turn j
+        mj_team_sync_n(T);  // the team's previous state is done with A[] / nx[]
+        Ab[ln] = tp0 * m_raw;
+        Ab[T + ln] = tp1 * m_raw;
+        Ab[2 * T + ln] = tp2 * m_raw;
+        Ab[3 * T + ln] = tp3 * m_raw;
+        mj_team_sync_n(T);
+        float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
+
+        // one draw entry: scores (level 0) or the folded child values in nx[buf] (level > 0)
+        auto accumulate = [&](int count, int buf, float s0, float s1, float s2, float s3) {
+            const float* Ac = Ab + (count - 1) * T;
+            const float* nx = nxb + buf * 4 * (T + 1);
+            sp_static_for<0, TN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j >= T) return;  // uniform (T is a constant of the row)
+                float prob = sp_div(Ac[j], my_m, my_r);
+                prob = eff_ln <= j ? prob : 0.f;
+                if constexpr (LK == 0) {
+                    const int hp = hp_base + (int)(assume_riichi && j == ln) + (int)(haitei && j == T - 1);
+                    acc_w += prob;
+                    acc_e += prob * (hp == 0 ? s0 : hp == 1 ? s1 : hp == 2 ? s2 : s3);
                 } else {
-                    const int value = __float_as_int(v[q][3]);  // `as i32` of the child's EV (maximize_win_prob = false)
-                    const int key = (int)SP_ENT_KEY(e);       // cmp_discard_priority(dt, max_tile) > 0  <=>  key > max_key
-                    if (value > max_value || (value == max_value && key > max_key)) {
-                        nx_t = v[q][0];
-                        nx_w = v[q][1];
-                        nx_e = v[q][2];
-                        max_value = value;
-                        max_key = key;
+                    if constexpr (LK == 1) acc_t += prob;
+                    if (j < T - 1) {
+                        const float* vv = nx + 4 * (j + 1);
+                        if constexpr (LK > 1) acc_t += prob * vv[0];
+                        acc_w += prob * vv[1];
+                        acc_e += prob * vv[2];
                     }
                 }
-                if (e & SP_ENT_LAST) {  // last child of this draw entry (uniform in the team)
-                    float* dst = nxb + (buf * (T + 1) + ln) * 4;
-                    dst[0] = nx_t; dst[1] = nx_w; dst[2] = nx_e; dst[3] = 0.f;
-                    mj_team_sync_n(T);
-                    accumulate(min(max((int)SP_ENT_COUNT(e), 1), 4), buf, 0.f, 0.f, 0.f, 0.f);
-                    buf ^= 1;
-                    nx_t = nx_w = nx_e = -3.40282347e+38f;
-                    max_value = INT_MIN;
-                    max_key = sp_discard_key(T_UNK);
+            });
+        };
+
+        if constexpr (LK == 0) {
+            const u32 yaku = child_off;  // bit e: draw entry e has a yaku
+            for (int e0 = 0; e0 < n_ch; e0 += SP_CH) {
+                if (e0 > 0) {  // more than SP_CH draw entries (rare): fetch the next batch now
+#pragma unroll
+                    for (int q = 0; q < SP_CH; q++) {
+                        const int e = min(e0 + q, SP_L0_MAX - 1);
+                        cnt0[q] = node.l0cnt[e];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[q][k] = node.sc[e][k];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SP_CH; q++) {
+                    if (e0 + q >= n_ch) break;
+                    if (!((yaku >> (e0 + q)) & 1)) continue;  // no yaku with this tile
+                    accumulate(min(max(cnt0[q], 1), 4), 0, v[q][0], v[q][1], v[q][2], v[q][3]);
+                }
+            }
+        } else {
+            // discard_slow (calc.rs:570-637) fold state of the current draw entry, per turn
+            float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
+            int max_value = INT_MIN, max_key = sp_discard_key(T_UNK), buf = 0;
+            for (int c0 = 0; c0 < n_ch; c0 += SP_CH) {
+                if (c0 > 0) {  // more than SP_CH children: fetch the next batch now (two dependent round trips)
+#pragma unroll
+                    for (int q = 0; q < SP_CH; q++) cur.ent[q] = Wg->pool[min((int)child_off + c0 + q, SP_POOL - 1)];
+#pragma unroll
+                    for (int q = 0; q < SP_CH; q++) {
+                        const SP_HBM float* src = Wg->node[SP_ENT_SLOT(cur.ent[q])].val[ln];
+                        const bool ok = c0 + q < n_ch && !(cur.ent[q] & SP_ENT_INVALID);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[q][k] = ok ? src[k] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SP_CH; q++) {
+                    if (c0 + q >= n_ch) break;
+                    const u32 e = cur.ent[q];
+                    if (e & SP_ENT_INVALID) {
+                        X->overflow = 1;
+                    } else {
+                        const int value = __float_as_int(v[q][3]);  // `as i32` of the child's EV (maximize_win_prob = false)
+                        const int key = (int)SP_ENT_KEY(e);       // cmp_discard_priority(dt, max_tile) > 0  <=>  key > max_key
+                        if (value > max_value || (value == max_value && key > max_key)) {
+                            nx_t = v[q][0];
+                            nx_w = v[q][1];
+                            nx_e = v[q][2];
+                            max_value = value;
+                            max_key = key;
+                        }
+                    }
+                    if (e & SP_ENT_LAST) {  // last child of this draw entry (uniform in the team)
+                        float* dst = nxb + (buf * (T + 1) + ln) * 4;
+                        dst[0] = nx_t; dst[1] = nx_w; dst[2] = nx_e; dst[3] = 0.f;
+                        mj_team_sync_n(T);
+                        accumulate(min(max((int)SP_ENT_COUNT(e), 1), 4), buf, 0.f, 0.f, 0.f, 0.f);
+                        buf ^= 1;
+                        nx_t = nx_w = nx_e = -3.40282347e+38f;
+                        max_value = INT_MIN;
+                        max_key = sp_discard_key(T_UNK);
+                    }
                 }
             }
         }
+        SP_HBM float* dst = node.val[ln];
+        dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
+        cur = nxt;
+        nxt = nn;
     }
-    SP_HBM float* dst = node.val[ln];
-    dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
 }
 
 MJD int f32_total_cmp(float a, float b) {
@@ -826,11 +910,11 @@ MJD int f32_total_cmp(float a, float b) {
     return (x > y) - (x < y);
 }
 
-__global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
+__global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
-    __shared__ TableOne st;
     __shared__ int s_row;
     __shared__ union SpTeams {
+        TableOne st;                                 // the decision's table record: read during the row set-up only
         SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
         float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
         struct {                 // row set-up (candidates + their required tiles), before any team runs
@@ -861,12 +945,12 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
         long long t_0 = wall_clock64(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0;
         {
             const float4* src = reinterpret_cast<const float4*>(P.snap + table);
-            float4* d4 = reinterpret_cast<float4*>(&st);
+            float4* d4 = reinterpret_cast<float4*>(&s_tm.st);
             for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += SP_THREADS) d4[i] = src[i];
         }
         __syncthreads();
         LaneT<TableOne> L;
-        L.B = &st;
+        L.B = &s_tm.st;
         L.l = 0;
         L.T = &c_mj_tables;
         float* out = P.obs + (size_t)row * (1012 * 34);
@@ -978,6 +1062,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
             X.n_pool = 0;
             X.overflow = 0;
             X.prof = P.prof;
+            for (int k = 0; k < 8; k++) X.pt[k] = 0;
             X.n_cand = 0;
             for (int l = 0; l < 5; l++) X.lvl_begin[l] = X.lvl_end[l] = 0;
         }
@@ -1114,7 +1199,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                     SpState s = root;
                     if (can_discard) sp_discard(s, X.cand_tile[c]);
                     bool fresh;
-                    int slot = sp_insert(W, &X, s, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), fresh);
+                    int slot = sp_insert(W, &X, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), s, -1, -1, fresh);
                     X.cand_slot[c] = slot;
                     if (fresh && slot >= 0) W->list[X.n_list++] = (u32)slot;
                 }
@@ -1153,22 +1238,19 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                     const int wl = tid & 63, tpw = 64 / T, tw = wl / T, ln = wl - tw * T;
                     const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
                     float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
-                    if (tw < tpw) {
-                        for (int i = b + team; i < e; i += n_teams) {
-                            const int slot = (int)W->list[i];
-                            if (T <= 8) {
-                                if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, slot, ln);
-                                else if (lv == 1) sp_eval_team<8, 1>(W, &X, lds, slot, ln);
-                                else sp_eval_team<8, 2>(W, &X, lds, slot, ln);
-                            } else if (T <= 16) {
-                                if (lv == 0) sp_eval_team<16, 0>(W, &X, lds, slot, ln);
-                                else if (lv == 1) sp_eval_team<16, 1>(W, &X, lds, slot, ln);
-                                else sp_eval_team<16, 2>(W, &X, lds, slot, ln);
-                            } else {
-                                if (lv == 0) sp_eval_team<17, 0>(W, &X, lds, slot, ln);
-                                else if (lv == 1) sp_eval_team<17, 1>(W, &X, lds, slot, ln);
-                                else sp_eval_team<17, 2>(W, &X, lds, slot, ln);
-                            }
+                    if (tw < tpw && b + team < e) {
+                        if (T <= 8) {
+                            if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln);
+                            else if (lv == 1) sp_eval_team<8, 1>(W, &X, lds, b + team, e, n_teams, ln);
+                            else sp_eval_team<8, 2>(W, &X, lds, b + team, e, n_teams, ln);
+                        } else if (T <= 16) {
+                            if (lv == 0) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln);
+                            else if (lv == 1) sp_eval_team<16, 1>(W, &X, lds, b + team, e, n_teams, ln);
+                            else sp_eval_team<16, 2>(W, &X, lds, b + team, e, n_teams, ln);
+                        } else {
+                            if (lv == 0) sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln);
+                            else if (lv == 1) sp_eval_team<17, 1>(W, &X, lds, b + team, e, n_teams, ln);
+                            else sp_eval_team<17, 2>(W, &X, lds, b + team, e, n_teams, ln);
                         }
                     }
                 }
@@ -1303,6 +1385,10 @@ __global__ __launch_bounds__(SP_THREADS, 4) void mj_k_sp(SpParams P) {
                 atomicAdd(&P.err[5], (unsigned long long)(t_4 - t_3));
                 atomicAdd(&P.err[6], (unsigned long long)(t_5 - t_4));
                 atomicAdd(&P.err[7], (unsigned long long)X.n_list);
+                if (P.prof)
+                    for (int k = 0; k < 7; k++) atomicAdd(&P.err[8 + k], X.pt[k]);  // expansion pass timers (MJ_SP_PROF)
+                atomicAdd(&P.err[15], (unsigned long long)X.n_pool);   // child-list entries (edges of the state graph)
+                atomicAdd(&P.err[16], (unsigned long long)X.n_items);  // level-0 draw entries scored
             }
         }
         // ---- reset the hash set for the next row
