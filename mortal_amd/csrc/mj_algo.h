@@ -134,6 +134,8 @@ struct Hand {
     }
     // yaokyuu tiles as field masks: 1m 9m 1p 9p (mp fields 0 8 9 17), 1s 9s + honours (sz fields 0 8 9..15)
     static constexpr u64 YAO_MP = 0x0008000009000001ull, YAO_SZ = 0x0000249249000001ull;
+    static MJD int sum_fields(u64 x) { return __popcll(x & LSB3) + 2 * __popcll((x >> 1) & LSB3) + 4 * __popcll((x >> 2) & LSB3); }
+    MJD int total() const { return sum_fields(mp) + sum_fields(sz); }  // number of tiles
     MJD int n_kinds() const { return __popcll(nz_fields(mp)) + __popcll(nz_fields(sz)); }
     MJD int n_pairs() const { return __popcll(ge2_fields(mp)) + __popcll(ge2_fields(sz)); }
     MJD int n_yao_kinds() const { return __popcll(nz_fields(mp) & YAO_MP) + __popcll(nz_fields(sz) & YAO_SZ); }

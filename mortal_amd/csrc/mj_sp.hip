@@ -277,38 +277,51 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
     const int fu = a.fu, han = a.han & 0xFF;
     const bool assume_riichi = X->is_menzen && X->prefer_riichi;
     if (assume_riichi && X->n_dora == 1) {
-        int n_ind[5] = {0, 0, 0, 0, 0}, sum_ind = 0;
-        for (int t = 0; t < 34; t++) {
-            int c = s.h.get(t);
-            if (c == 0) continue;
-            int ic = s.w.get(tile_prev(t));
-            n_ind[c] = (n_ind[c] + ic) & 0xFF;
-            sum_ind = (sum_ind + ic) & 0xFF;
+        // indicator tiles left in the wall per number of copies in the hand (scalars: a dynamically indexed local array
+        // would live in scratch), over the hand's tile kinds only
+        int n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+        for (u64 m = s.h.nonzero_mask(); m; m &= m - 1) {
+            const int t = __ffsll((long long)m) - 1, c = s.h.get(t), ic = s.w.get(tile_prev(t));
+            n1 += c == 1 ? ic : 0;
+            n2 += c == 2 ? ic : 0;
+            n3 += c == 3 ? ic : 0;
+            n4 += c == 4 ? ic : 0;
         }
-        int n_left = 0;
-        for (int t = 0; t < 34; t++) n_left += s.w.get(t);
-        n_left &= 0xFF;
+        n1 &= 0xFF; n2 &= 0xFF; n3 &= 0xFF; n4 &= 0xFF;
+        const int sum_ind = (n1 + n2 + n3 + n4) & 0xFF;
+        const int n_left = s.w.total() & 0xFF;
         float up[5];
         up[0] = (float)((n_left - sum_ind) & 0xFF) / (float)n_left;
-        for (int i = 1; i < 5; i++) up[i] = (float)n_ind[i] / (float)n_left;
+        up[1] = (float)n1 / (float)n_left;
+        up[2] = (float)n2 / (float)n_left;
+        up[3] = (float)n3 / (float)n_left;
+        up[4] = (float)n4 / (float)n_left;
+        float pt[8];  // the points of han + k, k = i + j: 8 values instead of 20 evaluations (static indices: registers)
+#pragma unroll
+        for (int k = 0; k < 8; k++) pt[k] = (float)tsumo_total(point_calc(is_oya, fu, (han + k) & 0xFF), is_oya);
+#pragma unroll
         for (int i = 0; i < 4; i++) {
             float sc = 0.f;
+#pragma unroll
             for (int j = 0; j < 5; j++) {
-                float p = up[j];
-                if (p == 0.f) continue;
-                float pt = (float)tsumo_total(point_calc(is_oya, fu, (han + i + j) & 0xFF), is_oya);
-                sc += pt * p;
+                if (up[j] == 0.f) continue;
+                sc += pt[i + j] * up[j];
             }
             scores[i] = sc;
         }
     } else if (assume_riichi && X->n_dora > 1) {
+        float pt[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) pt[k] = (float)tsumo_total(point_calc(is_oya, fu, (han + k) & 0xFF), is_oya);
+        const float* ur = SP_URADORA[X->n_dora - 1];
+#pragma unroll
         for (int i = 0; i < 4; i++) {
             float sc = 0.f;
+#pragma unroll
             for (int j = 0; j < 13; j++) {
-                float p = SP_URADORA[X->n_dora - 1][j];
+                const float p = ur[j];
                 if (p == 0.f) continue;
-                float pt = (float)tsumo_total(point_calc(is_oya, fu, (han + i + j) & 0xFF), is_oya);
-                sc += pt * p;
+                sc += pt[i + j] * p;
             }
             scores[i] = sc;
         }
@@ -1229,9 +1242,14 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
                     for (int c0 = b + SP_NS * (tid / SP_NT); c0 < e; c0 += SP_NS * (SP_THREADS / SP_NT))
                         sp_l0_probe_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(SP_NS, e - c0));
                     __syncthreads();
+                    const long long t_2a = wall_clock64();
                     const int n_items = min(X.n_items, SP_ITEMS);
                     for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
                     __syncthreads();
+                    if (P.prof && tid == 0) {  // level-0 sub-phases: probe, scoring (the sum is the rest of the level-0 timer)
+                        X.pt[7] += (unsigned long long)(t_2a - t_2);
+                        atomicAdd(&P.err[18], (unsigned long long)(wall_clock64() - t_2a));
+                    }
                 }
                 {
                     // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
@@ -1331,45 +1349,50 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
             // sp table (obs_repr.rs:644-692)
             const float ev_scale = max_ev < 1.f ? 0.f : 1.f / max_ev;
             bool table_ok = with_probs && first >= 0 && X.cand_tp0[first] > 0.f;
-            if (table_ok) {
-                if (can_discard0) {
-                    for (int c = tid / SP_T; c < n_cand; c += SP_THREADS / SP_T) {
-                        if (tid >= (SP_THREADS / SP_T) * SP_T) break;
-                        const int turn = tid % SP_T;
-                        if (turn >= T) continue;
-                        const SpNode& nd = W->node[X.cand_slot[c]];
-                        // take_while(p > 0) on the clamped tenpai probs
-                        bool alive = true;
-                        for (int q = 0; q <= turn && alive; q++) {
-                            float tpq = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[q][0], 0.f), 1.f);
-                            alive = tpq > 0.f;
+            if (table_ok) {  // uniform over the workgroup
+                // one load per (candidate, turn): the clamped values go to the LDS (the evaluation scratch is free now), and
+                // take_while(p > 0) on the tenpai probs becomes an AND over the lower turns' flags (instead of a chain of up to
+                // 17 dependent loads per thread)
+                float* tv = s_tm.ev;  // [candidate slot * SP_T + turn][4]: tenpai, win, ev, alive
+                static_assert(SP_EVAL_LDS_FLOATS >= (SP_THREADS / SP_T) * SP_T * 4, "table staging fits the evaluation scratch");
+                const int n_src = can_discard0 ? n_cand : 1;
+                {
+                    const int c = tid / SP_T, turn = tid % SP_T;
+                    if (c < n_src && c < SP_THREADS / SP_T) {
+                        float tpv = 0.f, wpv = 0.f, evv = 0.f;
+                        if (turn < T) {
+                            const SpNode& nd = W->node[X.cand_slot[can_discard0 ? c : first]];
+                            tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[turn][0], 0.f), 1.f);
+                            wpv = fminf(fmaxf(nd.val[turn][1], 0.f), 1.f);
+                            evv = fmaxf(nd.val[turn][2], 0.f);
                         }
-                        if (!alive) continue;
+                        float* dst = tv + (c * SP_T + turn) * 4;
+                        dst[0] = tpv; dst[1] = wpv; dst[2] = fminf(evv * ev_scale, 1.f); dst[3] = tpv > 0.f ? 1.f : 0.f;
+                    }
+                }
+                __syncthreads();
+                auto alive_upto = [&](int c, int turn) {
+                    bool alive = true;
+                    for (int q = 0; q <= turn; q++) alive = alive && tv[(c * SP_T + q) * 4 + 3] != 0.f;
+                    return alive;
+                };
+                if (can_discard0) {
+                    const int c = tid / SP_T, turn = tid % SP_T;
+                    if (c < n_cand && c < SP_THREADS / SP_T && turn < T && alive_upto(c, turn)) {
                         const int col = after_riichi ? deaka(last_tsumo) : deaka(X.cand_tile[c]);
-                        float tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[turn][0], 0.f), 1.f);
-                        float wpv = fminf(fmaxf(nd.val[turn][1], 0.f), 1.f);
-                        float evv = fmaxf(nd.val[turn][2], 0.f);
-                        out[(O_SP + 72 + turn) * 34 + col] = tpv;
-                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = wpv;
-                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = fminf(evv * ev_scale, 1.f);
+                        const float* src = tv + (c * SP_T + turn) * 4;
+                        out[(O_SP + 72 + turn) * 34 + col] = src[0];
+                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
+                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
                     }
                 } else {
-                    const SpNode& nd = W->node[X.cand_slot[first]];
                     for (int w = tid; w < SP_T * 34; w += SP_THREADS) {
                         const int turn = w / 34, col = w % 34;
-                        if (turn >= T) continue;
-                        bool alive = true;
-                        for (int q = 0; q <= turn && alive; q++) {
-                            float tpq = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[q][0], 0.f), 1.f);
-                            alive = tpq > 0.f;
-                        }
-                        if (!alive) continue;
-                        float tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[turn][0], 0.f), 1.f);
-                        float wpv = fminf(fmaxf(nd.val[turn][1], 0.f), 1.f);
-                        float evv = fmaxf(nd.val[turn][2], 0.f);
-                        out[(O_SP + 72 + turn) * 34 + col] = tpv;
-                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = wpv;
-                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = fminf(evv * ev_scale, 1.f);
+                        if (turn >= T || !alive_upto(0, turn)) continue;
+                        const float* src = tv + turn * 4;
+                        out[(O_SP + 72 + turn) * 34 + col] = src[0];
+                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
+                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
                     }
                 }
             }
@@ -1387,6 +1410,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
                 atomicAdd(&P.err[7], (unsigned long long)X.n_list);
                 if (P.prof)
                     for (int k = 0; k < 7; k++) atomicAdd(&P.err[8 + k], X.pt[k]);  // expansion pass timers (MJ_SP_PROF)
+                if (P.prof) atomicAdd(&P.err[17], X.pt[7]);                          // level-0 probe
                 atomicAdd(&P.err[15], (unsigned long long)X.n_pool);   // child-list entries (edges of the state graph)
                 atomicAdd(&P.err[16], (unsigned long long)X.n_items);  // level-0 draw entries scored
             }
