@@ -228,6 +228,7 @@ def main():
                          "device (hands at 0..3 shanten: realistic SP load); brain = greedy argmax of a random-init network of "
                          "the reference's Brain/DQN architecture (192 ch x 40 blocks, bf16 autocast), consuming the encoded "
                          "batch in place (BASELINE configs[2])")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for --gpus N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true", help="skip the extra workloads (obs v3, no pre-roll, greedy policy)")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
@@ -243,12 +244,19 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # one rank per GPU over RCCL ("nccl"); `--dist-backend gloo` + fewer GPUs than ranks is the smoke test of this code path
+    # on a single-GPU box (ranks share device 0, the three small collectives go through host tensors)
+    dev_idx = local_rank % max(1, torch.cuda.device_count())
+    red_dev = torch.device(f"cuda:{dev_idx}") if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_idx}"))
+        else:
+            dist.init_process_group(args.dist_backend)
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device(f"cuda:{dev_idx}")
 
     from mortal_amd.pool import TablePool, default_deal_algo
 
@@ -274,15 +282,15 @@ def main():
     enc_ms, enc_launches, sp_ms, sp_launches, C = r["enc_ms"], r["enc_launches"], r["sp_ms"], r["sp_launches"], r["C"]
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([steps, games, rows_timed], dtype=torch.float64, device=dev)
+        s = torch.tensor([steps, games, rows_timed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         steps, games, rows_all = (float(x) for x in s.tolist())
         # the single collective of the data path: gather of episode returns (final scores of finished games)
         sc, dn = r["results"]
-        ret = torch.from_numpy(sc).to(dev)
+        ret = torch.from_numpy(sc).to(red_dev)
         out = [torch.empty_like(ret) for _ in range(world)] if rank == 0 else None
         dist.gather(ret, out, dst=0)
     else:
