@@ -63,3 +63,47 @@ def test_emu_invisible_obs(oracle, emu):
     st = parity_util.run_lockstep(oracle, 2, version=3, max_cycles=200, obs_every=2, compare_obs=False, pool_cls=emu,
                                   policy="greedy", oracle_obs=True, verbose=False)
     assert st["oracle_obs_checked"] > 150
+
+
+def test_emu_device_engine_sampling_logs_and_stat(oracle, emu, tmp_path):
+    """The arena end to end on the emulated kernels with a `react_batch_device` engine that explores (Boltzmann-epsilon /
+    top-p on the device path) and returns (actions, q_values, is_greedy): logs are written with the reference's per-decision
+    `meta` objects (is_greedy False on explored decisions), `Stat.from_dir` reads them back, never an illegal action."""
+    import gzip
+    import json
+
+    import torch
+    from libriichi.arena import OneVsThree
+    from libriichi.stat import Stat
+
+    from mortal_amd import arena as A
+    from mortal_amd.policy import DeviceEngine, PolicyNet
+
+    def engine(seed, name, eps):
+        torch.manual_seed(seed)
+        return DeviceEngine(PolicyNet(version=3, conv_channels=16, num_blocks=1), 3, "cpu", name=name, enable_amp=False,
+                            boltzmann_epsilon=eps, boltzmann_temp=1.0, top_p=0.9, return_meta=True, seed=seed)
+
+    old = A.BatchRunner.pool_cls
+    A.BatchRunner.pool_cls = emu
+    try:
+        d = str(tmp_path / "logs")
+        got = OneVsThree(disable_progress_bar=True, log_dir=d).py_vs_py(challenger=engine(1, "challenger", 0.3),
+                                                                        champion=engine(2, "champion", 0.0),
+                                                                        seed_start=(10000, 0xD5DFAA4CEF265CD7), seed_count=1)
+    finally:
+        A.BatchRunner.pool_cls = old
+    assert sum(got) == 4
+    st = Stat.from_dir(d, "challenger", True)
+    assert st.game == 4 and [st.rank_1, st.rank_2, st.rank_3, st.rank_4] == got
+    n_meta = n_explored = 0
+    for f in sorted(os.listdir(d)):
+        for line in gzip.open(os.path.join(d, f), "rt"):
+            ev = json.loads(line)
+            meta = ev.get("meta")
+            if meta is None:
+                continue
+            n_meta += 1
+            assert len(meta["q_values"]) == bin(meta["mask_bits"]).count("1") and "shanten" in meta and "batch_size" in meta
+            n_explored += not meta["is_greedy"]
+    assert n_meta > 500 and 0 < n_explored < n_meta
