@@ -29,7 +29,9 @@
 #define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
+#ifndef SP_NS
 #define SP_NS 8                // states per expansion chunk (one chunk per wavefront)
+#endif
 #ifndef SP_WGS
 #define SP_WGS 4               // resident workgroups per CU the kernel is compiled for (register budget 512 / SP_WGS per lane)
 #endif
@@ -390,7 +392,7 @@ constexpr bool sp_item_div_is_exact() {  // (local * ceil(65536 / nk)) >> 16 == 
     return true;
 }
 static_assert(sp_item_div_is_exact(), "item index reciprocal");
-static_assert(SP_NS <= 8, "queue entries hold the state in 3 bits");
+static_assert(SP_NS <= 16, "queue entries hold the state in 4 bits");
 
 MJD SpState sp_chunk_state(const SpChunk* C, int s) {
     SpState S;
@@ -681,7 +683,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
                 kept = C->tiles[s][ti] != C->kinds[s][ki] && ((sp_chunk_keep(C, s, ti) >> ki) & 1);
             }
             const unsigned long long m = __ballot(kept);
-            if (kept) C->queue[(q_head + q_n + __popcll(m & ((1ull << tid) - 1))) & 127] = (unsigned short)(s | (ti << 3) | (ki << 9));
+            if (kept) C->queue[(q_head + q_n + __popcll(m & ((1ull << tid) - 1))) & 127] = (unsigned short)(s | (ti << 4) | (ki << 10));
             q_n += __popcll(m);
             mj_team_sync<SP_NT>();
         }
@@ -689,7 +691,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             const int take = min(q_n, SP_NT);
             if (tid < take) {
                 const int e = C->queue[(q_head + tid) & 127];
-                insert_children(e & 7, (e >> 3) & 63, (e >> 9) & 15);
+                insert_children(e & 15, (e >> 4) & 63, (e >> 10) & 15);
             }
             q_head = (q_head + take) & 127;
             q_n -= take;
