@@ -173,3 +173,56 @@ def test_log_meta_objects(oracle, tmp_path):
                     sn = p.snapshot()
                     at_decision[a] = (p.encode_obs(3, False)[1], sn["shanten"], sn["at_furiten"])
     assert n_meta > 500
+
+
+def test_mjai_log_engine_on_device(oracle):
+    """engine_type 'mjai-log' on the real device: explicit mjai reactions through mj_step_ev, GameState / callbacks — the same
+    scenario tests/test_mjai_log_agent.py runs on the emulator (ExampleMjaiLogEngine vs a lowest-legal 'mortal' engine)."""
+    import test_mjai_log_agent as T
+    from libriichi.arena import OneVsThree, TwoVsTwo
+
+    from mortal_amd.pool import default_deal_algo
+
+    eng = T._example_engine_cls()("logger")
+    got = OneVsThree(disable_progress_bar=True).py_vs_py(challenger=eng, champion=T._Lowest(), seed_start=(10000, KEY), seed_count=2)
+    sc = T._oracle_scores(oracle, [(10000 + g // 4, KEY) for g in range(8)], lambda g, s: s == g % 4, default_deal_algo())
+    want = [0, 0, 0, 0]
+    for g in range(8):
+        order = sorted(range(4), key=lambda i: -int(sc[g][i]))
+        want[order.index(g % 4)] += 1
+    assert got == want and eng.player_ids == [0, 1, 2, 3] * 2
+    env = TwoVsTwo(disable_progress_bar=True)
+    env.py_vs_py(challenger=T._example_engine_cls()("logger"), champion=T._Lowest(), seed_start=(20000, KEY), seed_count=2)
+    sc = T._oracle_scores(oracle, [(20000 + g // 2, KEY) for g in range(4)], lambda g, s: (s % 2 == 0) == (g % 2 == 0), default_deal_algo())
+    assert (env.last_scores == sc).all()
+
+
+def test_device_engine_exploration_meta_on_device(oracle, tmp_path):
+    """react_batch_device with Boltzmann-epsilon / top-p sampling on the GPU, q-values and is_greedy flowing into the log meta."""
+    import gzip
+    import json
+    import os
+
+    import torch
+    from libriichi.arena import OneVsThree
+
+    from mortal_amd.policy import DeviceEngine, PolicyNet
+
+    def engine(seed, name, eps):
+        torch.manual_seed(seed)
+        return DeviceEngine(PolicyNet(version=4, conv_channels=32, num_blocks=2), 4, "cuda:0", name=name, enable_amp=False,
+                            boltzmann_epsilon=eps, top_p=0.9, return_meta=True, seed=seed)
+
+    d = str(tmp_path / "logs")
+    got = OneVsThree(disable_progress_bar=True, log_dir=d).py_vs_py(challenger=engine(1, "challenger", 0.25), champion=engine(2, "champion", 0.0),
+                                                                    seed_start=(10000, KEY), seed_count=2)
+    assert sum(got) == 8
+    n_meta = n_explored = 0
+    for f in sorted(os.listdir(d)):
+        for line in gzip.open(os.path.join(d, f), "rt"):
+            meta = json.loads(line).get("meta")
+            if meta:
+                n_meta += 1
+                n_explored += not meta["is_greedy"]
+                assert len(meta["q_values"]) == bin(meta["mask_bits"]).count("1")
+    assert n_meta > 1000 and 0 < n_explored < n_meta / 2
