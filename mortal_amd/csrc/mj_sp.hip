@@ -45,7 +45,7 @@ struct SpNode {                 // one 3n+1 state (608 bytes, 16-byte aligned ro
     float sc[SP_L0_MAX][4];     // level 0: get_score() of every draw entry (sp_l0_score)
     u32 child_off;              // level > 0: first pool entry of the child list; level 0: bit e = draw entry e has a yaku
     unsigned short n_ch;        // level > 0: number of pool entries; level 0: number of draw entries
-    u8 sumreq, pad_;            // sum over the required tiles of their wall counts (row of the not_tsumo table)
+    u8 sumreq, n_ent;           // sum over the required tiles of their wall counts (row of the not_tsumo table); draw entries
     u8 l0cnt[SP_L0_MAX + 3];    // level 0: copies left in the wall of every draw entry (its tsumo_prob row)
 };
 static_assert(sizeof(SpNode) == 608 && offsetof(SpNode, val) % 16 == 0 && offsetof(SpNode, sc) % 16 == 0, "SpNode layout");
@@ -62,6 +62,7 @@ struct SpWork {                // per-workgroup scratch in HBM (persistent workg
     u64 tag[SP_CAP];           // 0 = empty, else state id | 1 << 63
     SpNode node[SP_CAP];
     u32 list[SP_CAP];          // slots grouped by level: level L occupies [lvl_begin[L], lvl_end[L])
+    u32 elist[SP_CAP];         // the same ranges ordered by child-list length for the evaluation (sp_sort_level)
     u32 pool[SP_POOL];         // child lists
     u32 items[SP_ITEMS];       // level 0: (state, winning tile, variant) work items of the dense scoring pass
 };
@@ -525,6 +526,7 @@ __device__ __noinline__ void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
         node.child_off = 0;  // bit i: draw entry i has a yaku (set by sp_l0_score)
         node.n_ch = (unsigned short)cnt;
         node.sumreq = (u8)(sumreq & 0xFF);
+        node.n_ent = (u8)cnt;
     }
     mj_team_sync<SP_NT>();
 }
@@ -617,13 +619,15 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     if (tid < n) {
         const int s = tid;
         const SpState S = sp_chunk_state(C, s);
-        int total = 0, sumreq = 0;
+        int total = 0, sumreq = 0, n_ent = 0;
         const int nt = C->n_tiles[s];
         for (int ti = 0; ti < nt; ti++) {
             const int t = C->tiles[s][ti], wc = S.w.get(t);
             const int nvar = sp_aka_in_wall(S, t) ? (wc >= 2 ? 2 : 1) : 1;
             C->coff[s][ti] = (unsigned short)total;
-            total += nvar * __popc(sp_chunk_keep(C, s, ti));
+            const int nkeep = __popc(sp_chunk_keep(C, s, ti));
+            total += nvar * nkeep;
+            n_ent += nkeep ? nvar : 0;
             sumreq += wc;
         }
         int child_base = atomicAdd(&X->n_pool, total);
@@ -633,6 +637,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         node.child_off = (u32)child_base;
         node.n_ch = (unsigned short)total;
         node.sumreq = (u8)(sumreq & 0xFF);
+        node.n_ent = (u8)min(n_ent, 255);
     }
     mj_team_sync<SP_NT>();
     if (prof) tp4 = wall_clock64();
@@ -759,7 +764,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
     const bool haitei = X->calc_haitei != 0;
     const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
 
-    auto fetch_slot = [&](int i) -> u32 { return Wg->list[min(i, end - 1)]; };
+    auto fetch_slot = [&](int i) -> u32 { return Wg->elist[min(i, end - 1)]; };
     auto fetch_hdr = [&](u32 slot) -> u64 {
         // one 8-byte load (level 0: past the L1 — the yaku bits were set by L2 atomics of the scoring pass)
         SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off);
@@ -916,6 +921,36 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
         cur = nxt;
         nxt = nn;
     }
+}
+
+// The teams of a wavefront evaluate consecutive states of a level, and the wavefront runs as long as its slowest team: order
+// the level by child-list length (counting sort over 64 buckets, workgroup-wide) so that neighbours cost about the same (key: children + 4 x draw entries).  The
+// order of states inside a level does not touch the results (each state is evaluated on its own).
+__device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] */, int b, int e) {
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const int tid = threadIdx.x;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    auto cost_key = [&](u32 slot) {  // ~ fold work (children) + accumulate work (draw entries), longest first
+        const SP_HBM SpNode& nd = Wg->node[slot];
+        return 63 - min(((int)nd.n_ch + 4 * (int)nd.n_ent) >> 1, 63);
+    };
+    for (int i = b + tid; i < e; i += SP_THREADS) atomicAdd(&hist[cost_key(Wg->list[i])], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int off = 0;
+        for (int k = 0; k < 64; k++) {
+            const int c = hist[k];
+            hist[k] = off;
+            off += c;
+        }
+    }
+    __syncthreads();
+    for (int i = b + tid; i < e; i += SP_THREADS) {
+        const u32 slot = Wg->list[i];
+        Wg->elist[b + atomicAdd(&hist[cost_key(slot)], 1)] = slot;
+    }
+    __syncthreads();
 }
 
 MJD int f32_total_cmp(float a, float b) {
@@ -1253,6 +1288,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
                         atomicAdd(&P.err[18], (unsigned long long)(wall_clock64() - t_2a));
                     }
                 }
+                sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
                 {
                     // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
                     const int wl = tid & 63, tpw = 64 / T, tw = wl / T, ln = wl - tw * T;
