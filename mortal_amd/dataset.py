@@ -168,6 +168,8 @@ class Gameplay:
 class GameplayLoader:
     """dataset/gameplay.rs:21-165."""
 
+    pool_cls = TablePool  # the test suite substitutes the host emulation of the same kernels (tests/host/emu_pool.py)
+
     def __init__(self, version, *, oracle=True, player_names=None, excludes=None, trust_seed=False,
                  always_include_kan_select=True, augmented=False, device="cuda:0", deal_algo=None):
         if version not in OBS_ROWS:
@@ -317,7 +319,7 @@ class GameplayLoader:
                     scripts.append(mjai_log.encode_events(g["events"], augmented=self.augmented, walls=walls))
         tracked = [sum(1 << p for p in g["wanted"]) for g in games]
         total_events = sum(len(g["events"]) for g in games)
-        pool = TablePool(n, version=self.version, device=self.device, max_rows=8 * n + 64, deal_algo=self.deal_algo)
+        pool = self.pool_cls(n, version=self.version, device=self.device, max_rows=8 * n + 64, deal_algo=self.deal_algo)
         try:
             pool.replay_load(scripts, tracked, self.always_include_kan_select, nonces, keys)
             obs_parts, mask_parts, meta_parts, inv_parts = [], [], [], []

@@ -41,11 +41,13 @@ class ActionCandidate:
 
 
 class PlayerState:
+    pool_cls = TablePool  # the test suite substitutes the host emulation of the same kernels (tests/host/emu_pool.py)
+
     def __init__(self, player_id, device="cuda:0"):
         if not 0 <= int(player_id) <= 3:
             raise ValueError("player_id must be within 0..3")
         self.player_id = int(player_id)
-        self._pool = TablePool(1, version=4, device=device)
+        self._pool = self.pool_cls(1, version=4, device=device)
         self._pool.reset([(0, 0)])
         self._tbl = 0
         self._owns = True
@@ -82,7 +84,7 @@ class PlayerState:
             ev = {"type": "end_kyoku"}  # same effect on a PlayerState: only the per-event reset of last_cans
         words = mjai_log.encode_events([ev])
         self._need_pool()
-        check(lib.mj_table_apply_event(self._pool.h, 0, words.ctypes.data, len(words), _stream()))
+        check(self._pool._L.mj_table_apply_event(self._pool.h, 0, words.ctypes.data, len(words), self._pool._stream()))
         self._cache = None
         code, _ = self._pool.first_error()
         if code:
@@ -180,7 +182,7 @@ class PlayerState:
         a = np.zeros(8, dtype=np.int32)
         a[:len(args)] = args
         out = np.zeros(8, dtype=np.int32)
-        check(lib.mj_table_query(self._pool.h, 0, self.player_id, what, a.ctypes.data, out.ctypes.data, _stream()))
+        check(self._pool._L.mj_table_query(self._pool.h, 0, self.player_id, what, a.ctypes.data, out.ctypes.data, self._pool._stream()))
         self._cache = None
         return out
 
@@ -188,11 +190,11 @@ class PlayerState:
     def encode_obs(self, version, at_kan_select):
         self._need_pool()
         self._pool.configure(0, version=int(version))
-        check(lib.mj_table_mark_row(self._pool.h, 0, self.player_id, int(bool(at_kan_select)), _stream()))
+        check(self._pool._L.mj_table_mark_row(self._pool.h, 0, self.player_id, int(bool(at_kan_select)), self._pool._stream()))
         import ctypes as C
 
         out = (C.c_int32 * 2)()
-        check(lib.mj_rows_count(self._pool.h, out, _stream()))
+        check(self._pool._L.mj_rows_count(self._pool.h, out, self._pool._stream()))
         self._pool.n_rows = [out[0], out[1]]
         obs, masks = self._pool.encode(0)
         return obs[0].cpu().numpy(), masks[0].cpu().numpy()

@@ -52,12 +52,17 @@ def _oracle_logs(oracle, n, policy, start):
 def test_gameplay_loader_matches_reference_restatement(oracle, version, always_kan, augmented):
     """Every sample of every wanted player: obs and mask bit-exact, label / kyoku index / turn / shanten / gamma / done
     equal to the reference loader restated on the oracle (tests/dataset_ref.py)."""
+    n_samples, n_kan = check_loader(oracle, version, always_kan, augmented, 6 if version == 4 else 12, 3)
+    assert n_samples > 1500 and n_kan > 0
+
+
+def check_loader(oracle, version, always_kan, augmented, n_greedy, n_random):
+    """Shared by the GPU test above and the host-emulator test (tests/test_emu_device_code.py)."""
     import dataset_ref
     from libriichi.dataset import GameplayLoader
     from mortal_amd import mjai_log
 
-    n = 6 if version == 4 else 12
-    logs = [open(GOLDEN).read()] + _oracle_logs(oracle, n, "greedy", 4242) + _oracle_logs(oracle, 3, "random", 99)
+    logs = [open(GOLDEN).read()] + _oracle_logs(oracle, n_greedy, "greedy", 4242) + _oracle_logs(oracle, n_random, "random", 99)
     loader = GameplayLoader(version, oracle=False, always_include_kan_select=always_kan, augmented=augmented,
                             player_names=["a", "mortal"])
     got = loader.load_logs(logs)
@@ -88,7 +93,7 @@ def test_gameplay_loader_matches_reference_restatement(oracle, version, always_k
             n_kan += sum(1 for a in ref["actions"] if a == 42)
             grp = g.take_grp()
             assert grp.take_feature().shape[1] == 7
-    assert n_samples > 1500 and n_kan > 0
+    return n_samples, n_kan
 
 
 @pytest.mark.gpu
@@ -97,10 +102,14 @@ def test_gameplay_loader_invisible_obs(oracle, version):
     """oracle=True: with trust_seed the wall is rebuilt from the game seed on the device and every invisible obs equals
     dataset/invisible.rs restated on the oracle; without it the opponents' planes still match and the wall planes hold
     the right number of tiles (the never-seen tiles are a random fill in the reference too)."""
+    assert check_invisible(oracle, version, 5) > 500
+
+
+def check_invisible(oracle, version, n_logs):
     import dataset_ref
     from libriichi.dataset import GameplayLoader
 
-    logs = _oracle_logs(oracle, 5, "greedy", 31337)
+    logs = _oracle_logs(oracle, n_logs, "greedy", 31337)
     names = ["a", "c"]
     trusted = GameplayLoader(version, oracle=True, trust_seed=True, player_names=names).load_logs(logs)
     blind = GameplayLoader(version, oracle=True, trust_seed=False, player_names=names).load_logs(logs)
@@ -117,4 +126,4 @@ def test_gameplay_loader_invisible_obs(oracle, version):
                 assert (inv_b[k][:opp_rows] == ref[k][:opp_rows]).all()
                 assert inv_b[k][opp_rows:].sum(axis=1)[::2].sum() == ref[k][opp_rows:].sum(axis=1)[::2].sum()
             n += len(ref)
-    assert n > 500
+    return n

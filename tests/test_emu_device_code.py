@@ -107,3 +107,45 @@ def test_emu_device_engine_sampling_logs_and_stat(oracle, emu, tmp_path):
             assert len(meta["q_values"]) == bin(meta["mask_bits"]).count("1") and "shanten" in meta and "batch_size" in meta
             n_explored += not meta["is_greedy"]
     assert n_meta > 500 and 0 < n_explored < n_meta
+
+
+def test_emu_dataset_loader(oracle, emu):
+    """libriichi.dataset.GameplayLoader on the emulated kernels (mj_k_replay + labels + encode, suit augmentation, and the
+    invisible obs with the wall rebuilt from the seed — the logs come from an oracle arena dealing with the OTHER rand
+    generation than the pool's default, so the replay's shuffle fallback runs too): the GPU tests of tests/test_dataset.py at
+    a reduced size."""
+    import test_dataset as TD
+    from mortal_amd.dataset import GameplayLoader
+
+    old = GameplayLoader.pool_cls
+    GameplayLoader.pool_cls = emu
+    try:
+        n_samples, _ = TD.check_loader(oracle, 3, True, False, 1, 1)
+        assert n_samples > 150
+        n_samples, _ = TD.check_loader(oracle, 2, True, True, 1, 0)
+        assert n_samples > 80
+        assert TD.check_invisible(oracle, 4, 1) > 60
+    finally:
+        GameplayLoader.pool_cls = old
+
+
+def test_emu_reference_state_scenarios_and_bot(oracle, emu):
+    """tests/test_gpu_state.py on the emulated kernels: the reference's own state/test.rs scenarios applied to the device event
+    handlers (mj_table_apply_event), single-table encode_obs of all four versions, validate_reaction, libriichi.mjai.Bot and
+    the reference's encode-obs benchmark kyoku for every seat."""
+    import test_gpu_state as G
+
+    from mortal_amd.state import PlayerState
+
+    old = PlayerState.pool_cls
+    PlayerState.pool_cls = emu
+    try:
+        for name in G.EVENT_DRIVEN:
+            G.test_reference_state_scenario_on_device(name)
+        G.test_device_player_state_obs_matches_oracle(oracle)
+        G.test_device_player_state_validate_reaction(oracle)
+        G.test_bot_replays_a_game_like_the_oracle_agent(oracle)
+        for pid in range(4):
+            G.test_reference_bench_kyoku_obs_device_vs_oracle(oracle, pid)
+    finally:
+        PlayerState.pool_cls = old
