@@ -1244,15 +1244,17 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
         t_2 = t_3 = t_4 = t_1;
         if (with_probs) {
             // root states = level cur_shanten
+            if (tid < n_cand) {  // one lane per candidate: the claims (one L2 atomic round trip each) run side by side
+                const int c = tid;
+                SpState s = root;
+                if (can_discard) sp_discard(s, X.cand_tile[c]);
+                bool fresh;
+                const int slot = sp_insert(W, &X, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), s, -1, -1, fresh);
+                X.cand_slot[c] = slot;
+                if (fresh && slot >= 0) W->list[atomicAdd(&X.n_list, 1)] = (u32)slot;
+            }
+            __syncthreads();
             if (tid == 0) {
-                for (int c = 0; c < n_cand; c++) {
-                    SpState s = root;
-                    if (can_discard) sp_discard(s, X.cand_tile[c]);
-                    bool fresh;
-                    int slot = sp_insert(W, &X, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), s, -1, -1, fresh);
-                    X.cand_slot[c] = slot;
-                    if (fresh && slot >= 0) W->list[X.n_list++] = (u32)slot;
-                }
                 X.lvl_begin[cur_shanten] = 0;
                 X.lvl_end[cur_shanten] = X.n_list;
             }
@@ -1317,18 +1319,20 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
         }
 
         // ---- sort (calc.rs:181-188 / 196-199) + encode (obs_repr.rs:564-692)
-        if (tid == 0) {
-            for (int c = 0; c < n_cand; c++) {
-                X.order[c] = c;
-                int slot = X.cand_slot[c];
-                if (with_probs && slot >= 0) {  // Candidate::from clamps (candidate.rs:46-70); shanten 0 => tenpai = 1
-                    const SpNode& nd = W->node[slot];
-                    float tp = cur_shanten == 0 ? 1.f : nd.val[0][0];
-                    X.cand_tp0[c] = fminf(fmaxf(tp, 0.f), 1.f);
-                    X.cand_wp0[c] = fminf(fmaxf(nd.val[0][1], 0.f), 1.f);
-                    X.cand_ev0[c] = fmaxf(nd.val[0][2], 0.f);
-                }
+        if (tid < n_cand) {  // one lane per candidate fetches its turn-0 values (side by side, not a chain of dependent loads)
+            const int c = tid;
+            X.order[c] = c;
+            const int slot = X.cand_slot[c];
+            if (with_probs && slot >= 0) {  // Candidate::from clamps (candidate.rs:46-70); shanten 0 => tenpai = 1
+                const SpNode& nd = W->node[slot];
+                const float tp = cur_shanten == 0 ? 1.f : nd.val[0][0];
+                X.cand_tp0[c] = fminf(fmaxf(tp, 0.f), 1.f);
+                X.cand_wp0[c] = fminf(fmaxf(nd.val[0][1], 0.f), 1.f);
+                X.cand_ev0[c] = fmaxf(nd.val[0][2], 0.f);
             }
+        }
+        __syncthreads();
+        if (tid == 0) {
             auto cmp = [&](int l, int r, int by) -> int {  // candidate.rs:73-106, by: 0 EV, 3 NotShantenDown
                 if (X.cand_tile[l] == X.cand_tile[r]) return 0;
                 int o;
