@@ -97,7 +97,9 @@ struct MjPool {
     TableOne* snap = nullptr;
     SpWork* sp_work = nullptr;      // lazily allocated on the first v4 encode
     int sp_grid = 0;
-    int* sp_queue = nullptr;
+    int* sp_queue = nullptr;        // [0] row queue head, [1..8] / [9..16] class counts / cursors of the row sort
+    uint32_t* sp_order = nullptr;   // [max_rows] queue position -> row
+    uint8_t* sp_cls = nullptr;      // [max_rows] cost class of a row
     unsigned long long* sp_err = nullptr;
     int* n_rows_host = nullptr;  // pinned
     unsigned long long* counters = nullptr;
@@ -241,6 +243,8 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->snap);
     hipFree(P->sp_work);
     hipFree(P->sp_queue);
+    hipFree(P->sp_order);
+    hipFree(P->sp_cls);
     hipFree(P->sp_err);
     hipFree(P->log);
     hipFree(P->log_len);
@@ -560,11 +564,13 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         if (!P->sp_work) {
             P->sp_grid = 256 * SP_WGS;  // persistent workgroups: SP_WGS per CU
             HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
-            HIP_OK(hipMalloc(&P->sp_queue, sizeof(int)));
+            HIP_OK(hipMalloc(&P->sp_queue, 17 * sizeof(int)));
+            HIP_OK(hipMalloc(&P->sp_order, (size_t)P->max_rows * sizeof(uint32_t)));
+            HIP_OK(hipMalloc(&P->sp_cls, (size_t)P->max_rows));
             HIP_OK(hipMalloc(&P->sp_err, 24 * sizeof(unsigned long long)));
             HIP_OK(hipMemset(P->sp_err, 0, 24 * sizeof(unsigned long long)));
         }
-        HIP_OK(hipMemsetAsync(P->sp_queue, 0, sizeof(int), s));
+        HIP_OK(hipMemsetAsync(P->sp_queue, 0, 17 * sizeof(int), s));
         SpParams sp;
         sp.snap = P->snap;
         sp.rows = P->rows[agent & 1];
@@ -573,6 +579,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         sp.obs = obs;
         sp.work = P->sp_work;
         sp.queue = P->sp_queue;
+        sp.order = P->sp_order;
         sp.err = P->sp_err;
         sp.prof = getenv("MJ_SP_PROF") ? P->sp_err : nullptr;
         int grid = n < P->sp_grid ? n : P->sp_grid;
@@ -582,6 +589,9 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
             HIP_OK(hipEventCreate(&s1));
             HIP_OK(hipEventRecord(s0, s));
         }
+        // queue order: rows counting-sorted by cost class, heaviest first (inside the timed mj_k_sp region)
+        hipLaunchKernelGGL(mj_k_sp_classify, dim3((n + 255) / 256), dim3(256), 0, s, P->snap, sp.rows, n, P->sp_cls, P->sp_queue + 1);
+        hipLaunchKernelGGL(mj_k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, P->sp_cls, n, P->sp_queue + 1, P->sp_queue + 9, P->sp_order);
         hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
         if (P->timing) {
             HIP_OK(hipEventRecord(s1, s));
@@ -697,8 +707,8 @@ int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
         out[7] = e2[1];
         if (getenv("MJ_SP_PROF"))
             fprintf(stderr, "[sp prof] rows %llu setup %llu expand %llu evalL0 %llu evalL>0 %llu encode %llu states %llu (wall_clock64 ticks, 100 MHz) | "
-                    "expand passes: probes %llu lists+V %llu td-probes %llu layout %llu inserts %llu; items %llu expanded %llu edges %llu l0-entries %llu; level-0 probe %llu scoring %llu\n",
-                    e2[1], e2[2], e2[3], e2[4], e2[5], e2[6], e2[7], e2[8], e2[9], e2[10], e2[11], e2[12], e2[13], e2[14], e2[15], e2[16], e2[17], e2[18]);
+                    "expand passes: probes %llu lists+V %llu td-probes %llu layout %llu inserts %llu; items %llu expanded %llu edges %llu l0-entries %llu; level-0 probe %llu scoring %llu; workgroup lifetimes: sum %llu max %llu queue pops %llu hash resets %llu\n",
+                    e2[1], e2[2], e2[3], e2[4], e2[5], e2[6], e2[7], e2[8], e2[9], e2[10], e2[11], e2[12], e2[13], e2[14], e2[15], e2[16], e2[17], e2[18], e2[19], e2[20], e2[21], e2[22]);
     }
     return 0;
 }

@@ -74,7 +74,8 @@ struct SpParams {
     MjTablesDev tables;
     float* obs;                // [n_rows][1012][34]; rows 889.. are zero on entry (written by mj_k_encode<4>)
     SpWork* work;              // [gridDim.x]
-    int* queue;                // dynamic row queue (zeroed before launch)
+    int* queue;                // dynamic row queue (zeroed before launch); [1..8] class counts, [9..16] class cursors of the row sort
+    const uint32_t* order;     // [n_rows] queue position -> row index, heaviest cost class first (mj_k_sp_classify / _scatter)
     unsigned long long* prof;  // NULL or [24] phase timers / counters (MJ_SP_PROF; mj_counters prints them)
     unsigned long long* err;   // [0] hash-capacity overflows, [1] rows; cycle sums: [2] setup [3] expand [4] eval L0 [5] eval L>0 [6] encode; [7] states
 };
@@ -960,6 +961,76 @@ MJD int f32_total_cmp(float a, float b) {
     return (x > y) - (x < y);
 }
 
+// ---------------------------------------------------------------- queue order: heaviest cost class first
+// A row costs between nothing (no single-player tables for this decision) and ~6,000 states; the persistent workgroups pop rows
+// from one queue, so a heavy row popped last leaves the other workgroups idle for its whole duration (15 % of the kernel,
+// measured).  84 % of all states belong to the 3-shanten hands that may discard, 8 % to the 3-shanten hands before a call
+// decision, 7 % to the 2-shanten hands: a counting sort of the rows by (shanten, may discard, discard candidates) -- the
+// table's incremental shanten bookkeeping, no calculator work -- puts the long rows first and leaves the short ones to
+// level the tail.
+// The order of the rows in the queue does not touch the results (obs rows are addressed by row index).
+#define SP_N_CLASS 8
+MJD int sp_row_class(const TableOne* snap, uint32_t desc) {
+    LaneT<TableOne> L;
+    L.B = const_cast<TableOne*>(snap + ROW_TABLE(desc));
+    L.l = 0;
+    L.T = nullptr;
+    const int p = ROW_SEAT(desc);
+    const u32 cans = F1(cans, p);
+    const bool cd = (cans & CAN_DISCARD) != 0;
+    const int tiles_left = F(tiles_left);
+    int sh = F1(shanten, p), tsumos_left;
+    if (cd) {
+        if (sh > 0 && F1(has_next_shanten, p)) sh -= 1;
+        tsumos_left = tiles_left / 4;
+    } else {
+        const int target = (F1(cans_target, p) + 4 - p) & 3;
+        tsumos_left = max(tiles_left - (4 - target), 0) / 4;
+    }
+    if (tiles_left < 4 || sh > 3 || tsumos_left < max(sh, 1)) return 7;  // no state graph at all
+    if (sh <= 1) return 6;
+    if (sh == 2) return cd ? 4 : 5;
+    if (!cd) return 2;
+    // 3-shanten, may discard: the number of root states = discards that keep the shanten number (the masks the table keeps
+    // for its legal-action logic) splits the class further: >= 7 candidates average 1.5 k states, 6 -> 0.9 k, <= 5 -> 0.4 k
+    const int n_cand = __popcll(F1(has_next_shanten, p) ? F1(next_shanten, p) : F1(keep_shanten, p));
+    return n_cand >= 7 ? 0 : n_cand == 6 ? 1 : 3;
+}
+
+__global__ __launch_bounds__(256) void mj_k_sp_classify(const TableOne* snap, const uint32_t* rows, int n, uint8_t* cls, int* cnt) {
+    __shared__ int h[SP_N_CLASS];
+    if (threadIdx.x < SP_N_CLASS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int c = sp_row_class(snap, rows[i]);
+        cls[i] = (uint8_t)c;
+        atomicAdd(&h[c], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < SP_N_CLASS && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void mj_k_sp_scatter(const uint8_t* cls, int n, const int* cnt, int* cursor, uint32_t* order) {
+    __shared__ int h[SP_N_CLASS], base[SP_N_CLASS];
+    if (threadIdx.x < SP_N_CLASS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int c = 0, r = 0;
+    if (i < n) {
+        c = cls[i];
+        r = atomicAdd(&h[c], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < SP_N_CLASS) {
+        int b = 0;
+        for (int k = 0; k < (int)threadIdx.x; k++) b += cnt[k];
+        base[threadIdx.x] = b + (h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0);
+    }
+    __syncthreads();
+    if (i < n) order[base[c] + r] = (uint32_t)i;
+}
+
 __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ int s_row;
@@ -985,11 +1056,15 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
     for (int i = tid; i < SP_CAP; i += SP_THREADS) W->tag[i] = 0ull;
     __syncthreads();
 
+    const long long t_wg0 = P.prof ? wall_clock64() : 0;  // MJ_SP_PROF: workgroup lifetime / queue + reset time (err[19..22])
+    long long t_pop = 0, t_reset = 0;
     for (;;) {
+        const long long t_a = P.prof ? wall_clock64() : 0;
         if (tid == 0) s_row = atomicAdd(P.queue, 1);
         __syncthreads();
-        const int row = s_row;
-        if (row >= P.n_rows) break;
+        if (s_row >= P.n_rows) break;
+        const int row = (int)P.order[s_row];
+        if (P.prof) t_pop += wall_clock64() - t_a;
         const uint32_t desc = P.rows[row];
         const int table = ROW_TABLE(desc), p = ROW_SEAT(desc);
         long long t_0 = wall_clock64(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0;
@@ -1458,6 +1533,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
             }
         }
         // ---- reset the hash set for the next row
+        const long long t_r = P.prof ? wall_clock64() : 0;
         {
             const int n = min(X.n_list, SP_CAP);
             for (int i = tid; i < n; i += SP_THREADS) W->tag[W->list[i]] = 0ull;
@@ -1467,5 +1543,13 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
             }
         }
         __syncthreads();
+        if (P.prof) t_reset += wall_clock64() - t_r;
+    }
+    if (P.prof && tid == 0) {
+        const unsigned long long life = (unsigned long long)(wall_clock64() - t_wg0);
+        atomicAdd(&P.err[19], life);
+        atomicMax(&P.err[20], life);
+        atomicAdd(&P.err[21], (unsigned long long)t_pop);
+        atomicAdd(&P.err[22], (unsigned long long)t_reset);
     }
 }
