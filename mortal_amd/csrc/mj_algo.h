@@ -342,6 +342,21 @@ MJD int sh_pair_idx(int a, int b) {  // unordered suit pair -> 0..5 : 01 02 03 1
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     return lo == 0 ? hi - 1 : lo == 1 ? hi + 1 : 5;
 }
+// For every suit s the merge of the three OTHER suits' rows: 6 merges, after which any hand one tile away from the base
+// hand costs one gather + sh_final (the step kernel's discard / wait scans; the SP kernel spreads the same merges over lanes).
+struct ShOthers {
+    u64 r[4];
+    MJD u64 of(int s) const { return s == 0 ? r[0] : s == 1 ? r[1] : s == 2 ? r[2] : r[3]; }
+};
+MJD ShOthers sh_others(const ShBase& B, int m) {
+    const u64 m01 = sh_merge(B.row[0], B.row[1], m), m23 = sh_merge(B.row[2], B.row[3], m);
+    ShOthers o;
+    o.r[0] = sh_merge(m23, B.row[1], m);
+    o.r[1] = sh_merge(m23, B.row[0], m);
+    o.r[2] = sh_merge(m01, B.row[3], m);
+    o.r[3] = sh_merge(m01, B.row[2], m);
+    return o;
+}
 // normal-form shanten from the final entry + chitoi / kokushi (shanten.rs:139-150)
 MJD int sh_finish(int fin, int len_div3, int pairs, int kinds, int kpairs, int kkinds) {
     int s = fin - 1;

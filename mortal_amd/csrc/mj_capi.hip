@@ -34,6 +34,7 @@ struct DevTables {
     MjTablesDev dev{};
     MjGatherEnt* gather = nullptr;
     int n_gather = 0;
+    int gather_chunk[SNAP_NCH + 1] = {0};  // first gather entry of each record chunk (mj_k_snapshot)
     float *decay = nullptr, *rbf_score = nullptr, *rbf_6 = nullptr, *rbf_12 = nullptr, *rbf_23 = nullptr;
 } g_tables;
 
@@ -178,6 +179,12 @@ int mj_tables_upload(const void* payload, size_t size) {
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_mj_tables), &g_tables.dev, sizeof(MjTablesDev)));
     auto g = build_gather();
     g_tables.n_gather = (int)g.size();
+    for (int c = 0, k = 0; c <= SNAP_NCH; c++) {  // entries are in field order = ascending dst_off
+        while (k < (int)g.size() && (int)g[k].dst_off < c * SNAP_CH) k++;
+        g_tables.gather_chunk[c] = c == SNAP_NCH ? (int)g.size() : k;
+    }
+    for (size_t k = 1; k < g.size(); k++)
+        if (g[k].dst_off < g[k - 1].dst_off) return fail("gather list not in record order");
     if (upload(g, &g_tables.gather)) return -1;
     std::vector<float> decay(64);
     for (int k = 0; k < 64; k++) decay[k] = expf(-0.2f * (float)k);  // obs_repr.rs:228,266
@@ -392,8 +399,9 @@ static int launch_rows(MjPool* P, hipStream_t s) {
     rp.max_rows[0] = rp.max_rows[1] = P->max_rows;
     hipLaunchKernelGGL(mj_k_scan, dim3(1), dim3(1024), 0, s, rp);
     hipLaunchKernelGGL(mj_k_assign, dim3(P->n_blocks), dim3(64), 0, s, rp);
-    SnapParams snp = {P->blocks, P->snap, g_tables.gather, g_tables.n_gather};
-    hipLaunchKernelGGL(mj_k_snapshot, dim3(P->n_blocks), dim3(256), 0, s, snp);
+    SnapParams snp = {P->blocks, P->snap, g_tables.gather, {0}};
+    for (int c = 0; c <= SNAP_NCH; c++) snp.chunk_first[c] = g_tables.gather_chunk[c];
+    hipLaunchKernelGGL(mj_k_snapshot, dim3(P->n_blocks * SNAP_NCH), dim3(256), 0, s, snp);
     HIP_OK(hipMemcpyAsync(P->n_rows_host, P->n_rows_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(hipGetLastError());
     P->cycles += 1;
@@ -590,8 +598,8 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
             HIP_OK(hipEventRecord(s0, s));
         }
         // queue order: rows counting-sorted by cost class, heaviest first (inside the timed mj_k_sp region)
-        hipLaunchKernelGGL(mj_k_sp_classify, dim3((n + 255) / 256), dim3(256), 0, s, P->snap, sp.rows, n, P->sp_cls, P->sp_queue + 1);
-        hipLaunchKernelGGL(mj_k_sp_scatter, dim3((n + 255) / 256), dim3(256), 0, s, P->sp_cls, n, P->sp_queue + 1, P->sp_queue + 9, P->sp_order);
+        hipLaunchKernelGGL(mj_k_order_classify, dim3((n + 255) / 256), dim3(256), 0, s, P->snap, sp.rows, n, P->sp_cls, P->sp_queue + 1);
+        hipLaunchKernelGGL(mj_k_order_scatter, dim3((n + 255) / 256), dim3(256), 0, s, P->sp_cls, n, P->sp_queue + 1, P->sp_queue + 9, P->sp_order);
         hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
         if (P->timing) {
             HIP_OK(hipEventRecord(s1, s));
@@ -694,6 +702,18 @@ int mj_greedy_policy(MjPool* P, int agent, const uint8_t* masks, const float* ob
 }
 
 int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
+#ifdef MJ_STEP_PROF
+    if (getenv("MJ_STEP_PROF")) {
+        unsigned long long sp_[32];
+        hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(sp_, HIP_SYMBOL(g_step_prof), sizeof sp_) == hipSuccess) {
+            fprintf(stderr, "[step prof] waves %llu kernel %llu commit %llu poll %llu (start_kyoku %llu board_step %llu [n %llu] any_can_act %llu; kyoku ends %llu) classify %llu | board_step by event:",
+                    sp_[8], sp_[0], sp_[1], sp_[2], sp_[3], sp_[4], sp_[9], sp_[5], sp_[10], sp_[7]);
+            for (int k = 11; k < 32; k++) fprintf(stderr, " %llu", sp_[k]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     if (!P) return fail("null pool");
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
     unsigned long long tmp[8];

@@ -41,21 +41,37 @@ MJDN void keccak_f(u64 a[25]) {
     }
 }
 
+// LDS work area of one wavefront, lane-interleaved (lane l owns wall[.][l] and rng[.][l]).  The Fisher-Yates swaps are a chain
+// of ~136 dependent load/store pairs at data-dependent addresses and the RNG buffer is indexed dynamically: in HBM / scratch
+// every link of that chain costs a memory round trip (the deal was the critical path of mj_k_step: a wavefront with one
+// dealing lane ran 3x as long as one without), in LDS it costs ~100 cycles.
+#define DEAL_LANES 64
+struct DealScratch {
+    u8 wall[136][DEAL_LANES];
+    u32 rng[16][DEAL_LANES];
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MJ_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define MJ_ASSUME_LDS(p) ((void)0)  // host pass of the single-source compile: the builtin only exists on the device
+#endif
+
 struct ChaCha12Dev {
     u32 key[8];
-    u32 buf[16];
+    u32* buf;  // -> DealScratch::rng[0][lane], stride DEAL_LANES
     u32 counter;
     int idx;
-    MJD void init(const u64 seed[4]) {
+    MJD void init(const u64 seed[4], u32* lds_buf) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             key[2 * i] = (u32)seed[i];
             key[2 * i + 1] = (u32)(seed[i] >> 32);
         }
+        buf = lds_buf;
         counter = 0;
         idx = 16;
     }
-    MJDN void refill() {
+    MJD void refill() {
         u32 s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
                      key[4], key[5], key[6], key[7], counter, 0u, 0u, 0u};
         u32 x[16];
@@ -72,19 +88,19 @@ struct ChaCha12Dev {
         }
 #undef QR
 #pragma unroll
-        for (int i = 0; i < 16; i++) buf[i] = x[i] + s[i];
+        for (int i = 0; i < 16; i++) buf[i * DEAL_LANES] = x[i] + s[i];
         counter++;
         idx = 0;
     }
     MJD u32 next() {
         if (idx >= 16) refill();
-        // buf is indexed dynamically -> lives in scratch; 16 dwords per lane, fine.
-        return buf[idx++];
+        return buf[(idx++) * DEAL_LANES];
     }
 };
 
-// Writes the shuffled 136-tile sequence into wall[i * stride].
-MJDN void deal_wall(u8* wall, int stride, u64 nonce, u64 key, int kyoku, int honba, int algo) {
+// Writes the shuffled 136-tile sequence into wall[i * stride]; S = the wavefront's LDS work area, lane = this thread's column.
+MJDN void deal_wall(u8* wall, int stride, DealScratch* S, int lane, u64 nonce, u64 key, int kyoku, int honba, int algo) {
+    MJ_ASSUME_LDS(S);
     // SHA3-256 of an 18-byte message: one rate block (136 B), pad 0x06 .. 0x80
     u64 st[25];
 #pragma unroll
@@ -95,13 +111,15 @@ MJDN void deal_wall(u8* wall, int stride, u64 nonce, u64 key, int kyoku, int hon
     st[16] = 0x80ull << 56;
     keccak_f(st);
     ChaCha12Dev rng;
-    rng.init(st);
+    rng.init(st, &S->rng[0][lane]);
+    u8* w = &S->wall[0][lane];
+    constexpr int WS = DEAL_LANES;
 
     for (int t = 0; t < 34; t++)
-        for (int k = 0; k < 4; k++) wall[(t * 4 + k) * stride] = (u8)t;
-    wall[(T_5M * 4) * stride] = T_5MR;
-    wall[(T_5P * 4) * stride] = T_5PR;
-    wall[(T_5S * 4) * stride] = T_5SR;
+        for (int k = 0; k < 4; k++) w[(t * 4 + k) * WS] = (u8)t;
+    w[(T_5M * 4) * WS] = T_5MR;
+    w[(T_5P * 4) * WS] = T_5PR;
+    w[(T_5S * 4) * WS] = T_5SR;
 
     if (algo == 0) {  // rand 0.8: for i in (1..n).rev(): swap(i, gen_range(0..=i))
         for (int i = 135; i >= 1; i--) {
@@ -115,9 +133,9 @@ MJDN void deal_wall(u8* wall, int stride, u64 nonce, u64 key, int kyoku, int hon
                     break;
                 }
             }
-            u8 a = wall[i * stride], b = wall[j * stride];
-            wall[i * stride] = b;
-            wall[j * stride] = a;
+            u8 a = w[i * WS], b = w[j * WS];
+            w[i * WS] = b;
+            w[j * WS] = a;
         }
     } else {  // rand 0.9.1: forward loop with the chunked IncreasingUniform sampler
         u32 n = 0, chunk = 0;
@@ -154,9 +172,10 @@ MJDN void deal_wall(u8* wall, int stride, u64 nonce, u64 key, int kyoku, int hon
             }
             chunk_remaining = next_rem;
             n = next_n;
-            u8 a = wall[i * stride], b = wall[result * stride];
-            wall[i * stride] = b;
-            wall[result * stride] = a;
+            u8 a = w[i * WS], b = w[result * WS];
+            w[i * WS] = b;
+            w[result * WS] = a;
         }
     }
+    for (int i = 0; i < 136; i++) wall[i * stride] = w[i * WS];
 }

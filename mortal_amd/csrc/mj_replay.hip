@@ -85,7 +85,7 @@ template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uin
                 // the pool's shuffle first, then the other one: logs of either rand generation of the reference arena load
                 bool same = false;
                 for (int attempt = 0; attempt < 2 && !same; attempt++) {
-                    deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), F(kyoku), F(honba),
+                    deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, L.deal, L.l, F(seed_nonce), F(seed_key), F(kyoku), F(honba),
                               attempt == 0 ? deal_algo : 1 - deal_algo);
                     same = F1(wall, 60) == ev.pai;
                     for (int i = 0; i < 52; i++) same = same && logged[i] == F1(wall, i);
@@ -171,8 +171,10 @@ template <class LN> MJDN int rp_label(const LN& L, int p, const RpEvent nxt[3], 
 
 // Apply events until at least one tracked seat has a sample (or the log ends).  One lane per table.
 __global__ __launch_bounds__(64) void mj_k_replay(ReplayParams P) {
+    __shared__ DealScratch s_deal;
     const int table = blockIdx.x * 64 + threadIdx.x;
     Lane L = {MJ_POOL_PTR(P.blocks + blockIdx.x), (int)threadIdx.x, &c_mj_tables};
+    L.deal = &s_deal;
     int nr = 0;
     if (table < P.n_tables) {
         const uint64_t* sc = P.script + P.script_off[table];
@@ -275,7 +277,9 @@ __global__ void mj_k_replay_meta(ReplayMetaParams P) {
 // ================================================================ single-table access for libriichi.state.PlayerState
 // (state/player_state.rs:142-167 pyo3 surface: update / encode_obs / getters; used by tests and debugging)
 __global__ void mj_k_apply_event(TableBlock* blocks, int table, const uint64_t* words) {
+    __shared__ DealScratch s_deal;
     Lane L = {MJ_POOL_PTR(blocks + (table >> 6)), table & 63, &c_mj_tables};
+    L.deal = &s_deal;
     const RpEvent ev = rp_decode(words[0]);
     rp_apply(L, ev, words);
 }

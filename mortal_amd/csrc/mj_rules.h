@@ -10,6 +10,27 @@
 #include "mj_algo.h"
 #include "mj_deal.h"
 
+// Section timers of the step kernel (variant build -DMJ_STEP_PROF only: tools/build_variant.sh stepprof -DMJ_STEP_PROF;
+// MJ_STEP_PROF=1 in the environment makes mj_counters print them).  A section's clocks are read once per wavefront by
+// whichever lanes are inside it, so a sum is "wave time with at least one lane in the section".
+#ifdef MJ_STEP_PROF
+__device__ unsigned long long g_step_prof[32];
+#define SPROF_T(t) const long long t = clock64()
+#define SPROF_ADD(k, t)                                                                                   \
+    do {                                                                                                  \
+        const long long d_ = clock64() - (t);                                                             \
+        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_step_prof[k], (unsigned long long)d_); \
+    } while (0)
+#define SPROF_CNT(k)                                                                                      \
+    do {                                                                                                  \
+        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_step_prof[k], 1ull);    \
+    } while (0)
+#else
+#define SPROF_T(t)
+#define SPROF_ADD(k, t)
+#define SPROF_CNT(k)
+#endif
+
 // Lookup tables of the process (set once by mj_tables_upload).  A __constant__ symbol rather than a kernel argument:
 // taking the address of a by-value kernel parameter makes hipcc copy the WHOLE parameter struct to scratch in every
 // thread (160 B x 256 threads per encoded row showed up as +34 % HBM write traffic in the PMC counters).
@@ -24,6 +45,7 @@ struct LaneT {  // a table viewed through lane `l` of a block (pool block in HBM
     uint64_t* log = nullptr;   // this table's event log (NULL = logging off), see mj_state.h LG_*
     uint32_t* log_len = nullptr;
     uint32_t log_cap = 0;
+    DealScratch* deal = nullptr;  // the wavefront's LDS work area for deal_wall (kernels that may start a kyoku set it)
 };
 typedef LaneT<TableBlock> Lane;
 #define MJ_POOL_PTR(p) ((LaneBlockPtr<TableBlock>::type)(p))
@@ -104,15 +126,22 @@ template <class LN> MJD void update_shanten(const LN& L, int s) {
     int v = calc_all(*L.T, load_hand(L, s), F1(len_div3, s));
     F1(shanten, s) = (int8_t)max(v, 0);
 }
+// The hands probed below are one tile away from the seat's hand, so they share the base rows and the six partial merges of
+// the untouched suits (mj_algo.h sh_others): a probe is one table gather + sh_final instead of a from-scratch calc_all
+// (four dependent gathers + two full merges) -- these two scans were 60 % of mj_k_step's wave time.
 template <class LN> MJDN void update_shanten_discards(const LN& L, int s) {  // 3n+2
-    Hand h = load_hand(L, s);
-    int ld3 = F1(len_div3, s), sh = F1(shanten, s);
+    const Hand h = load_hand(L, s);
+    const int ld3 = F1(len_div3, s), sh = F1(shanten, s);
+    const ShTab ST = sh_tab(*L.T);
+    const ShBase B = sh_base(ST, h);
+    const ShOthers O = sh_others(B, ld3);
     u64 next = 0, keep = 0;
-    for (int t = 0; t < 34; t++) {
-        if (h.get(t) == 0) continue;
-        Hand g = h;
-        g.dec(t);
-        int after = calc_all(*L.T, g, ld3);
+    for (u64 m = h.nonzero_mask(); m; m &= m - 1) {  // each lane walks its own tile kinds: <= 14 rounds per wavefront
+        const int t = __ffsll((long long)m) - 1, st = sh_suit(t), c = h.get(t);
+        const int y = (int)((YAOKYUU_MASK >> t) & 1);
+        const u64 row = sh_load(ST, st, B.key_of(st) - sh_pow(t));
+        const int after = sh_finish(sh_final(O.of(st), row, ld3), ld3, B.pairs - (c == 2), B.kinds - (c == 1),
+                                    B.kpairs - (y && c == 2), B.kkinds - (y && c == 1));
         if (after < sh) next |= BIT(t);
         else if (after == sh) keep |= BIT(t);
     }
@@ -124,15 +153,20 @@ template <class LN> MJDN void update_waits_and_furiten(const LN& L, int s) {  //
     u8 pf = F1(pflags, s) & ~PF_AT_FURITEN;
     u64 waits = 0;
     if (F1(shanten, s) <= 0) {
-        Hand h = load_hand(L, s);
-        int ld3 = F1(len_div3, s);
-        u64 disc = F1(discarded, s);
+        const Hand h = load_hand(L, s);
+        const int ld3 = F1(len_div3, s);
+        const u64 disc = F1(discarded, s);
+        const ShTab ST = sh_tab(*L.T);
+        const ShBase B = sh_base(ST, h);
+        const ShOthers O = sh_others(B, ld3);
         for (int t = 0; t < 34; t++) {
-            int c = h.get(t);
+            const int c = h.get(t);
             if (c == 4) continue;
-            Hand g = h;
-            g.inc(t);
-            if (calc_all(*L.T, g, ld3) == -1) {
+            const int st = sh_suit(t), y = (int)((YAOKYUU_MASK >> t) & 1);
+            const u64 row = sh_load(ST, st, B.key_of(st) + sh_pow(t));
+            const int v = sh_finish(sh_final(O.of(st), row, ld3), ld3, B.pairs + (c == 1), B.kinds + (c == 0),
+                                    B.kpairs + (y && c == 1), B.kkinds + (y && c == 0));
+            if (v == -1) {
                 if ((disc >> t) & 1) pf |= PF_AT_FURITEN;
                 if (F1(pub_seen, t) + c < 4) waits |= BIT(t);  // tiles_seen = pub_seen + own hand
             }
@@ -616,9 +650,14 @@ template <class LN> MJDN void kyoku_init(const LN& L) {
     }
 }
 template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
+    static_assert(MJ_LANES == DEAL_LANES, "one DealScratch column per pool lane");
     const int kyoku = F(kyoku), honba = F(honba);
-    deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
+    SPROF_T(t_d);
+    deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, L.deal, L.l, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
+    SPROF_ADD(19, t_d);
+    SPROF_T(t_i);
     kyoku_init(L);
+    SPROF_ADD(20, t_i);
     const int marker = F1(wall, 56 + 4);
     // first tsumo of the oya
     const int oya = kyoku & 3;
@@ -642,7 +681,9 @@ template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
         }
         log_push(L, LG_WORD(LG_TSUMO, oya, 0, tile, 0, 0, 0, 0, 0));
     }
+    SPROF_T(t_t);
     ev_tsumo(L, oya, tile);
+    SPROF_ADD(21, t_t);
 }
 
 // ---------------------------------------------------------------- scoring (agent_helper.rs:377-462)

@@ -75,7 +75,7 @@ struct SpParams {
     float* obs;                // [n_rows][1012][34]; rows 889.. are zero on entry (written by mj_k_encode<4>)
     SpWork* work;              // [gridDim.x]
     int* queue;                // dynamic row queue (zeroed before launch); [1..8] class counts, [9..16] class cursors of the row sort
-    const uint32_t* order;     // [n_rows] queue position -> row index, heaviest cost class first (mj_k_sp_classify / _scatter)
+    const uint32_t* order;     // [n_rows] queue position -> row index, heaviest cost class first (mj_k_order_classify / _scatter)
     unsigned long long* prof;  // NULL or [24] phase timers / counters (MJ_SP_PROF; mj_counters prints them)
     unsigned long long* err;   // [0] hash-capacity overflows, [1] rows; cycle sums: [2] setup [3] expand [4] eval L0 [5] eval L>0 [6] encode; [7] states
 };
@@ -997,7 +997,7 @@ MJD int sp_row_class(const TableOne* snap, uint32_t desc) {
     return n_cand >= 7 ? 0 : n_cand == 6 ? 1 : 3;
 }
 
-__global__ __launch_bounds__(256) void mj_k_sp_classify(const TableOne* snap, const uint32_t* rows, int n, uint8_t* cls, int* cnt) {
+__global__ __launch_bounds__(256) void mj_k_order_classify(const TableOne* snap, const uint32_t* rows, int n, uint8_t* cls, int* cnt) {
     __shared__ int h[SP_N_CLASS];
     if (threadIdx.x < SP_N_CLASS) h[threadIdx.x] = 0;
     __syncthreads();
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256) void mj_k_sp_classify(const TableOne* snap, co
     if (threadIdx.x < SP_N_CLASS && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void mj_k_sp_scatter(const uint8_t* cls, int n, const int* cnt, int* cursor, uint32_t* order) {
+__global__ __launch_bounds__(256) void mj_k_order_scatter(const uint8_t* cls, int n, const int* cnt, int* cursor, uint32_t* order) {
     __shared__ int h[SP_N_CLASS], base[SP_N_CLASS];
     if (threadIdx.x < SP_N_CLASS) h[threadIdx.x] = 0;
     __syncthreads();

@@ -375,7 +375,9 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
     switch (ev.type) {
         case RX_NONE: {
             if (F(tiles_left) == 0) {
+                SPROF_T(t_e);
                 exhaustive_ryukyoku(L);
+                SPROF_ADD(17, t_e);
                 return true;
             }
             check_riichi_accepted(L);
@@ -401,7 +403,9 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
             F(flags) = fl;
             if (dora_now) add_new_dora(L);
             log_push(L, LG_WORD(LG_TSUMO, F(tsumo_actor), 0, tile, 0, 0, 0, 0, 0));
+            SPROF_T(t_e);
             ev_tsumo(L, F(tsumo_actor), tile);
+            SPROF_ADD(11, t_e);
             break;
         }
         case RX_DAHAI: {
@@ -410,7 +414,9 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
                 add_new_dora(L);
             }
             log_push_rx(L, LG_WORD(LG_DAHAI, ev.actor, 0, ev.pai, 0, 0, 0, 0, ev.tsumogiri), ev.tag);
+            SPROF_T(t_e);
             ev_dahai(L, ev.actor, ev.pai, ev.tsumogiri);
+            SPROF_ADD(12, t_e);
             const int next_actor = (ev.actor + 1) & 3;
             F(tsumo_actor) = (u8)next_actor;
             fl = F(flags);
@@ -451,7 +457,11 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
         case RX_PON:
             check_riichi_accepted(L);
             log_push_rx(L, LG_WORD(ev.type == RX_PON ? LG_PON : LG_CHI, ev.actor, ev.target, ev.pai, ev.c0, ev.c1, 0, 0, 0), ev.tag);
-            ev_chi_pon(L, ev.type == RX_PON, ev.actor, ev.target, ev.pai, ev.c0, ev.c1);
+            {
+                SPROF_T(t_e);
+                ev_chi_pon(L, ev.type == RX_PON, ev.actor, ev.target, ev.pai, ev.c0, ev.c1);
+                SPROF_ADD(13, t_e);
+            }
             break;
         case RX_ANKAN:
             if (fl & TF_NEW_DORA_AT_DISCARD) {
@@ -488,9 +498,12 @@ template <class LN> MJDN bool board_step(const LN& L, const Reaction rx[4]) {
             ev_reach(L, ev.actor);
             F(riichi_to_be_accepted) = ev.actor;
             break;
-        case RX_HORA:
+        case RX_HORA: {
+            SPROF_T(t_e);
             handle_hora(L, ev.actor, ev.target, rx);
+            SPROF_ADD(16, t_e);
             return true;
+        }
         case RX_RYUKYOKU:  // 九種九牌
             abortive_ryukyoku(L);  // (the reference logs this Ryukyoku without the agent's meta, board.rs:502-509)
             return true;
@@ -532,16 +545,25 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
                 F(flags) = fl | TF_ENDED;
                 return;
             }
+            SPROF_T(t_sk);
             start_kyoku(L, P.deal_algo);  // haipai + first tsumo == the first board step (board.rs:512-515)
+            SPROF_ADD(3, t_sk);
             kyoku_end = false;
         } else {
+            SPROF_T(t_bs);
+            SPROF_CNT(9);
             kyoku_end = board_step(L, rx);
+            SPROF_ADD(4, t_bs);
         }
         for (int i = 0; i < 4; i++) rx[i].type = RX_NONE;
         if (!kyoku_end) {
-            if (any_can_act(L)) return;
+            SPROF_T(t_ca);
+            const bool act = any_can_act(L);
+            SPROF_ADD(5, t_ca);
+            if (act) return;
             continue;
         }
+        SPROF_CNT(10);
         // ---- Poll::End (board.rs:149-157, game.rs:114-174)
         log_push(L, LG_WORD(LG_END_KYOKU, 0, 0, 0, 0, 0, 0, 0, 0));
         fl = F(flags);
@@ -581,13 +603,16 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
 }
 
 __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
+    __shared__ DealScratch s_deal;
     const int table = blockIdx.x * 64 + threadIdx.x;
     Lane L = {MJ_POOL_PTR(P.blocks + blockIdx.x), (int)threadIdx.x, &c_mj_tables};
+    L.deal = &s_deal;
     if (P.log && table < P.n_tables) {
         L.log = P.log + (size_t)table * P.log_cap;
         L.log_len = P.log_len + table;
         L.log_cap = P.log_cap;
     }
+    SPROF_T(t_k0);
     u32 fl = F(flags);
     const bool active = table < P.n_tables && !(fl & TF_INACTIVE);
     bool live_after = false;
@@ -639,8 +664,12 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
                             ((uint64_t)((F1(pflags, s) & PF_AT_FURITEN) != 0) << 60) | (1ull << 63);
         }
         F(pending) = 0;
+        SPROF_ADD(1, t_k0);
         // ---- poll
+        SPROF_T(t_gp);
         game_poll(L, rx, P);
+        SPROF_ADD(2, t_gp);
+        SPROF_T(t_cl);
         fl = F(flags);
         if (fl & TF_ENDED) {
             // game.rs:181-197: leftover kyotaku to the (first) top, emit the result
@@ -696,6 +725,7 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
             F1(n_rows, 0) = (u8)nr[0];
             F1(n_rows, 1) = (u8)nr[1];
         }
+        SPROF_ADD(7, t_cl);
     } else if (active) {
         F1(n_rows, 0) = 0;
         F1(n_rows, 1) = 0;
@@ -720,6 +750,8 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
         if (dec_sum) atomicAdd(&P.counters[3], (unsigned long long)dec_sum);
         if (quick_sum) atomicAdd(&P.counters[4], (unsigned long long)quick_sum);
     }
+    SPROF_ADD(0, t_k0);
+    SPROF_CNT(8);
 }
 
 // Restart finished tables with fresh seeds (steady-state throughput mode; not used in parity runs).
@@ -815,31 +847,53 @@ __global__ __launch_bounds__(64) void mj_k_assign(RowsParams P) {
 }
 
 // ---------------------------------------------------------------- snapshot (SoA pool -> one contiguous record per table)
-// The pool is lane-major for the step kernel; the encoder wants one table's ~2.3 KB in one piece.  Every element is
-// read coalesced (64 lanes = 64 consecutive elements) and written to that table's TableOne record; the 550 small
-// writes per table land in the same few cache lines within microseconds and merge in L2.  Tables without a policy
-// row this cycle are skipped.
+// The pool is lane-major for the step kernel; the encoder wants one table's 2.1 KB in one piece.  A workgroup transposes
+// a quarter of the record of its block of 64 tables through LDS: every pool element is read coalesced (64 lanes =
+// 64 consecutive elements) and dropped at its record offset in the table's LDS row, then the rows go out as 16-byte
+// coalesced stores (33 consecutive lanes per table).  (Round 1 wrote the ~550 elements of a record straight to HBM: 64
+// different cache lines per store instruction -- 0.27 ms per cycle for 0.28 GB of traffic.)  Tables without a policy row
+// this cycle are not written.
+#define SNAP_NCH 4
+constexpr int SNAP_CH = (int)(sizeof(TableOne) / SNAP_NCH);
+static_assert(sizeof(TableOne) % (SNAP_NCH * 16) == 0, "record = SNAP_NCH chunks of whole 16-byte pieces");
 struct SnapParams {
     const TableBlock* blocks;
     TableOne* snap;
-    const MjGatherEnt* gather;
-    int n_gather;
+    const MjGatherEnt* gather;  // ascending dst_off (field order); naturally aligned elements of <= 8 bytes never straddle a chunk
+    int chunk_first[SNAP_NCH + 1];  // gather entries of chunk c: [chunk_first[c], chunk_first[c + 1])
 };
 __global__ __launch_bounds__(256) void mj_k_snapshot(SnapParams P) {
-    const TableBlock* B = P.blocks + blockIdx.x;
+    __shared__ __attribute__((aligned(16))) char s_rec[MJ_LANES * SNAP_CH];
+    __shared__ int s_has[MJ_LANES];
+    // one workgroup per (pool block, record chunk): 4 x n_blocks independent workgroups keep more loads in flight than a
+    // chunk loop inside one workgroup per block
+    const int blk = blockIdx.x / SNAP_NCH, c = blockIdx.x % SNAP_NCH;
+    const TableBlock* B = P.blocks + blk;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    if ((B->n_rows[0][lane] | B->n_rows[1][lane]) == 0) return;
+    const bool has = (B->n_rows[0][lane] | B->n_rows[1][lane]) != 0;
+    if (__ballot(has) == 0) return;  // (the same value in all four wavefronts)
+    if (grp == 0) s_has[lane] = has;
     const char* src_base = reinterpret_cast<const char*>(B);
-    char* dst_base = reinterpret_cast<char*>(P.snap + (size_t)blockIdx.x * 64 + lane);
-    for (int g = grp; g < P.n_gather; g += 4) {
-        const MjGatherEnt e = P.gather[g];  // wave-uniform
-        const char* s = src_base + e.src_off + lane * e.size;
-        char* d = dst_base + e.dst_off;
-        switch (e.size) {
-            case 1: *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s); break;
-            case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
-            case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
-            default: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
+    char* dst_block = reinterpret_cast<char*>(P.snap + (size_t)blk * MJ_LANES);
+    {
+        for (int g = P.chunk_first[c] + grp; g < P.chunk_first[c + 1]; g += 4) {
+            const MjGatherEnt e = P.gather[g];  // wave-uniform
+            const char* s = src_base + e.src_off + lane * e.size;
+            char* d = s_rec + lane * SNAP_CH + ((int)e.dst_off - c * SNAP_CH);
+            switch (e.size) {
+                case 1: *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s); break;
+                case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
+                case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
+                default: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
+            }
+        }
+        __syncthreads();
+        constexpr int PPT = SNAP_CH / 16;  // 16-byte pieces per table and chunk
+        for (int p = threadIdx.x; p < MJ_LANES * PPT; p += 256) {
+            const int t = p / PPT, o = (p - t * PPT) * 16;
+            if (s_has[t])
+                *reinterpret_cast<float4*>(dst_block + (size_t)t * sizeof(TableOne) + c * SNAP_CH + o) =
+                    *reinterpret_cast<const float4*>(s_rec + t * SNAP_CH + o);
         }
     }
 }
