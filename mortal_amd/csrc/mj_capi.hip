@@ -401,7 +401,7 @@ static int launch_rows(MjPool* P, hipStream_t s) {
     hipLaunchKernelGGL(mj_k_assign, dim3(P->n_blocks), dim3(64), 0, s, rp);
     SnapParams snp = {P->blocks, P->snap, g_tables.gather, {0}};
     for (int c = 0; c <= SNAP_NCH; c++) snp.chunk_first[c] = g_tables.gather_chunk[c];
-    hipLaunchKernelGGL(mj_k_snapshot, dim3(P->n_blocks * SNAP_NCH), dim3(256), 0, s, snp);
+    hipLaunchKernelGGL(mj_k_snapshot, dim3(P->n_blocks), dim3(256), 0, s, snp);
     HIP_OK(hipMemcpyAsync(P->n_rows_host, P->n_rows_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(hipGetLastError());
     P->cycles += 1;

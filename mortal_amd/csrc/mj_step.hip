@@ -848,7 +848,7 @@ __global__ __launch_bounds__(64) void mj_k_assign(RowsParams P) {
 
 // ---------------------------------------------------------------- snapshot (SoA pool -> one contiguous record per table)
 // The pool is lane-major for the step kernel; the encoder wants one table's 2.1 KB in one piece.  A workgroup transposes
-// a quarter of the record of its block of 64 tables through LDS: every pool element is read coalesced (64 lanes =
+// its block of 64 tables through LDS, a quarter of the record at a time: every pool element is read coalesced (64 lanes =
 // 64 consecutive elements) and dropped at its record offset in the table's LDS row, then the rows go out as 16-byte
 // coalesced stores (33 consecutive lanes per table).  (Round 1 wrote the ~550 elements of a record straight to HBM: 64
 // different cache lines per store instruction -- 0.27 ms per cycle for 0.28 GB of traffic.)  Tables without a policy row
@@ -865,26 +865,38 @@ struct SnapParams {
 __global__ __launch_bounds__(256) void mj_k_snapshot(SnapParams P) {
     __shared__ __attribute__((aligned(16))) char s_rec[MJ_LANES * SNAP_CH];
     __shared__ int s_has[MJ_LANES];
-    // one workgroup per (pool block, record chunk): 4 x n_blocks independent workgroups keep more loads in flight than a
-    // chunk loop inside one workgroup per block
-    const int blk = blockIdx.x / SNAP_NCH, c = blockIdx.x % SNAP_NCH;
-    const TableBlock* B = P.blocks + blk;
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const TableBlock* B = P.blocks + blockIdx.x;
+    const int lane = threadIdx.x & 63, grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool has = (B->n_rows[0][lane] | B->n_rows[1][lane]) != 0;
     if (__ballot(has) == 0) return;  // (the same value in all four wavefronts)
     if (grp == 0) s_has[lane] = has;
     const char* src_base = reinterpret_cast<const char*>(B);
-    char* dst_block = reinterpret_cast<char*>(P.snap + (size_t)blk * MJ_LANES);
-    {
-        for (int g = P.chunk_first[c] + grp; g < P.chunk_first[c + 1]; g += 4) {
-            const MjGatherEnt e = P.gather[g];  // wave-uniform
-            const char* s = src_base + e.src_off + lane * e.size;
-            char* d = s_rec + lane * SNAP_CH + ((int)e.dst_off - c * SNAP_CH);
-            switch (e.size) {
-                case 1: *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s); break;
-                case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
-                case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
-                default: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
+    char* dst_block = reinterpret_cast<char*>(P.snap + (size_t)blockIdx.x * MJ_LANES);
+#pragma unroll 1
+    for (int c = 0; c < SNAP_NCH; c++) {
+        // four elements per round and wavefront: the list entries come through the scalar cache (uniform index) and every
+        // element is fetched as the aligned 8-byte word around it -- no size-dependent branch between the four loads, so
+        // they are in flight together (a load -> LDS store chain per element made the kernel latency-bound)
+        const int end = P.chunk_first[c + 1];
+        for (int g = P.chunk_first[c] + grp; g < end; g += 16) {
+            MjGatherEnt e[4];
+            uint64_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                e[k] = P.gather[min(g + 4 * k, end - 1)];
+                const uintptr_t a = reinterpret_cast<uintptr_t>(src_base + e[k].src_off) + (uintptr_t)(lane * e[k].size);
+                w[k] = *reinterpret_cast<const uint64_t*>(a & ~(uintptr_t)7) >> (8 * (a & 7));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (g + 4 * k >= end) break;
+                char* d = s_rec + lane * SNAP_CH + ((int)e[k].dst_off - c * SNAP_CH);
+                switch (e[k].size) {
+                    case 1: *reinterpret_cast<uint8_t*>(d) = (uint8_t)w[k]; break;
+                    case 2: *reinterpret_cast<uint16_t*>(d) = (uint16_t)w[k]; break;
+                    case 4: *reinterpret_cast<uint32_t*>(d) = (uint32_t)w[k]; break;
+                    default: *reinterpret_cast<uint64_t*>(d) = w[k]; break;
+                }
             }
         }
         __syncthreads();
@@ -895,6 +907,7 @@ __global__ __launch_bounds__(256) void mj_k_snapshot(SnapParams P) {
                 *reinterpret_cast<float4*>(dst_block + (size_t)t * sizeof(TableOne) + c * SNAP_CH + o) =
                     *reinterpret_cast<const float4*>(s_rec + t * SNAP_CH + o);
         }
+        __syncthreads();
     }
 }
 

@@ -319,6 +319,7 @@ inline void __threadfence_block() {}
 inline void __threadfence() {}
 #define __builtin_amdgcn_wave_barrier() emu::die("bare wave_barrier: use mj_team_sync<W>() so the emulator knows the lane group")
 #define __builtin_amdgcn_is_shared(p) true
+#define __builtin_amdgcn_readfirstlane(x) (x)  /* callers pass wave-uniform values */
 
 // ---- wavefront collectives
 template <class T> inline T __shfl(T v, int src, int width = 64) {
