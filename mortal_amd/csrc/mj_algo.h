@@ -137,6 +137,7 @@ struct Hand {
     static MJD int sum_fields(u64 x) { return __popcll(x & LSB3) + 2 * __popcll((x >> 1) & LSB3) + 4 * __popcll((x >> 2) & LSB3); }
     MJD int total() const { return sum_fields(mp) + sum_fields(sz); }  // number of tiles
     MJD int n_kinds() const { return __popcll(nz_fields(mp)) + __popcll(nz_fields(sz)); }
+    MJD bool has_quad() const { return (((mp | sz) >> 2) & LSB3) != 0; }  // some tile held four times (fields count 0..4)
     MJD int n_pairs() const { return __popcll(ge2_fields(mp)) + __popcll(ge2_fields(sz)); }
     MJD int n_yao_kinds() const { return __popcll(nz_fields(mp) & YAO_MP) + __popcll(nz_fields(sz) & YAO_SZ); }
     MJD int n_yao_pairs() const { return __popcll(ge2_fields(mp) & YAO_MP) + __popcll(ge2_fields(sz) & YAO_SZ); }
@@ -356,6 +357,34 @@ MJD ShOthers sh_others(const ShBase& B, int m) {
     o.r[2] = sh_merge(m01, B.row[3], m);
     o.r[3] = sh_merge(m01, B.row[2], m);
     return o;
+}
+// Which draws can lower the shanten number L of a hand at all?  A superset, per suit group i (0..2 number suits, 3 honours),
+// as 3-bit-field masks (bit 3j = j-th tile of the group) from the group's non-zero-count fields `hn` of the hand:
+//   standard form: a drawn tile only helps inside a block with a tile the hand already holds, i.e. the same tile or, in a
+//     number suit, a tile at most two ranks away (a block made of new tiles only is never cheaper than one seeded by a
+//     left-over tile, and 3k+1 tiles cannot all sit in k blocks);
+//   seven pairs (closed hands): pairs up a single (a held tile), or ANY new kind while the hand has fewer than 7 kinds --
+//     which lowers min(standard, pairs, orphans) only if the hand's seven-pairs number is already <= L;
+//   thirteen orphans (closed hands): any terminal / honour -- only if the hand's orphans number is already <= L.
+// A hand that holds all four copies of some tile is not pruned at all: the tables know that its left-over fourth copy cannot
+// seed a pair, so there an unrelated new tile can be the cheaper seed (333p + EEEE: any draw makes it tenpai).
+// Checked against calc_all on 1.5 M random hands of every size and shape class in tests/host/algo_check.hip (19 M once).
+struct ShDrawRule {
+    bool all, yao;  // probe every tile / add the terminals and honours
+};
+MJD ShDrawRule sh_draw_rule(int L, int len_div3, int pairs, int kinds, int kpairs, int kkinds, bool has_quad) {
+    ShDrawRule r;
+    const bool closed = len_div3 == 4;
+    r.yao = closed && 13 - kkinds - (kpairs > 0) <= L;
+    r.all = has_quad || (closed && kinds < 7 && 6 - pairs + (7 - kinds) <= L);
+    return r;
+}
+MJD u32 sh_draw_candidate_fields(u32 hn, int group, ShDrawRule r) {
+    constexpr u32 ALL9 = 0x1249249u, ALL7 = 0x49249u;
+    u32 c = group < 3 ? (hn | (hn << 3) | (hn << 6) | (hn >> 3) | (hn >> 6)) & ALL9 : hn;
+    if (r.yao) c |= group < 3 ? 0x1000001u : ALL7;
+    if (r.all) c = group < 3 ? ALL9 : ALL7;
+    return c;
 }
 // normal-form shanten from the final entry + chitoi / kokushi (shanten.rs:139-150)
 MJD int sh_finish(int fin, int len_div3, int pairs, int kinds, int kpairs, int kkinds) {

@@ -383,6 +383,7 @@ struct SpChunk {
     u8 cnt[SP_NS][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds (shanten.rs:104-137)
     u8 tiles[SP_NS][36], kinds[SP_NS][16];
     u8 n_tiles[SP_NS], n_kinds[SP_NS], n_hk[SP_NS];  // required tiles, safe discard kinds, tile kinds in the hand
+    u32 cf[SP_NS][4];       // per suit group: field mask of the draws worth probing (P1 -> P2b; tiles / n_tiles hold their list until P4a)
     unsigned short inv[SP_NS];   // ceil(65536 / n_kinds): item index -> (tile ordinal, kind ordinal) without a division
     unsigned short queue[128];   // ring of kept (state, tile ordinal, kind ordinal) items waiting for the dense insert pass
 };
@@ -435,6 +436,14 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         C->row[s][i] = sh_load(ST, i, key);
         C->cnt[s][i] = (u8)(i == 0 ? S.h.n_pairs() : i == 1 ? S.h.n_kinds() : i == 2 ? S.h.n_yao_pairs() : S.h.n_yao_kinds());
         if (i == 0) C->n_hk[s] = (u8)__popcll(S.h.nonzero_mask());
+        // draws worth a probe in suit group i: left in the wall and able to lower a shanten number at all (mj_algo.h)
+        const int sh27 = (i & 1) * 27;
+        const u32 hn = (u32)(Hand::nz_fields(i < 2 ? S.h.mp : S.h.sz) >> sh27) & 0x7FFFFFFu;
+        const u32 wn = (u32)(Hand::nz_fields(i < 2 ? S.w.mp : S.w.sz) >> sh27) & 0x7FFFFFFu;
+        const ShDrawRule rule = sh_draw_rule(L, ld3, S.h.n_pairs(), S.h.n_kinds(), S.h.n_yao_pairs(), S.h.n_yao_kinds(), S.h.has_quad());
+        C->cf[s][i] = sh_draw_candidate_fields(hn, i, rule) & wn;
+#pragma unroll
+        for (int q = i; q < 17; q += 4) C->keepw[s][q] = 0;
     }
     mj_team_sync<SP_NT>();
     for (int task = tid; task < n * 6; task += SP_NT) {
@@ -447,14 +456,28 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         const int s = task >> 2, i = task & 3;
         const u64 pr = i == 0 ? C->r2[s][3] : i == 1 ? C->r2[s][1] : C->r2[s][0];
         C->r3[s][i] = sh_merge(pr, C->row[s][i == 3 ? 2 : 3], ld3);
+        // P2b: ascending list of the state's probe-worthy draws, group i at its offset (tiles / n_tiles are free until P4a)
+        const u32 c0 = C->cf[s][0], c1 = C->cf[s][1], c2 = C->cf[s][2];
+        int off = i > 0 ? __popc(c0) : 0;
+        if (i > 1) off += __popc(c1);
+        if (i > 2) off += __popc(c2);
+        u32 c = C->cf[s][i];
+        if (i == 3) C->n_tiles[s] = (u8)(off + __popc(c));
+        for (; c; c &= c - 1) C->tiles[s][off++] = (u8)(9 * i + (((__ffs((int)c) - 1) * 11) >> 5));  // bit 3j -> tile 9 i + j
     }
     mj_team_sync<SP_NT>();
-    // P3a: "+t" probes over (state, tile): which draws lower the shanten number
-    for (int task = tid; task < n * 34; task += SP_NT) {
-        const int s = task / 34, t = task % 34;
-        if (t < 17) C->keepw[s][t] = 0;
+    // P3a: "+t" probes over the packed (state, probe-worthy draw) pairs: which draws lower the shanten number
+    int ct_off[SP_NS + 1];
+    ct_off[0] = 0;
+#pragma unroll
+    for (int s = 0; s < SP_NS; s++) ct_off[s + 1] = ct_off[s] + (s < n ? (int)C->n_tiles[s] : 0);
+    for (int task = tid; task < ct_off[SP_NS]; task += SP_NT) {
+        int s = 0, base = 0;  // static indices only (a dynamically indexed local array would live in scratch)
+#pragma unroll
+        for (int q = 1; q < SP_NS; q++)
+            if (task >= ct_off[q]) { s = q; base = ct_off[q]; }
+        const int t = C->tiles[s][task - base];
         const SpState S = sp_chunk_state(C, s);
-        if (S.w.get(t) == 0) continue;
         const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
         const u64 rt = sh_load(ST, st, C->bkey[s][st] + sh_pow(t));
         const int sh = sh_finish(sh_final(C->r3[s][st], rt, ld3), ld3, (int)C->cnt[s][0] + (hc == 1), (int)C->cnt[s][1] + (hc == 0),

@@ -1,12 +1,17 @@
 // Host-side equivalence checks of the pure device helpers in mortal_amd/csrc/mj_algo.h (no GPU needed): the helpers
 // are compiled __host__ __device__ here and the optimised formulations are compared with the reference-shaped ones.
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -o algo_check tests/host/algo_check.hip && ./algo_check
+#include <hip/hip_runtime.h>
 #define MJD __host__ __device__ inline
 #define MJDN __device__ __noinline__
+// the bit-count intrinsics of the device headers are __device__-only; the compiler builtins serve both passes
+#define __popcll(x) __builtin_popcountll(x)
+#define __popc(x) __builtin_popcount(x)
 #include "../../mortal_amd/csrc/mj_algo.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 
 static u64 random_row(std::mt19937_64& g, int max_nib) {
@@ -15,7 +20,87 @@ static u64 random_row(std::mt19937_64& g, int max_nib) {
     return r;
 }
 
-int main() {
+// Draw-candidate property (mj_algo.h sh_draw_candidate_fields): every draw that lowers calc_all of a 3k+1-tile hand is inside
+// the candidate set the SP kernel probes.  Needs the shanten tables: argv[1] = the MJT1 payload (mortal_amd.tables.payload()).
+#include <vector>
+#ifndef DRAW_CHECK_ITERS
+#define DRAW_CHECK_ITERS 1500000
+#endif
+#ifndef DRAW_CHECK_SEED
+#define DRAW_CHECK_SEED 777
+#endif
+static int check_draw_candidates(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { printf("cannot open %s\n", path); return 10; }
+    std::vector<unsigned char> buf;
+    unsigned char tmp[65536];
+    size_t k;
+    while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + k);
+    fclose(f);
+    uint32_t ns, nj;
+    memcpy(&ns, &buf[4], 4);
+    memcpy(&nj, &buf[8], 4);
+    std::vector<uint64_t> su(ns), ji(nj);
+    for (uint32_t i = 0; i < ns; i++) for (int b = 0; b < 5; b++) su[i] |= (uint64_t)buf[16 + (size_t)i * 5 + b] << (8 * b);
+    for (uint32_t i = 0; i < nj; i++) for (int b = 0; b < 5; b++) ji[i] |= (uint64_t)buf[16 + (size_t)ns * 5 + (size_t)i * 5 + b] << (8 * b);
+    MjTablesDev T{};
+    T.suhai = su.data();
+    T.n_suhai = ns;
+    T.jihai = ji.data();
+    T.n_jihai = nj;
+    std::mt19937_64 g(DRAW_CHECK_SEED);
+    long hands = 0, lowering = 0, cand_total = 0;
+    for (int it = 0; it < DRAW_CHECK_ITERS; it++) {
+        const int ld3 = it % 5 == 0 ? (int)(g() % 4) : 4, n_tiles = 3 * ld3 + 1, mode = it % 7;
+        int cnt[34] = {0};
+        // tile pool of the mode: everything / few kinds / one suit + honours / terminals + honours / triplet-heavy
+        int pool[34], np = 0;
+        if (mode <= 2) for (int t = 0; t < 34; t++) pool[np++] = t;
+        else if (mode == 3) { const int kk = 2 + (int)(g() % 6); while (np < kk) { int t = (int)(g() % 34), dup = 0; for (int i = 0; i < np; i++) dup |= pool[i] == t; if (!dup) pool[np++] = t; } }
+        else if (mode == 4) { const int s0 = 9 * (int)(g() % 3); for (int t = s0; t < s0 + 9; t++) pool[np++] = t; for (int t = 27; t < 34; t++) if (g() & 1) pool[np++] = t; }
+        else if (mode == 5) { const int yao[13] = {0, 8, 9, 17, 18, 26, 27, 28, 29, 30, 31, 32, 33}; for (int i = 0; i < 13; i++) pool[np++] = yao[i]; for (int i = 0; i < 3; i++) pool[np++] = (int)(g() % 27); }
+        else { const int kk = 4 + (int)(g() % 3); while (np < kk) { int t = (int)(g() % 34), dup = 0; for (int i = 0; i < np; i++) dup |= pool[i] == t; if (!dup) pool[np++] = t; } }
+        if (np * 4 < n_tiles) continue;
+        for (int placed = 0; placed < n_tiles;) {
+            const int t = pool[g() % np];
+            if (cnt[t] < 4) { cnt[t]++; placed++; }
+        }
+        Hand h = {0, 0};
+        for (int t = 0; t < 34; t++) for (int c = 0; c < cnt[t]; c++) h.inc(t);
+        const int base = calc_all(T, h, ld3), nk = h.n_kinds();
+        u32 cf[4];
+        for (int i = 0; i < 4; i++) {
+            const u32 hn = (u32)(Hand::nz_fields(i < 2 ? h.mp : h.sz) >> ((i & 1) * 27)) & 0x7FFFFFFu;
+            cf[i] = sh_draw_candidate_fields(hn, i, sh_draw_rule(base, ld3, h.n_pairs(), nk, h.n_yao_pairs(), h.n_yao_kinds(), h.has_quad()));
+            cand_total += __builtin_popcount(cf[i]);
+        }
+        for (int t = 0; t < 34; t++) {
+            if (cnt[t] == 4) continue;
+            Hand x = h;
+            x.inc(t);
+            if (calc_all(T, x, ld3) < base) {
+                lowering++;
+                const int i = t < 27 ? t / 9 : 3, j = t < 27 ? t % 9 : t - 27;
+                if (!((cf[i] >> (3 * j)) & 1)) {
+                    printf("draw candidate missed: tile %d lowers %d, len_div3 %d, hand", t, base, ld3);
+                    for (int q = 0; q < 34; q++) printf(" %d", cnt[q]);
+                    printf("\n");
+                    return 11;
+                }
+            }
+        }
+        hands++;
+    }
+    printf("draw candidates cover every shanten-lowering draw: %ld hands, %ld lowering draws, %.1f candidates per hand\n", hands, lowering,
+           (double)cand_total / (double)hands);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) {
+        const int rc = check_draw_candidates(argv[1]);
+        if (rc) return rc;
+    }
     std::mt19937_64 g(12345);
     long n = 0;
     for (int it = 0; it < 2000000; it++) {

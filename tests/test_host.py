@@ -117,9 +117,14 @@ def test_device_helpers_host_equivalence(tmp_path):
     src = os.path.join(os.path.dirname(__file__), "host", "algo_check.hip")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-value", "-o", exe, src],
                           stderr=subprocess.DEVNULL)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    from mortal_amd import tables
+
+    payload = tmp_path / "mjtables.bin"
+    payload.write_bytes(tables.payload())
+    out = subprocess.run([exe, str(payload)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "sh_final == reference-shaped loop" in out.stdout
+    assert "draw candidates cover every shanten-lowering draw" in out.stdout  # the SP kernel's pruned "+t" probe set
 
 
 def test_sp_kernel_isa_has_no_flat_or_spilled_hot_paths(tmp_path):
