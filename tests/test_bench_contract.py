@@ -1,0 +1,64 @@
+"""The driver's bench.py contract, checked on the committed line of the last GPU run (profiles/r02_bench_v4.json) and on
+bench.py's argument defaults — no GPU needed.  Guards against drift between the JSON the driver parses, BASELINE.json's
+metric, and the numbers quoted in DESIGN.md §7."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r02_bench_v4.json")) as f:
+        return json.load(f)
+
+
+def test_committed_bench_line_has_the_contract_keys_and_consistent_arithmetic():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert d["unit"] == "env steps/s" and d["metric"].startswith("env steps/sec") and base["metric"].startswith("env steps/sec")
+    assert "65536" in d["metric"] and "65536" in base["metric"] and base["published"] == {}  # nothing published => vs_baseline null
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = env steps of the timed region / its duration; a cycle advances every live table by one step
+    tables = d["config"]["tables_per_gpu"] * d["n_gpus"]
+    steps_per_cycle = d["value"] * d["ms_per_step"] / 1e3
+    assert 0.95 * tables <= steps_per_cycle <= tables  # finished tables are refilled, a few are between games
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2  # no wasted re-reads / rewrites
+    s = d["roofline_sp"]
+    assert s["bound"] == "valu" and abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-6
+    assert abs(s["achieved"] - s["valu_insts_per_state"] * s["states_per_launch"] / (s["avg_launch_ms"] * 1e-3) / 1e9) / s["achieved"] < 1e-3
+    k = d["kernel_ms_per_step"]
+    assert abs(sum(k.values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.02  # the per-kernel split covers the cycle
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
+    for w in ("obs_v3_random", "obs_v4_random_no_preroll", "obs_v4_greedy"):
+        assert d["workloads"][w]["value"] > 0
+
+
+def test_design_quotes_the_committed_numbers():
+    d = _line()
+    with open(os.path.join(ROOT, "DESIGN.md")) as f:
+        text = f.read()
+    head = f"{d['value'] / 1e6:.2f} M env steps/s"
+    assert head in text, head
+    assert f"{d['ms_per_step']:.1f} ms/cycle" in text
+    assert f"`mj_k_sp` {d['kernel_ms_per_step']['mj_k_sp']:.1f} ms" in text
+
+
+def test_bench_defaults_match_the_driver_contract():
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        src = f.read()
+    # no flags => one GPU and a K/W that finish within minutes; the flags the driver passes exist
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert re.search(r'add_argument\("%s"' % flag, src), flag
+    assert re.search(r'add_argument\("--gpus", type=int, default=1', src)
+    # the oracle is only touched by the cpu_baseline leg
+    assert "oracle_lib" in src and src.count("import oracle_lib") <= 2
