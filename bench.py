@@ -123,6 +123,25 @@ def cpu_baseline(version, budget_s=12.0, n_tables=16):
                        f"not buildable here (no rustc)")
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _self_launch(n):
+    """Re-exec this script under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1)."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MORTAL_AMD_BENCH_SELF_LAUNCH="1")
+    return subprocess.call(cmd, env=env)
+
+
 def _phase_ticks(pool):
     """Optional extra (`sp_phases`): never let it cost the benchmark line."""
     try:
@@ -231,6 +250,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for --gpus N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true", help="skip the extra workloads (obs v3, no pre-roll, greedy policy)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: spawn / join the --gpus N ranks, all-reduce one token over --dist-backend, print the rank "
+                         "count on rank 0 and exit before any GPU work (CPU test of the launcher: tests/test_bench_contract.py)")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-tables", type=int, default=16, help=argparse.SUPPRESS)
@@ -239,10 +261,36 @@ def main():
         print(json.dumps(_cpu_worker(args.version, args.cpu_budget, args.cpu_tables, args.cpu_worker)))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a bare shell: launch the N ranks ourselves (one process per GPU), exactly the command
+        # line the driver uses.  The reference covers all games from one process (arena/game.rs:286-296,
+        # one_vs_three.rs:55-60); here the ranks are independent shards and rank 0 prints the whole-job line.
+        sys.exit(_self_launch(args.gpus))
+
     import torch
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without torchrun and let it spawn the ranks)")
+    if args.launch_check:
+        import torch.distributed as dist
+
+        if world > 1:
+            dist.init_process_group("gloo" if args.dist_backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            t = torch.ones(1, dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                t = t.cuda(local_rank := int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "ranks": world, "gpus": args.gpus, "self_launched": os.environ.get("MORTAL_AMD_BENCH_SELF_LAUNCH") == "1"}))
+        return
+    if args.dist_backend == "nccl" and world > max(1, torch.cuda.device_count()):
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node has {torch.cuda.device_count()} "
+                         f"(--dist-backend gloo shares one GPU between the ranks: a smoke test of the code path, not a measurement)")
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     # one rank per GPU over RCCL ("nccl"); `--dist-backend gloo` + fewer GPUs than ranks is the smoke test of this code path
     # on a single-GPU box (ranks share device 0, the three small collectives go through host tensors)
@@ -328,6 +376,9 @@ def main():
             "value": steps / dt,
             "unit": "env steps/s",
             "n_gpus": world,
+            "ranks": world,
+            "dist_backend": (args.dist_backend if world > 1 else None),
+            "gpus_visible_per_rank": torch.cuda.device_count(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

@@ -62,3 +62,21 @@ def test_bench_defaults_match_the_driver_contract():
     assert re.search(r'add_argument\("--gpus", type=int, default=1', src)
     # the oracle is only touched by the cpu_baseline leg
     assert "oracle_lib" in src and src.count("import oracle_lib") <= 2
+
+
+def test_bench_gpus_n_spawns_its_own_ranks_and_refuses_a_mismatch():
+    """`python bench.py --gpus 2` from a bare shell launches two ranks itself (torch.distributed.run, rendezvous on 127.0.0.1);
+    a WORLD_SIZE that differs from --gpus is an error, never a silent single-rank run (`--gpus N` was ignored).
+    The reference covers all games from one process (arena/game.rs:286-296, one_vs_three.rs:55-60)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"launch_check": True, "ranks": 2, "gpus": 2, "self_launched": True}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in bad.stderr
