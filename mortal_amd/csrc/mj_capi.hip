@@ -177,6 +177,17 @@ int mj_tables_upload(const void* payload, size_t size) {
     if (upload(suhai, &d_s) || upload(jihai, &d_j) || upload(keys, &d_k) || upload(divs, &d_d) || upload(ahash, &d_h)) return -1;
     g_tables.dev = {d_s, ns, d_j, nj, d_k, d_h, d_d, na};
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_mj_tables), &g_tables.dev, sizeof(MjTablesDev)));
+    {   // table-id shanten (mj_sptab.h): row ids, merge closure, optimal-entry table, per-key wait / keep masks
+        SpTabHost H;
+        if (!sp_tab_build(suhai.data(), ns, jihai.data(), nj, H)) return fail("sp_tab_build: " + H.error);
+        u8 *d_is, *d_ij, *d_m;
+        SpRec *d_o, *d_ws, *d_wj;
+        if (upload(H.id_su, &d_is) || upload(H.id_ji, &d_ij) || upload(H.mrg, &d_m) || upload(H.opt, &d_o) || upload(H.wk_su, &d_ws) ||
+            upload(H.wk_ji, &d_wj))
+            return -1;
+        SpTabDev st{d_is, d_ij, d_m, d_o, d_ws, d_wj, ns, nj, H.zero_id};
+        HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_sp_tab), &st, sizeof(SpTabDev)));
+    }
     auto g = build_gather();
     g_tables.n_gather = (int)g.size();
     for (int c = 0, k = 0; c <= SNAP_NCH; c++) {  // entries are in field order = ascending dst_off

@@ -24,13 +24,19 @@
 #include <type_traits>
 
 #include "mj_rules.h"
+#include "mj_sptab.h"
+
+__constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_upload)
 
 #define SP_THREADS 256
 #define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
 #ifndef SP_NS
-#define SP_NS 8                // states per expansion chunk (one chunk per wavefront)
+#define SP_NS 16               // states per expansion chunk (one chunk per wavefront)
+#endif
+#ifndef SP_ITEM_CAP
+#define SP_ITEM_CAP 128        // draw items (state, required tile) per sub-batch of a chunk
 #endif
 #ifndef SP_WGS
 #define SP_WGS 4               // resident workgroups per CU the kernel is compiled for (register budget 512 / SP_WGS per lane)
@@ -358,44 +364,45 @@ __device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense expansion / level-0 probe: SP_NS states of one level at a time PER WAVEFRONT, every phase a THREAD-PER-TASK pass
-// over the 64 lanes (tasks = (state, suit), (state, merge), (state, tile), (state, draw tile, discard kind) ...), separated
-// by wave-level LDS hand-offs (mj_team_sync<64>): no workgroup barrier inside a level, four chunks in flight per workgroup.
-// `safe` = the tile kinds d in the hand with shanten(h - d) <= L.  Only those can be shanten-keeping discards after a
-// required draw t: shanten(h + t - d) == L - 1 needs shanten(h - d) <= L, since one more tile lowers a shanten number
-// (normal, chiitoi and kokushi form alike) by at most one; the (t, d) probes run over these kinds only.
-// All probes of a state share the partial merges of its four base rows (mj_algo.h sh_merge).
+// over the 64 lanes, separated by wave-level LDS hand-offs (mj_team_sync<64>): no workgroup barrier inside a level, four
+// chunks in flight per workgroup.  Shanten numbers are never computed here: the required draws of a state and, after each
+// of them, the shanten-keeping discards come from the table-id formulation of mj_sptab.h —
+//   P0  (state, suit)  : suit key -> row id; seven-pairs / orphans counters
+//   P1  (state, suit)  : id of the merge of the other three suits (two byte gathers), optimal-entry record, the key's wait /
+//                        keep records -> the suit's part of "draws that lower the normal-form number"; pair merges for P2
+//   P1c (state)        : required draws = closed form over normal form / seven pairs / orphans (sp_req_set), wall applied
+//   P2  (state, draw t): g = h + t differs from h in ONE suit: its new row id, then per suit the optimal entries against the
+//                        other three (table walks) and the keep masks -> shanten-keeping discards of g (sp_keep_set)
+//   P3  (state)        : child-list layout (reference order: draw tile ascending, plain before red, discard ascending)
+//   P4  (edge)         : hash-set insert of h + t - d, child-list entry
+// A state with a suit key whose neighbour lies past the end of the reference's table (SPT_FALLBACK, 8 one-suit 13-tile
+// patterns) takes the brute-force loops of the reference instead (sp_*_brute).
 struct SpChunk {
     u64 k[SP_NS][4];        // state keys (hand.mp, hand.sz | akas, wall.mp, wall.sz | akas)
     u64 dk[SP_NS];          // state ids
-    u64 r2[SP_NS][6];       // merges of two base rows (suit pairs 01 02 03 12 13 23)
-    u64 r3[SP_NS][4];       // per suit: merge of the three OTHER base rows
-    union {
-        u64 row[SP_NS][4];      // base table rows of the four suits (dead after the partial merges P1 / P2)
-        u64 V[SP_NS][13][3];    // per safe discard kind d and k-th other suit: merge(two untouched suits, row of h - d) (P4b on)
-    };
-    u64 req[SP_NS], safe[SP_NS];
-    u32 bkey[SP_NS][4];     // base-5 suit keys
+    u64 req[SP_NS];         // required draws
+    SpRec keep[SP_NS][4];   // keep records of the four suit keys
+    u32 key[SP_NS][4];      // base-5 suit keys
     u32 slot[SP_NS];
-    u32 keepw[SP_NS][17];   // per required-tile ORDINAL ti: 16-bit mask over the safe-kind ordinals, two per word
-    int item_off[SP_NS + 1];  // prefix sums of n_tiles * n_kinds
-    int child_base[SP_NS];
-    unsigned short coff[SP_NS][34];  // per required-tile ordinal: offset of its first child inside the state's child list
+    unsigned short wn[SP_NS][4];  // per suit: tiles that lower the normal-form number (9 bits) | fallback << 15
+    u8 id[SP_NS][4];        // row ids
+    u8 r2[SP_NS][8];        // ids of the pair merges 01 02 03 12 13 23
+    u8 r3[SP_NS][4];        // per suit: id of the merge of the three OTHER suits
     u8 cnt[SP_NS][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds (shanten.rs:104-137)
-    u8 tiles[SP_NS][36], kinds[SP_NS][16];
-    u8 n_tiles[SP_NS], n_kinds[SP_NS], n_hk[SP_NS];  // required tiles, safe discard kinds, tile kinds in the hand
-    u32 cf[SP_NS][4];       // per suit group: field mask of the draws worth probing (P1 -> P2b; tiles / n_tiles hold their list until P4a)
-    unsigned short inv[SP_NS];   // ceil(65536 / n_kinds): item index -> (tile ordinal, kind ordinal) without a division
-    unsigned short queue[128];   // ring of kept (state, tile ordinal, kind ordinal) items waiting for the dense insert pass
+    u8 fin[SP_NS];          // normal-form final value (shanten + 1)
+    u8 fb[SP_NS];           // brute-force path
+    u8 n_tiles[SP_NS];      // required draws
+    int child_base[SP_NS];
+    int etot[SP_NS];        // kept (draw, discard) pairs of the state
+    // the draw items (state, required tile) of the current sub-batch of states
+    u64 kept[SP_ITEM_CAP];                  // shanten-keeping discards after the draw
+    unsigned short item[SP_ITEM_CAP];       // state | tile << 4
+    unsigned short coff[SP_ITEM_CAP];       // offset of the item's first child inside the state's child list
+    unsigned short eoff[SP_ITEM_CAP + 2];   // prefix sums of the kept discards over the items
 };
 #define SP_NT 64  // co-operating threads of a chunk
-constexpr bool sp_item_div_is_exact() {  // (local * ceil(65536 / nk)) >> 16 == local / nk over the whole item space of a state
-    for (int nk = 2; nk <= 16; nk++)
-        for (int local = 0; local < 34 * 16; local++)
-            if (((local * ((65536 + nk - 1) / nk)) >> 16) != local / nk) return false;
-    return true;
-}
-static_assert(sp_item_div_is_exact(), "item index reciprocal");
-static_assert(SP_NS <= 16, "queue entries hold the state in 4 bits");
+static_assert(SP_NS <= 16, "item entries hold the state in 4 bits");
+static_assert(SP_ITEM_CAP >= 34 && SP_ITEM_CAP <= 1024, "a sub-batch holds at least one state's draws");
 
 MJD SpState sp_chunk_state(const SpChunk* C, int s) {
     SpState S;
@@ -406,14 +413,15 @@ MJD SpState sp_chunk_state(const SpChunk* C, int s) {
     S.akas = (u32)((C->k[s][1] >> 48) & 7) | ((u32)((C->k[s][3] >> 48) & 7) << 3);
     return S;
 }
-MJD u32 sp_chunk_keep(const SpChunk* C, int s, int ti) { return (C->keepw[s][ti >> 1] >> (16 * (ti & 1))) & 0xFFFFu; }
 MJD bool sp_aka_in_wall(const SpState& S, int t) {
     return (t == T_5M && (S.akas & 8)) || (t == T_5P && (S.akas & 16)) || (t == T_5S && (S.akas & 32));
 }
+__device__ __noinline__ u64 sp_req_brute_dev(Hand h, int ld3, int L) { return sp_req_brute(c_mj_tables, h, ld3, L); }
+__device__ __noinline__ u64 sp_keep_brute_dev(Hand g, int ld3, int Tg) { return sp_keep_brute(c_mj_tables, g, ld3, Tg); }
 
-// Passes P0-P3, shared by the expansion (L >= 1) and the level-0 probe (L == 0): state keys, base rows, partial merges
-// and the 34 "+t" (and for L >= 1 "-t") shanten probes of every state of the chunk -> req, safe.
-__device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunk* C, const ShTab& ST, int first, int n, int L) {
+// Passes P0-P1c, shared by the expansion (L >= 1) and the level-0 probe (L == 0): state keys, row ids, optimal entries ->
+// req[s] = the draws left in the wall that lower the shanten number of state s.
+__device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunk* C, const SpTabG& TG, int first, int n, int L) {
     const int tid = threadIdx.x & (SP_NT - 1);
     const int ld3 = X->len_div3;
     for (int task = tid; task < n * 4; task += SP_NT) {
@@ -423,8 +431,6 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         if (j == 0) {
             C->slot[s] = slot;
             C->dk[s] = Wg->tag[slot] & ~(1ull << 63);
-            C->req[s] = 0;
-            C->safe[s] = 0;
         }
     }
     mj_team_sync<SP_NT>();
@@ -432,79 +438,43 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         const int s = task >> 2, i = task & 3;
         const SpState S = sp_chunk_state(C, s);
         const u32 key = i == 0 ? suit_key9(S.h.mp) : i == 1 ? suit_key9(S.h.mp >> 27) : i == 2 ? suit_key9(S.h.sz) : suit_key7(S.h.sz >> 27);
-        C->bkey[s][i] = key;
-        C->row[s][i] = sh_load(ST, i, key);
+        C->key[s][i] = key;
+        C->id[s][i] = (u8)spt_id(TG, i, key);
         C->cnt[s][i] = (u8)(i == 0 ? S.h.n_pairs() : i == 1 ? S.h.n_kinds() : i == 2 ? S.h.n_yao_pairs() : S.h.n_yao_kinds());
-        if (i == 0) C->n_hk[s] = (u8)__popcll(S.h.nonzero_mask());
-        // draws worth a probe in suit group i: left in the wall and able to lower a shanten number at all (mj_algo.h)
-        const int sh27 = (i & 1) * 27;
-        const u32 hn = (u32)(Hand::nz_fields(i < 2 ? S.h.mp : S.h.sz) >> sh27) & 0x7FFFFFFu;
-        const u32 wn = (u32)(Hand::nz_fields(i < 2 ? S.w.mp : S.w.sz) >> sh27) & 0x7FFFFFFu;
-        const ShDrawRule rule = sh_draw_rule(L, ld3, S.h.n_pairs(), S.h.n_kinds(), S.h.n_yao_pairs(), S.h.n_yao_kinds(), S.h.has_quad());
-        C->cf[s][i] = sh_draw_candidate_fields(hn, i, rule) & wn;
-#pragma unroll
-        for (int q = i; q < 17; q += 4) C->keepw[s][q] = 0;
     }
     mj_team_sync<SP_NT>();
-    for (int task = tid; task < n * 6; task += SP_NT) {
-        const int s = task / 6, p = task % 6;
-        const int a = p < 3 ? 0 : p < 5 ? 1 : 2, b = p < 3 ? p + 1 : p < 5 ? p - 1 : 3;
-        C->r2[s][p] = sh_merge(C->row[s][a], C->row[s][b], ld3);
-    }
-    mj_team_sync<SP_NT>();
-    for (int task = tid; task < n * 4; task += SP_NT) {  // 0: (1,2)+3, 1: (0,2)+3, 2: (0,1)+3, 3: (0,1)+2
+    for (int task = tid; task < n * 4; task += SP_NT) {
         const int s = task >> 2, i = task & 3;
-        const u64 pr = i == 0 ? C->r2[s][3] : i == 1 ? C->r2[s][1] : C->r2[s][0];
-        C->r3[s][i] = sh_merge(pr, C->row[s][i == 3 ? 2 : 3], ld3);
-        // P2b: ascending list of the state's probe-worthy draws, group i at its offset (tiles / n_tiles are free until P4a)
-        const u32 c0 = C->cf[s][0], c1 = C->cf[s][1], c2 = C->cf[s][2];
-        int off = i > 0 ? __popc(c0) : 0;
-        if (i > 1) off += __popc(c1);
-        if (i > 2) off += __popc(c2);
-        u32 c = C->cf[s][i];
-        if (i == 3) C->n_tiles[s] = (u8)(off + __popc(c));
-        for (; c; c &= c - 1) C->tiles[s][off++] = (u8)(9 * i + (((__ffs((int)c) - 1) * 11) >> 5));  // bit 3j -> tile 9 i + j
+        const u32 i0 = C->id[s][0], i1 = C->id[s][1], i2 = C->id[s][2], i3 = C->id[s][3];
+        // first pair of the other three suits: (1,2) (0,2) (0,1) (0,1); third: 3 3 3 2
+        const u32 pa = i == 0 ? i1 : i0, pb = i <= 1 ? i2 : i1, pc = i == 3 ? i2 : i3;
+        const u32 r2 = spt_merge(TG, pa, pb);
+        C->r2[s][i == 0 ? 3 : i == 1 ? 1 : 0] = (u8)r2;
+        if (i < 3) C->r2[s][i == 0 ? 2 : i == 1 ? 4 : 5] = (u8)spt_merge(TG, i == 0 ? i0 : i == 1 ? i1 : i2, i3);  // (i, 3)
+        const u32 r3 = spt_merge(TG, r2, pc);
+        C->r3[s][i] = (u8)r3;
+        const u32 key = C->key[s][i], myid = i == 0 ? i0 : i == 1 ? i1 : i == 2 ? i2 : i3;
+        const bool inside = spt_in_table(TG, i, key);
+        const SpRec o = spt_opt(TG, ld3, r3, myid);
+        const SpRec w = spt_rec(TG, i, inside ? key : 0u, 0), kp = spt_rec(TG, i, inside ? key : 0u, 1);
+        C->wn[s][i] = (unsigned short)(spt_wait_tiles(w, o) | ((!inside || (w.w & SPT_FALLBACK)) ? 0x8000u : 0u));
+        C->keep[s][i] = kp;
+        if (i == 3) C->fin[s] = (u8)spt_fin(o);
     }
     mj_team_sync<SP_NT>();
-    // P3a: "+t" probes over the packed (state, probe-worthy draw) pairs: which draws lower the shanten number
-    int ct_off[SP_NS + 1];
-    ct_off[0] = 0;
-#pragma unroll
-    for (int s = 0; s < SP_NS; s++) ct_off[s + 1] = ct_off[s] + (s < n ? (int)C->n_tiles[s] : 0);
-    for (int task = tid; task < ct_off[SP_NS]; task += SP_NT) {
-        int s = 0, base = 0;  // static indices only (a dynamically indexed local array would live in scratch)
-#pragma unroll
-        for (int q = 1; q < SP_NS; q++)
-            if (task >= ct_off[q]) { s = q; base = ct_off[q]; }
-        const int t = C->tiles[s][task - base];
+    if (tid < n) {
+        const int s = tid;
         const SpState S = sp_chunk_state(C, s);
-        const int st = sh_suit(t), hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
-        const u64 rt = sh_load(ST, st, C->bkey[s][st] + sh_pow(t));
-        const int sh = sh_finish(sh_final(C->r3[s][st], rt, ld3), ld3, (int)C->cnt[s][0] + (hc == 1), (int)C->cnt[s][1] + (hc == 0),
-                                 (int)C->cnt[s][2] + (yao && hc == 1), (int)C->cnt[s][3] + (yao && hc == 0));
-        if (sh - L == -1) atomicOr((unsigned long long*)&C->req[s], 1ull << t);
-    }
-    // P3b (L >= 1): "-d" probes over the tile kinds of each hand only (packed tasks: a hand has ~9 of the 34 kinds) -> `safe`:
-    // only discards with shanten(h - d) <= L can keep shanten after a required draw
-    if (L > 0) {
-        int hk_off[SP_NS + 1];
-        hk_off[0] = 0;
-#pragma unroll
-        for (int s = 0; s < SP_NS; s++) hk_off[s + 1] = hk_off[s] + (s < n ? (int)C->n_hk[s] : 0);
-        for (int task = tid; task < hk_off[SP_NS]; task += SP_NT) {
-            int s = 0, base = 0;
-#pragma unroll
-            for (int q = 1; q < SP_NS; q++)
-                if (task >= hk_off[q]) { s = q; base = hk_off[q]; }
-            const SpState S = sp_chunk_state(C, s);
-            u64 m = S.h.nonzero_mask();
-            for (int k = task - base; k > 0; k--) m &= m - 1;
-            const int d = __ffsll((long long)m) - 1, sd = sh_suit(d), hc = S.h.get(d), yao = (int)((YAOKYUU_MASK >> d) & 1);
-            const u64 rd = sh_load(ST, sd, C->bkey[s][sd] - sh_pow(d));
-            const int sh = sh_finish(sh_final(C->r3[s][sd], rd, ld3), ld3, (int)C->cnt[s][0] - (hc == 2), (int)C->cnt[s][1] - (hc == 1),
-                                     (int)C->cnt[s][2] - (yao && hc == 2), (int)C->cnt[s][3] - (yao && hc == 1));
-            if (sh <= L) atomicOr((unsigned long long*)&C->safe[s], 1ull << d);
-        }
+        const u32 w0 = C->wn[s][0], w1 = C->wn[s][1], w2 = C->wn[s][2], w3 = C->wn[s][3];
+        const bool fb = ((w0 | w1 | w2 | w3) & 0x8000u) != 0;
+        const u64 waitN = (u64)(w0 & 0x1FF) | ((u64)(w1 & 0x1FF) << 9) | ((u64)(w2 & 0x1FF) << 18) | ((u64)(w3 & 0x1FF) << 27);
+        u64 req;
+        if (fb) req = sp_req_brute_dev(S.h, ld3, L);
+        else req = sp_req_set(ld3, L, (int)C->fin[s], waitN, (int)C->cnt[s][0], (int)C->cnt[s][1], (int)C->cnt[s][2], (int)C->cnt[s][3], sp_count_sets(S.h));
+        req &= S.w.nonzero_mask();
+        C->req[s] = req;
+        C->fb[s] = (u8)fb;
+        C->n_tiles[s] = (u8)__popcll(req);
     }
     mj_team_sync<SP_NT>();
 }
@@ -515,8 +485,8 @@ __device__ __noinline__ void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(C);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const ShTab ST = sh_tab(c_mj_tables);
-    sp_chunk_probe(Wg, X, C, ST, first, n, 0);
+    const SpTabG TG = sp_tab_g(c_sp_tab);
+    sp_chunk_probe(Wg, X, C, TG, first, n, 0);
     const int s = threadIdx.x & (SP_NT - 1);
     if (s < n) {
         const SpState S = sp_chunk_state(C, s);
@@ -560,185 +530,183 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(C);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const ShTab ST = sh_tab(c_mj_tables);
+    const SpTabG TG = sp_tab_g(c_sp_tab);
     const int tid = threadIdx.x & (SP_NT - 1);
     const int ld3 = X->len_div3;
     // optional pass timers (MJ_SP_PROF): wave wall-clock per pass, summed into prof[8..13] by lane 0
     const bool prof = X->prof != nullptr;
-    long long tp0 = prof ? wall_clock64() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0, tp5 = 0;
-    sp_chunk_probe(Wg, X, C, ST, first, n, L);
-    if (prof) tp1 = wall_clock64();
-    // P4a: ascending lists of the required tiles and of the safe discard kinds — one lane per state walks the two bit sets
-    // (~16 short iterations on 8 lanes issue fewer instructions than 34 tasks per state over the whole wavefront)
-    if (tid < n) {
-        const int s = tid;
-        int nt = 0, nk = 0;
-        for (u64 rest = C->req[s]; rest; rest &= rest - 1) C->tiles[s][nt++] = (u8)(__ffsll((long long)rest) - 1);
-        for (u64 rest = C->safe[s]; rest; rest &= rest - 1) C->kinds[s][nk++] = (u8)(__ffsll((long long)rest) - 1);
-        C->n_tiles[s] = (u8)nt;
-        C->n_kinds[s] = (u8)nk;
-        C->inv[s] = (unsigned short)(nk > 1 ? (65536 + nk - 1) / nk : 0);  // nk == 1: handled apart (65536 does not fit)
-    }
-    mj_team_sync<SP_NT>();
-    if (tid == 0) {
-        int off = 0;
-        for (int s = 0; s < n; s++) {
-            C->item_off[s] = off;
-            off += (int)C->n_tiles[s] * (int)C->n_kinds[s];
+    long long tq0 = prof ? wall_clock64() : 0, tq1 = 0;
+    long long acc_list = 0, acc_keep = 0, acc_layout = 0, acc_ins = 0;
+    int n_items_total = 0, n_edges_total = 0;
+    sp_chunk_probe(Wg, X, C, TG, first, n, L);
+    if (prof) tq1 = wall_clock64();
+    const long long t_probe = tq1 - tq0;
+
+    // The draw items (state, required tile) are processed in sub-batches of whole states with at most SP_ITEM_CAP items.
+    for (int sb = 0; sb < n;) {
+        long long tp0 = prof ? wall_clock64() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
+        int se = sb, n_items = 0;  // uniform over the wavefront
+        int my_first = 0;
+        for (int s = sb; s < n; s++) {
+            const int nt = (int)C->n_tiles[s];
+            if (s > sb && n_items + nt > SP_ITEM_CAP) break;
+            if (s == tid) my_first = n_items;
+            n_items += nt;
+            se = s + 1;
         }
-        C->item_off[n] = off;
-    }
-    // P4b: V = merge(two untouched suits, row of h - d), the row gathered again (it was probed in P3: an L2 hit)
-    // tasks over the existing (state, safe kind, other suit) triples only: 3 * n_kinds per state, packed
-    int kind_off[SP_NS + 1];
-    kind_off[0] = 0;
+        // item list: one lane per state walks its required-draw set (ascending)
+        if (tid >= sb && tid < se) {
+            const int s = tid;
+            int it = my_first;
+            for (u64 rest = C->req[s]; rest; rest &= rest - 1) C->item[it++] = (unsigned short)(s | ((__ffsll((long long)rest) - 1) << 4));
+        }
+        mj_team_sync<SP_NT>();
+        if (prof) tp1 = wall_clock64();
+        // P2: the shanten-keeping discards of g = h + t
+        for (int it = tid; it < n_items; it += SP_NT) {
+            const int e = C->item[it], s = e & 15, t = e >> 4;
+            const SpState S = sp_chunk_state(C, s);
+            Hand g = S.h;
+            g.inc(t);
+            const int st = sh_suit(t);
+            const u32 key1 = C->key[s][st] + sh_pow(t);
+            u64 kept;
+            if (C->fb[s] || !spt_in_table(TG, st, key1)) {
+                kept = sp_keep_brute_dev(g, ld3, L - 1);
+            } else {
+                const u32 id1 = spt_id(TG, st, key1);
+                const SpRec o1 = spt_opt(TG, ld3, (u32)C->r3[s][st], id1);
+                u64 keepN = (u64)spt_keep_tiles(spt_rec(TG, st, key1, 1), o1) << (9 * st);
 #pragma unroll
-    for (int s = 0; s < SP_NS; s++) kind_off[s + 1] = kind_off[s] + (s < n ? 3 * (int)C->n_kinds[s] : 0);
-    for (int task = tid; task < kind_off[SP_NS]; task += SP_NT) {
-        int s = 0, base = 0;  // static indices only: a dynamically indexed local array would live in scratch
-#pragma unroll
-        for (int q = 1; q < SP_NS; q++)
-            if (task >= kind_off[q]) { s = q; base = kind_off[q]; }
-        const int local = task - base, ki = (local * 21846) >> 16, k = local - 3 * ki;  // local / 3, local < 39
-        const int d = C->kinds[s][ki], sd = sh_suit(d), st = k + (k >= sd);  // k-th suit != sd
-        int x = -1, y = -1;  // the two suits other than st and sd
-        for (int i = 0; i < 4; i++)
-            if (i != st && i != sd) { if (x < 0) x = i; else y = i; }
-        const u64 rowd = sh_load(ST, sd, C->bkey[s][sd] - sh_pow(d));
-        C->V[s][ki][k] = sh_merge(C->r2[s][sh_pair_idx(x, y)], rowd, ld3);
-    }
-    mj_team_sync<SP_NT>();
-    if (prof) tp2 = wall_clock64();
-    // P5: (state, required t, safe d) probes of h + t - d (d == t never keeps: that is the state itself):
-    // same suit -> final(r3[suit], gathered row of h+t-d); other suit -> final(V[d][suit t], gathered row of h+t)
-    const int n_items = C->item_off[n];
-    auto item_decode = [&](int it, int& s, int& ti, int& ki) {
-        int lo = 0, hi = n;  // largest s with item_off[s] <= it
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (C->item_off[mid] <= it) lo = mid; else hi = mid;
-        }
-        s = lo;
-        const int local = it - C->item_off[s], nk = C->n_kinds[s];
-        ti = nk > 1 ? (local * (int)C->inv[s]) >> 16 : local;  // local < 34 * 13: exact (sp_item_div_is_exact)
-        ki = local - ti * nk;
-    };
-    for (int it = tid; it < n_items; it += SP_NT) {
-        int s, ti, ki;
-        item_decode(it, s, ti, ki);
-        const int t = C->tiles[s][ti], d = C->kinds[s][ki];
-        if (d == t) continue;
-        const SpState S = sp_chunk_state(C, s);
-        const int st = sh_suit(t), sd = sh_suit(d);
-        const int c = S.h.get(d), hct = S.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1), yd = (int)((YAOKYUU_MASK >> d) & 1);
-        const u64 r = sh_load(ST, st, C->bkey[s][st] + sh_pow(t) - (sd == st ? sh_pow(d) : 0u));
-        const int fin = sh_final(sd == st ? C->r3[s][st] : C->V[s][ki][st - (st > sd)], r, ld3);
-        const int pairs = (int)C->cnt[s][0] + (hct == 1) - (c == 2), kinds = (int)C->cnt[s][1] + (hct == 0) - (c == 1);
-        const int kpairs = (int)C->cnt[s][2] + (yt && hct == 1) - (yd && c == 2), kkinds = (int)C->cnt[s][3] + (yt && hct == 0) - (yd && c == 1);
-        if (sh_finish(fin, ld3, pairs, kinds, kpairs, kkinds) - (L - 1) == 0) atomicOr(&C->keepw[s][ti >> 1], 1u << (ki + 16 * (ti & 1)));
-    }
-    mj_team_sync<SP_NT>();
-    if (prof) tp3 = wall_clock64();
-    // P6: child list layout per state (for each required tile `variants(t) * popcount(keep[t])` entries) + node header
-    if (tid < n) {
-        const int s = tid;
-        const SpState S = sp_chunk_state(C, s);
-        int total = 0, sumreq = 0, n_ent = 0;
-        const int nt = C->n_tiles[s];
-        for (int ti = 0; ti < nt; ti++) {
-            const int t = C->tiles[s][ti], wc = S.w.get(t);
-            const int nvar = sp_aka_in_wall(S, t) ? (wc >= 2 ? 2 : 1) : 1;
-            C->coff[s][ti] = (unsigned short)total;
-            const int nkeep = __popc(sp_chunk_keep(C, s, ti));
-            total += nvar * nkeep;
-            n_ent += nkeep ? nvar : 0;
-            sumreq += wc;
-        }
-        int child_base = atomicAdd(&X->n_pool, total);
-        if (child_base + total > SP_POOL) { X->overflow = 1; child_base = 0; total = 0; }
-        C->child_base[s] = child_base;
-        SP_HBM SpNode& node = Wg->node[C->slot[s]];
-        node.child_off = (u32)child_base;
-        node.n_ch = (unsigned short)total;
-        node.sumreq = (u8)(sumreq & 0xFF);
-        node.n_ent = (u8)min(n_ent, 255);
-    }
-    mj_team_sync<SP_NT>();
-    if (prof) tp4 = wall_clock64();
-    // P7: children.  The kept (t, d) of the item space are few (about a third) and an insert is long, so the items are
-    // first compacted through a small ring (wave ballot + prefix), and the inserts run over full wavefronts of kept items:
-    // each inserts its child state(s) (one per existing draw variant of t) into the hash set and leaves its child-list entry
-    // at its place of the reference's order (t, variant, d ascending).
-    auto insert_children = [&](int s, int ti, int ki) {
-        const u32 bits = sp_chunk_keep(C, s, ti);
-        const int t = C->tiles[s][ti], d = C->kinds[s][ki];
-        const SpState S = sp_chunk_state(C, s);
-        const int nk = __popc(bits), rank = __popc(bits & ((1u << ki) - 1));
-        const int cnt = S.w.get(t);
-        const bool aka = sp_aka_in_wall(S, t);
-        for (int variant = 0; variant < 2; variant++) {
-            int vidx, count;  // index of this variant among the tile's existing draw entries; copies of that entry
-            if (!aka) { if (variant == 1) continue; vidx = 0; count = cnt; }
-            else if (variant == 0) { if (cnt < 2) continue; vidx = 0; count = cnt - 1; }
-            else { vidx = cnt >= 2 ? 1 : 0; count = 1; }
-            const int tile = (aka && variant == 1) ? akaize(t) : t;
-            const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;  // akas_in_hand after the draw
-            const int c = S.h.get(d);  // d != t: the draw does not change its count
-            int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
-            if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
-            else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
-            else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
-            bool fresh;
-            const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), S, tile, dt, fresh);
-            if (fresh && cs >= 0) {
-                const int idx = atomicAdd(&X->n_list, 1);
-                if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
-                else X->overflow = 1;
+                for (int q = 0; q < 3; q++) {
+                    const int u = q + (q >= st);                                    // q-th suit != st
+                    const u32 others = spt_merge(TG, (u32)C->r2[s][5 - sh_pair_idx(st, u)], id1);  // the two untouched suits + the new row
+                    const SpRec o = spt_opt(TG, ld3, others, (u32)C->id[s][u]);
+                    keepN |= (u64)spt_keep_tiles(C->keep[s][u], o) << (9 * u);
+                }
+                const int hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
+                kept = sp_keep_set(ld3, L - 1, spt_fin(o1), keepN, (int)C->cnt[s][0] + (hc == 1), (int)C->cnt[s][1] + (hc == 0),
+                                   (int)C->cnt[s][2] + (yao && hc == 1), (int)C->cnt[s][3] + (yao && hc == 0), sp_count_sets(g));
             }
-            const int pos = C->child_base[s] + (int)C->coff[s][ti] + vidx * nk + rank;
-            const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(dt) << 14) | (rank == nk - 1 ? SP_ENT_LAST : 0u) |
-                            ((u32)count << 24);
-            if (pos < SP_POOL) Wg->pool[pos] = ent;
+            C->kept[it] = kept & ~(1ull << t);  // d == t gives the state itself back
         }
-    };
-    int q_head = 0, q_n = 0;  // uniform over the wavefront
-    for (int it0 = 0; it0 < n_items || q_n > 0; it0 += SP_NT) {
-        if (it0 < n_items) {
-            const int it = it0 + tid;
-            bool kept = false;
-            int s = 0, ti = 0, ki = 0;
-            if (it < n_items) {
-                item_decode(it, s, ti, ki);
-                kept = C->tiles[s][ti] != C->kinds[s][ki] && ((sp_chunk_keep(C, s, ti) >> ki) & 1);
+        mj_team_sync<SP_NT>();
+        if (prof) tp2 = wall_clock64();
+        // P3: child list layout per state (for each required tile `variants(t) * kept discards` entries) + node header
+        int my_edges = 0;
+        if (tid >= sb && tid < se) {
+            const int s = tid;
+            const SpState S = sp_chunk_state(C, s);
+            int total = 0, sumreq = 0, n_ent = 0;
+            const int nt = C->n_tiles[s];
+            for (int q = 0; q < nt; q++) {
+                const int it = my_first + q, t = C->item[it] >> 4, wc = S.w.get(t);
+                const int nvar = sp_aka_in_wall(S, t) ? (wc >= 2 ? 2 : 1) : 1;
+                C->coff[it] = (unsigned short)total;
+                const int nkeep = __popcll(C->kept[it]);
+                total += nvar * nkeep;
+                n_ent += nkeep ? nvar : 0;
+                sumreq += wc;
+                my_edges += nkeep;
             }
-            const unsigned long long m = __ballot(kept);
-            if (kept) C->queue[(q_head + q_n + __popcll(m & ((1ull << tid) - 1))) & 127] = (unsigned short)(s | (ti << 4) | (ki << 10));
-            q_n += __popcll(m);
-            mj_team_sync<SP_NT>();
+            int child_base = atomicAdd(&X->n_pool, total);
+            if (child_base + total > SP_POOL) { X->overflow = 1; child_base = 0; total = 0; my_edges = -1; }
+            C->child_base[s] = child_base;
+            C->etot[s] = max(my_edges, 0);
+            SP_HBM SpNode& node = Wg->node[C->slot[s]];
+            node.child_off = (u32)child_base;
+            node.n_ch = (unsigned short)total;
+            node.sumreq = (u8)(sumreq & 0xFF);
+            node.n_ent = (u8)min(n_ent, 255);
         }
-        if (q_n >= SP_NT || it0 + SP_NT >= n_items) {  // a full wavefront of kept items, or the tail
-            const int take = min(q_n, SP_NT);
-            if (tid < take) {
-                const int e = C->queue[(q_head + tid) & 127];
-                insert_children(e & 15, (e >> 4) & 63, (e >> 10) & 15);
+        mj_team_sync<SP_NT>();
+        int n_edges = 0;  // uniform
+        {
+            int ebase = 0;
+            for (int s = sb; s < se; s++) {
+                if (s == tid) ebase = n_edges;
+                n_edges += C->etot[s];
             }
-            q_head = (q_head + take) & 127;
-            q_n -= take;
-            mj_team_sync<SP_NT>();
+            if (tid >= sb && tid < se) {
+                const int nt = C->n_tiles[tid];
+                int off = ebase;
+                for (int q = 0; q < nt; q++) {
+                    C->eoff[my_first + q] = (unsigned short)off;
+                    off += my_edges < 0 ? 0 : __popcll(C->kept[my_first + q]);
+                }
+            }
+            if (tid == 0) C->eoff[n_items] = (unsigned short)n_edges;
         }
+        mj_team_sync<SP_NT>();
+        if (prof) tp3 = wall_clock64();
+        // P4: children, one lane per kept (draw, discard) pair: it inserts its child state(s) (one per existing draw variant of
+        // t) into the hash set and leaves its child-list entry at its place of the reference's order (t, variant, d ascending).
+        for (int e0 = 0; e0 < n_edges; e0 += SP_NT) {
+            const int e = e0 + tid;
+            if (e < n_edges) {
+                int lo = 0, hi = n_items;  // largest item with eoff[item] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)C->eoff[mid] <= e) lo = mid; else hi = mid;
+                }
+                const int it = lo, rank = e - (int)C->eoff[it];
+                const u64 bits = C->kept[it];
+                u64 mrest = bits;
+                for (int r = rank; r > 0; r--) mrest &= mrest - 1;
+                const int d = __ffsll((long long)mrest) - 1;
+                const int s = C->item[it] & 15, t = C->item[it] >> 4;
+                const SpState S = sp_chunk_state(C, s);
+                const int nk = __popcll(bits);
+                const int cnt = S.w.get(t);
+                const bool aka = sp_aka_in_wall(S, t);
+                for (int variant = 0; variant < 2; variant++) {
+                    int vidx, count;  // index of this variant among the tile's existing draw entries; copies of that entry
+                    if (!aka) { if (variant == 1) continue; vidx = 0; count = cnt; }
+                    else if (variant == 0) { if (cnt < 2) continue; vidx = 0; count = cnt - 1; }
+                    else { vidx = cnt >= 2 ? 1 : 0; count = 1; }
+                    const int tile = (aka && variant == 1) ? akaize(t) : t;
+                    const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;  // akas_in_hand after the draw
+                    const int c = S.h.get(d);  // d != t: the draw does not change its count
+                    int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+                    if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
+                    else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
+                    else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
+                    bool fresh;
+                    const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), S, tile, dt, fresh);
+                    if (fresh && cs >= 0) {
+                        const int idx = atomicAdd(&X->n_list, 1);
+                        if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
+                        else X->overflow = 1;
+                    }
+                    const int pos = C->child_base[s] + (int)C->coff[it] + vidx * nk + rank;
+                    const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(dt) << 14) | (rank == nk - 1 ? SP_ENT_LAST : 0u) |
+                                    ((u32)count << 24);
+                    if (pos < SP_POOL) Wg->pool[pos] = ent;
+                }
+            }
+        }
+        mj_team_sync<SP_NT>();
+        if (prof) {
+            tp4 = wall_clock64();
+            acc_list += tp1 - tp0;
+            acc_keep += tp2 - tp1;
+            acc_layout += tp3 - tp2;
+            acc_ins += tp4 - tp3;
+            n_items_total += n_items;
+            n_edges_total += n_edges;
+        }
+        sb = se;
     }
     if (prof && tid == 0) {
-        tp5 = wall_clock64();
-        atomicAdd(&X->pt[0], (unsigned long long)(tp1 - tp0));  // P0-P3 keys, base rows, merges, +t / -d probes
-        atomicAdd(&X->pt[1], (unsigned long long)(tp2 - tp1));  // P4 lists, V merges
-        atomicAdd(&X->pt[2], (unsigned long long)(tp3 - tp2));  // P5 (t, d) probes
-        atomicAdd(&X->pt[3], (unsigned long long)(tp4 - tp3));  // P6 layout
-        atomicAdd(&X->pt[4], (unsigned long long)(tp5 - tp4));  // P7 scan + inserts
-        atomicAdd(&X->pt[5], (unsigned long long)n_items);     // (t, d) items
-        atomicAdd(&X->pt[6], (unsigned long long)n);           // states expanded
+        atomicAdd(&X->pt[0], (unsigned long long)t_probe);       // P0-P1c keys, ids, optimal entries, required draws
+        atomicAdd(&X->pt[1], (unsigned long long)acc_list);      // item lists
+        atomicAdd(&X->pt[2], (unsigned long long)acc_keep);      // P2 keeping discards
+        atomicAdd(&X->pt[3], (unsigned long long)acc_layout);    // P3 layout
+        atomicAdd(&X->pt[4], (unsigned long long)acc_ins);       // P4 inserts
+        atomicAdd(&X->pt[5], (unsigned long long)n_items_total); // draw items
+        atomicAdd(&X->pt[6], (unsigned long long)n);             // states expanded
     }
 }
-
 template <int J, int N, class F>
 MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_constant<N - 1>): the index is a compile-time constant
     if constexpr (J < N) {
@@ -1061,15 +1029,6 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
         TableOne st;                                 // the decision's table record: read during the row set-up only
         SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
         float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
-        struct {                 // row set-up (candidates + their required tiles), before any team runs
-            u64 r2[6], r3[4];    // partial merges of the root hand's rows (mj_algo.h sh_merge)
-            u64 rowt[34];        // row of root + t in suit(t)
-            u64 rowd[34];        // row of root - d in suit(d)
-            u64 U[34][3];        // discard d, k-th other suit: merge(two untouched suits, rowd[d])
-            int sh_d[34];        // shanten of root - d (only for tiles in hand)
-            u64 req[SP_MAX_CAND];
-            int nreq[SP_MAX_CAND];
-        } setup;
     } s_tm;
     SpWork* W = P.work + blockIdx.x;
     const int tid = threadIdx.x;
@@ -1232,60 +1191,25 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
         }
         __syncthreads();
 
-        // ---- candidates: analyze_discard / analyze_draw (+ *_simple for shanten > 3)  (calc.rs:205-312).
-        // All shanten numbers here are of hands one or two tiles away from the root hand, so they are incremental probes
-        // (one table gather + one final merge step) on partial merges shared by the whole row, spread over the workgroup.
-        auto& SU = s_tm.setup;
-        const ShTab ST = sh_tab(c_mj_tables);
-        const ShBase RB = sh_base(ST, root.h);
-        const u64 root_mask = root.h.nonzero_mask();
-        if (tid < 6) {
-            const int a = tid < 3 ? 0 : tid < 5 ? 1 : 2, b = tid < 3 ? tid + 1 : tid < 5 ? tid - 1 : 3;
-            SU.r2[tid] = sh_merge(RB.row_of(a), RB.row_of(b), ld3);
-        } else if (tid >= 64 && tid < 98) {
-            const int t = tid - 64, st = sh_suit(t);
-            const u32 kb = RB.key_of(st), pw = sh_pow(t);
-            const bool in_wall = root.w.get(t) > 0, in_hand = can_discard && ((root_mask >> t) & 1);
-            const u64 rt = sh_load(ST, st, in_wall ? kb + pw : kb), rd = sh_load(ST, st, in_hand ? kb - pw : kb);
-            SU.rowt[t] = in_wall ? rt : 0ull;
-            SU.rowd[t] = in_hand ? rd : 0ull;
-        }
-        if (tid < SP_MAX_CAND) { SU.req[tid] = 0; SU.nreq[tid] = 0; }
-        __syncthreads();
-        if (tid < 4) {
-            const u64 pr = tid == 0 ? SU.r2[3] : tid == 1 ? SU.r2[1] : SU.r2[0];
-            SU.r3[tid] = sh_merge(pr, tid == 3 ? RB.row[2] : RB.row[3], ld3);
-        } else if (can_discard && tid >= 64 && tid < 64 + 34 * 3) {
-            const int d = (tid - 64) / 3, k = (tid - 64) % 3;
-            if ((root_mask >> d) & 1) {
-                const int sd = sh_suit(d), st = k + (k >= sd);
-                int x = -1, y = -1;
-                for (int q = 0; q < 4; q++)
-                    if (q != sd && q != st) { if (x < 0) x = q; else y = q; }
-                SU.U[d][k] = sh_merge(SU.r2[sh_pair_idx(x, y)], SU.rowd[d], ld3);
-            }
-        }
-        __syncthreads();
-        if (can_discard && tid < 34 && ((root_mask >> tid) & 1)) {  // shanten of root - d
-            const int d = tid, sd = sh_suit(d), hd = root.h.get(d), yd = (int)((YAOKYUU_MASK >> d) & 1);
-            SU.sh_d[d] = sh_finish(sh_final(SU.r3[sd], SU.rowd[d], ld3), ld3, RB.pairs - (hd == 2), RB.kinds - (hd == 1),
-                                   RB.kpairs - (yd && hd == 2), RB.kkinds - (yd && hd == 1));
-        }
-        __syncthreads();
+        // ---- candidates: analyze_discard / analyze_draw (+ *_simple for shanten > 3)  (calc.rs:205-312), from the table-id
+        // sets of mj_sptab.h: the discards of the root hand that keep its shanten number, then one lane per candidate for the
+        // draws that lower the shanten number of root - d.
+        const SpTabG TG = sp_tab_g(c_sp_tab);
         if (tid == 0) {
             int n = 0;
             if (can_discard) {
+                const u64 keepers = sp_keep_of_hand(TG, c_mj_tables, root.h, ld3, cur_shanten);  // calc_all(root - d) == cur_shanten
                 for (int d = 0; d < 34; d++) {
                     int c = root.h.get(d);
                     if (c == 0) continue;
-                    int diff = SU.sh_d[d] - cur_shanten;
+                    const bool keeps = (keepers >> d) & 1;
                     int dt = d;
                     if (d == T_5M && (root.akas & 1) && c == 1) dt = T_5MR;
                     else if (d == T_5P && (root.akas & 2) && c == 1) dt = T_5PR;
                     else if (d == T_5S && (root.akas & 4) && c == 1) dt = T_5SR;
-                    if (cur_shanten <= 3 && diff != 0) continue;
+                    if (cur_shanten <= 3 && !keeps) continue;
                     X.cand_tile[n] = dt;
-                    X.cand_down[n] = cur_shanten > 3 && diff == 1;
+                    X.cand_down[n] = cur_shanten > 3 && !keeps;
                     n++;
                 }
             } else {
@@ -1298,38 +1222,20 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
         __syncthreads();
         const int n_cand = X.n_cand;
         // required tiles of every candidate (state.rs:176-200): draws t that lower the shanten number of root - d (+ t)
-        for (int w = tid; w < n_cand * 34; w += SP_THREADS) {
-            const int c = w / 34, t = w % 34;
-            const int wc = root.w.get(t);  // the discard does not change the wall
-            if (wc == 0) continue;
-            const int st = sh_suit(t), ht = root.h.get(t), yt = (int)((YAOKYUU_MASK >> t) & 1);
-            int sh_base_c, sh_new;
-            if (can_discard) {
-                const int d = deaka(X.cand_tile[c]), sd = sh_suit(d), hd = root.h.get(d), yd = (int)((YAOKYUU_MASK >> d) & 1);
-                sh_base_c = SU.sh_d[d];
-                if (t == d) {
-                    sh_new = calc_all(c_mj_tables, root.h, ld3);  // root - d + d
-                } else {
-                    int fin;
-                    if (sd == st) fin = sh_final(SU.r3[st], sh_load(ST, st, RB.key_of(st) + sh_pow(t) - sh_pow(d)), ld3);
-                    else fin = sh_final(SU.U[d][st - (st > sd)], SU.rowt[t], ld3);
-                    sh_new = sh_finish(fin, ld3, RB.pairs - (hd == 2) + (ht == 1), RB.kinds - (hd == 1) + (ht == 0),
-                                       RB.kpairs - (yd && hd == 2) + (yt && ht == 1), RB.kkinds - (yd && hd == 1) + (yt && ht == 0));
-                }
-            } else {
-                sh_base_c = calc_all(c_mj_tables, root.h, ld3);
-                sh_new = sh_finish(sh_final(SU.r3[st], SU.rowt[t], ld3), ld3, RB.pairs + (ht == 1), RB.kinds + (ht == 0),
-                                   RB.kpairs + (yt && ht == 1), RB.kkinds + (yt && ht == 0));
-            }
-            if (sh_new < sh_base_c) {
-                atomicOr((unsigned long long*)&SU.req[c], 1ull << t);
-                atomicAdd(&SU.nreq[c], wc);
-            }
-        }
-        __syncthreads();
         if (tid < n_cand) {
-            X.cand_req[tid] = SU.req[tid];
-            X.cand_nreq[tid] = SU.nreq[tid] & 0xFF;
+            Hand hc = root.h;
+            int base;
+            if (can_discard) {
+                hc.dec(deaka(X.cand_tile[tid]));
+                base = cur_shanten + X.cand_down[tid];
+            } else {
+                base = calc_all(c_mj_tables, root.h, ld3);
+            }
+            const u64 req = sp_req_of_hand(TG, c_mj_tables, hc, ld3, base) & root.w.nonzero_mask();  // the discard does not change the wall
+            int nreq = 0;
+            for (u64 rest = req; rest; rest &= rest - 1) nreq += root.w.get(__ffsll((long long)rest) - 1);
+            X.cand_req[tid] = req;
+            X.cand_nreq[tid] = nreq & 0xFF;
             X.cand_slot[tid] = -1;
             X.cand_tp0[tid] = X.cand_wp0[tid] = X.cand_ev0[tid] = 0.f;
         }

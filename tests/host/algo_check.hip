@@ -7,7 +7,7 @@
 // the bit-count intrinsics of the device headers are __device__-only; the compiler builtins serve both passes
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
-#include "../../mortal_amd/csrc/mj_algo.h"
+#include "../../mortal_amd/csrc/mj_sptab.h"
 
 #include <cmath>
 #include <cstdio>
@@ -96,9 +96,140 @@ static int check_draw_candidates(const char* path) {
     return 0;
 }
 
+
+// Table-id shanten (mj_sptab.h): required draws / shanten-keeping discards from the per-key wait / keep masks and the
+// optimal-entry table, against the reference-shaped brute force (calc_all of every h + t, g - d; state.rs:100-173).
+#ifndef SPTAB_CHECK_ITERS
+#define SPTAB_CHECK_ITERS 400000
+#endif
+static bool load_tables(const char* path, std::vector<uint64_t>& su, std::vector<uint64_t>& ji) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    std::vector<unsigned char> buf;
+    unsigned char tmp[65536];
+    size_t k;
+    while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + k);
+    fclose(f);
+    uint32_t ns, nj;
+    memcpy(&ns, &buf[4], 4);
+    memcpy(&nj, &buf[8], 4);
+    su.assign(ns, 0);
+    ji.assign(nj, 0);
+    for (uint32_t i = 0; i < ns; i++) for (int b = 0; b < 5; b++) su[i] |= (uint64_t)buf[16 + (size_t)i * 5 + b] << (8 * b);
+    for (uint32_t i = 0; i < nj; i++) for (int b = 0; b < 5; b++) ji[i] |= (uint64_t)buf[16 + (size_t)ns * 5 + (size_t)i * 5 + b] << (8 * b);
+    return true;
+}
+static int check_sptab(const char* path) {
+    std::vector<uint64_t> su, ji;
+    if (!load_tables(path, su, ji)) { printf("cannot open %s\n", path); return 20; }
+    MjTablesDev MT{};
+    MT.suhai = su.data();
+    MT.n_suhai = (uint32_t)su.size();
+    MT.jihai = ji.data();
+    MT.n_jihai = (uint32_t)ji.size();
+    SpTabHost H;
+    if (!sp_tab_build(su.data(), MT.n_suhai, ji.data(), MT.n_jihai, H)) { printf("sp_tab_build: %s\n", H.error.c_str()); return 21; }
+    SpTabDev T{H.id_su.data(), H.id_ji.data(), H.mrg.data(), H.opt.data(), H.wk_su.data(), H.wk_ji.data(), MT.n_suhai, MT.n_jihai, H.zero_id};
+    printf("sp tables: %u distinct rows, merge closure %zu vectors\n", H.n_rows, H.vec.size());
+    // merge / final tables == the nibble arithmetic of mj_algo.h, for every (vector, row) and every len_div3
+    for (size_t v = 0; v < H.vec.size(); v++)
+        for (uint32_t b = 0; b < H.n_rows; b++)
+            for (int m = 0; m <= 4; m++) {
+                const u64 mg = sh_merge(H.vec[v], H.vec[b], m), full = H.vec[H.mrg[v * SPT_NB + b]];
+                // a truncated merge (entries beyond m keep the left operand's values) agrees with the full one on the entries a final for m reads
+                for (int j = 0; j <= 9; j++)
+                    if ((j <= m || (j >= 5 && j <= 5 + m)) && NIB(mg, j) != NIB(full, j)) { printf("merge table mismatch\n"); return 22; }
+                if (spt_fin(spt_opt(T, m, (u32)v, b)) != sh_final(H.vec[v], H.vec[b], m)) { printf("final table mismatch\n"); return 23; }
+            }
+    std::mt19937_64 g(4242);
+    long hands = 0, n_req = 0, n_keep = 0, n_fb = 0, n_slow = 0;
+    auto check_hand = [&](Hand h, int ld3) -> int {
+        const int L = calc_all(MT, h, ld3);
+        int fin = -1;
+        const u64 got = sp_req_of_hand(T, MT, h, ld3, L, &fin), want = sp_req_brute(MT, h, ld3, L);
+        u64 full = 0;
+        for (int t = 0; t < 34; t++) if (h.get(t) >= 4) full |= 1ull << t;
+        if ((got & ~full) != want) {
+            printf("required draws differ: ld3 %d L %d got %llx want %llx hand", ld3, L, (unsigned long long)got, (unsigned long long)want);
+            for (int q = 0; q < 34; q++) printf(" %d", h.get(q));
+            printf("\n");
+            return 24;
+        }
+        if (fin - 1 != calc_normal(MT, h, ld3) && fin >= 0) {
+            const SpSuitView v = sp_suit_view(T, h);
+            bool inside = true;
+            for (int s = 0; s < 4; s++) inside &= spt_in_table(T, s, v.key[s]);
+            if (inside) { printf("normal-form number differs\n"); return 25; }
+        }
+        n_req += __builtin_popcountll(want);
+        for (int t = 0; t < 34; t++) {
+            if (h.get(t) >= 4) continue;
+            if (!((want >> t) & 1) && (g() % 4)) continue;  // every required draw, a quarter of the others
+            Hand x = h;
+            x.inc(t);
+            const int Tg = calc_all(MT, x, ld3);
+            const u64 k_got = sp_keep_of_hand(T, MT, x, ld3, Tg), k_want = sp_keep_brute(MT, x, ld3, Tg);
+            if (k_got != k_want) {
+                printf("keeping discards differ: ld3 %d T %d got %llx want %llx hand", ld3, Tg, (unsigned long long)k_got, (unsigned long long)k_want);
+                for (int q = 0; q < 34; q++) printf(" %d", x.get(q));
+                printf("\n");
+                return 26;
+            }
+            n_keep += __builtin_popcountll(k_want);
+        }
+        hands++;
+        return 0;
+    };
+    for (int it = 0; it < SPTAB_CHECK_ITERS; it++) {
+        const int ld3 = it % 5 == 0 ? (int)(g() % 4) : 4, n_tiles = 3 * ld3 + 1, mode = it % 9;
+        int cnt[34] = {0};
+        int pool[34], np = 0;
+        if (mode <= 2) for (int t = 0; t < 34; t++) pool[np++] = t;
+        else if (mode == 3) { const int kk = 2 + (int)(g() % 6); while (np < kk) { int t = (int)(g() % 34), dup = 0; for (int i = 0; i < np; i++) dup |= pool[i] == t; if (!dup) pool[np++] = t; } }
+        else if (mode == 4) { const int s0 = 9 * (int)(g() % 3); for (int t = s0; t < s0 + 9; t++) pool[np++] = t; for (int t = 27; t < 34; t++) if (g() & 1) pool[np++] = t; }
+        else if (mode == 5) { const int yao[13] = {0, 8, 9, 17, 18, 26, 27, 28, 29, 30, 31, 32, 33}; for (int i = 0; i < 13; i++) pool[np++] = yao[i]; for (int i = 0; i < 3; i++) pool[np++] = (int)(g() % 27); }
+        else if (mode == 6) { const int kk = 4 + (int)(g() % 3); while (np < kk) { int t = (int)(g() % 34), dup = 0; for (int i = 0; i < np; i++) dup |= pool[i] == t; if (!dup) pool[np++] = t; } }
+        else if (mode == 7) { const int s0 = 9 * (int)(g() % 3); for (int t = s0; t < s0 + 9; t++) pool[np++] = t; }  // one suit only
+        else { const int kk = 7 + (int)(g() % 3); while (np < kk) { int t = (int)(g() % 34), dup = 0; for (int i = 0; i < np; i++) dup |= pool[i] == t; if (!dup) pool[np++] = t; } }  // pairs-heavy
+        if (np * 4 < n_tiles) continue;
+        if (mode == 8) {  // seven-pairs shapes: pairs first, then singles
+            int placed = 0;
+            for (int i = 0; i < np && placed + 2 <= n_tiles && i < 6; i++) { cnt[pool[i]] = 2; placed += 2; }
+            while (placed < n_tiles) { const int t = pool[g() % np]; if (cnt[t] < 4) { cnt[t]++; placed++; } }
+        } else {
+            for (int placed = 0; placed < n_tiles;) {
+                const int t = pool[g() % np];
+                if (cnt[t] < 4) { cnt[t]++; placed++; }
+            }
+        }
+        Hand h = {0, 0};
+        for (int t = 0; t < 34; t++) for (int c = 0; c < cnt[t]; c++) h.inc(t);
+        const int rc = check_hand(h, ld3);
+        if (rc) return rc;
+    }
+    // the 13-tile one-suit patterns whose +1 neighbour lies past the table (fallback records), in every suit
+    const int fb[8][5] = {{3, 4, 4, 1, 1}, {3, 4, 4, 2, 0}, {4, 3, 4, 1, 1}, {4, 3, 4, 2, 0}, {4, 4, 3, 1, 1}, {4, 4, 3, 2, 0}, {4, 4, 4, 0, 1}, {4, 4, 4, 1, 0}};
+    for (int s = 0; s < 3; s++)
+        for (int q = 0; q < 8; q++) {
+            Hand h = {0, 0};
+            int n = 0;
+            for (int i = 0; i < 5; i++) for (int c = 0; c < fb[q][i]; c++) { h.inc(9 * s + i); n++; }
+            while (n < 13) { h.inc(27 + n % 7); n++; }
+            const SpSuitView v = sp_suit_view(T, h);
+            if (n == 13 && spt_in_table(T, s, v.key[s]) && (spt_rec(T, s, v.key[s], 0).w & SPT_FALLBACK)) n_fb++;
+            const int rc = check_hand(h, 4);
+            if (rc) return rc;
+        }
+    printf("table-id shanten sets == brute force: %ld hands, %ld required draws, %ld keeping discards, %ld fallback patterns\n", hands, n_req, n_keep, n_fb);
+    (void)n_slow;
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1) {
-        const int rc = check_draw_candidates(argv[1]);
+        int rc = check_draw_candidates(argv[1]);
+        if (rc) return rc;
+        rc = check_sptab(argv[1]);
         if (rc) return rc;
     }
     std::mt19937_64 g(12345);
