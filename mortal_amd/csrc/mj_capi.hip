@@ -180,12 +180,10 @@ int mj_tables_upload(const void* payload, size_t size) {
     {   // table-id shanten (mj_sptab.h): row ids, merge closure, optimal-entry table, per-key wait / keep masks
         SpTabHost H;
         if (!sp_tab_build(suhai.data(), ns, jihai.data(), nj, H)) return fail("sp_tab_build: " + H.error);
-        u8 *d_is, *d_ij, *d_m;
-        SpRec *d_o, *d_ws, *d_wj;
-        if (upload(H.id_su, &d_is) || upload(H.id_ji, &d_ij) || upload(H.mrg, &d_m) || upload(H.opt, &d_o) || upload(H.wk_su, &d_ws) ||
-            upload(H.wk_ji, &d_wj))
-            return -1;
-        SpTabDev st{d_is, d_ij, d_m, d_o, d_ws, d_wj, ns, nj, H.zero_id};
+        u8 *d_id, *d_m;
+        SpRec *d_o, *d_wk;
+        if (upload(H.id, &d_id) || upload(H.mrg, &d_m) || upload(H.opt, &d_o) || upload(H.wk, &d_wk)) return -1;
+        SpTabDev st{d_id, d_m, d_o, d_wk, ns, nj, H.zero_id};
         HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_sp_tab), &st, sizeof(SpTabDev)));
     }
     auto g = build_gather();

@@ -40,46 +40,51 @@ struct alignas(16) SpRec {
 // opt record          : x / y / z = 0x1FF in the field of every entry that attains the final minimum, x bits 27..30 = the final
 //                       value (normal-form shanten + 1), w = 0x1FF if entry 0 attains it
 struct SpTabDev {
-    const u8* id_su;     // [n_su]
-    const u8* id_ji;     // [n_ji]
+    const u8* id;        // [n_su + n_ji]: number-suit keys, then honour keys (ONE array: a lane-dependent suit selects an offset,
+                         //                not a pointer — hipcc turns a select between two pointers of a local struct into a scratch array)
     const u8* mrg;       // [SPT_NV][SPT_NB]
     const SpRec* opt;    // [5][SPT_NV][SPT_NB]
-    const SpRec* wk_su;  // [n_su][2]: wait, keep
-    const SpRec* wk_ji;  // [n_ji][2]
+    const SpRec* wk;     // [n_su + n_ji][2]: wait, keep
     u32 n_su, n_ji;
     u32 zero_id;         // id of the all-zero row (keys past the table)
 };
 
 // the same table block with explicit global-address-space pointers (kernels: global_load instead of flat_load)
 struct SpTabG {
-    const MJ_HBM u8* id_su;
-    const MJ_HBM u8* id_ji;
+    const MJ_HBM u8* id;
     const MJ_HBM u8* mrg;
     const MJ_HBM SpRec* opt;
-    const MJ_HBM SpRec* wk_su;
-    const MJ_HBM SpRec* wk_ji;
+    const MJ_HBM SpRec* wk;
     u32 n_su, n_ji, zero_id;
 };
 MJD SpTabG sp_tab_g(const SpTabDev& T) {
     SpTabG g;
-    g.id_su = (const MJ_HBM u8*)T.id_su;
-    g.id_ji = (const MJ_HBM u8*)T.id_ji;
+    g.id = (const MJ_HBM u8*)T.id;
     g.mrg = (const MJ_HBM u8*)T.mrg;
     g.opt = (const MJ_HBM SpRec*)T.opt;
-    g.wk_su = (const MJ_HBM SpRec*)T.wk_su;
-    g.wk_ji = (const MJ_HBM SpRec*)T.wk_ji;
+    g.wk = (const MJ_HBM SpRec*)T.wk;
+    // the three scalars pass through readfirstlane: an opaque value in an SGPR.  Otherwise hipcc folds a lane-dependent
+    // `suit < 3 ? n_su : n_ji` over two loads into ONE load from a selected address and keeps a copy of the block in scratch.
+#if defined(__HIP_DEVICE_COMPILE__)
+    g.n_su = (u32)__builtin_amdgcn_readfirstlane((int)T.n_su);
+    g.n_ji = (u32)__builtin_amdgcn_readfirstlane((int)T.n_ji);
+    g.zero_id = (u32)__builtin_amdgcn_readfirstlane((int)T.zero_id);
+#else
     g.n_su = T.n_su;
     g.n_ji = T.n_ji;
     g.zero_id = T.zero_id;
+#endif
     return g;
 }
 
 // ---- device / host-testable lookups (TT = SpTabDev or SpTabG)
 template <class TT> MJD u32 spt_id(const TT& T, int suit, u32 key) {
-    const u32 n = suit < 3 ? T.n_su : T.n_ji;
-    const u32 k = key < n ? key : 0u;
-    const u32 v = suit < 3 ? T.id_su[k] : T.id_ji[k];
-    return key < n ? v : T.zero_id;
+    // the fields are read BEFORE the lane-dependent selects: with the loads inside the arms hipcc sinks them into one load
+    // from a selected ADDRESS, which pins the whole table block in scratch memory
+    const u32 n_su = T.n_su, n_ji = T.n_ji, zero = T.zero_id;
+    const u32 n = suit < 3 ? n_su : n_ji;
+    const u32 v = T.id[(key < n ? key : 0u) + (suit < 3 ? 0u : n_su)];  // unconditional load (always a valid address)
+    return key < n ? v : zero;
 }
 template <class TT> MJD u32 spt_merge(const TT& T, u32 vec, u32 row) { return T.mrg[vec * SPT_NB + row]; }
 template <class R> MJD SpRec spt_load(const R* p) {  // one 16-byte load
@@ -91,10 +96,13 @@ template <class TT> MJD SpRec spt_opt(const TT& T, int m, u32 vec, u32 row) { re
 MJD int spt_fin(const SpRec& o) { return (int)((o.x >> 27) & 15u); }
 // which = 0 wait, 1 keep; key must be inside the table
 template <class TT> MJD SpRec spt_rec(const TT& T, int suit, u32 key, int which) {
-    const size_t i = (size_t)key * 2 + which;
-    return suit < 3 ? spt_load(&T.wk_su[i]) : spt_load(&T.wk_ji[i]);
+    const u32 n_su = T.n_su;
+    return spt_load(&T.wk[(size_t)(key + (suit < 3 ? 0u : n_su)) * 2 + which]);
 }
-template <class TT> MJD bool spt_in_table(const TT& T, int suit, u32 key) { return key < (suit < 3 ? T.n_su : T.n_ji); }
+template <class TT> MJD bool spt_in_table(const TT& T, int suit, u32 key) {
+    const u32 n_su = T.n_su, n_ji = T.n_ji;
+    return key < (suit < 3 ? n_su : n_ji);
+}
 MJD u32 spt_fold27(u32 v) { return (v | (v >> 9) | (v >> 18)) & 0x1FFu; }
 MJD u32 spt_wait_tiles(const SpRec& wait, const SpRec& opt) { return spt_fold27((wait.x & opt.x) | (wait.y & opt.y) | (wait.z & opt.z)); }  // wait.x < 2^27
 MJD u32 spt_keep_tiles(const SpRec& keep, const SpRec& opt) {
@@ -259,8 +267,8 @@ template <class TT> MJD u64 sp_keep_of_hand(const TT& T, const MjTablesDev& MT, 
 #include <vector>
 
 struct SpTabHost {
-    std::vector<u8> id_su, id_ji, mrg;
-    std::vector<SpRec> opt, wk_su, wk_ji;
+    std::vector<u8> id, mrg;          // id: [n_su + n_ji]
+    std::vector<SpRec> opt, wk;       // wk: [n_su + n_ji][2]
     std::vector<u64> vec;  // id -> packed vector (ids < n_rows are the table rows)
     u32 n_rows = 0, zero_id = 0;
     std::string error;
@@ -301,10 +309,9 @@ static inline bool sp_tab_build(const u64* suhai, u32 n_su, const u64* jihai, u3
     H.zero_id = ids[0ull];
     H.vec.assign(n, 0);
     for (auto& kv : ids) H.vec[kv.second] = kv.first;
-    H.id_su.resize(n_su);
-    H.id_ji.resize(n_ji);
-    for (u32 i = 0; i < n_su; i++) H.id_su[i] = (u8)ids[suhai[i] & 0xFFFFFFFFFFull];
-    for (u32 i = 0; i < n_ji; i++) H.id_ji[i] = (u8)ids[jihai[i] & 0xFFFFFFFFFFull];
+    H.id.resize((size_t)n_su + n_ji);
+    for (u32 i = 0; i < n_su; i++) H.id[i] = (u8)ids[suhai[i] & 0xFFFFFFFFFFull];
+    for (u32 i = 0; i < n_ji; i++) H.id[(size_t)n_su + i] = (u8)ids[jihai[i] & 0xFFFFFFFFFFull];
     // 2. closure under merge(vector, row)
     std::map<u64, u32> vid(ids);
     H.mrg.assign((size_t)SPT_NV * SPT_NB, 0);
@@ -344,8 +351,8 @@ static inline bool sp_tab_build(const u64* suhai, u32 n_su, const u64* jihai, u3
                 H.opt[((size_t)m * SPT_NV + v) * SPT_NB + b] = r;
             }
     // 4. per-key wait / keep masks
-    auto build_wk = [&](const u64* tab, u32 nk, int ntile, std::vector<SpRec>& out) -> bool {
-        out.assign((size_t)nk * 2, SpRec{0, 0, 0, 0});
+    H.wk.assign(((size_t)n_su + n_ji) * 2, SpRec{0, 0, 0, 0});
+    auto build_wk = [&](const u64* tab, u32 nk, int ntile, SpRec* out) -> bool {
         u32 pw[9];
         pw[ntile - 1] = 1;
         for (int i = ntile - 2; i >= 0; i--) pw[i] = pw[i + 1] * 5;
@@ -385,5 +392,5 @@ static inline bool sp_tab_build(const u64* suhai, u32 n_su, const u64* jihai, u3
         }
         return true;
     };
-    return build_wk(suhai, n_su, 9, H.wk_su) && build_wk(jihai, n_ji, 7, H.wk_ji);
+    return build_wk(suhai, n_su, 9, H.wk.data()) && build_wk(jihai, n_ji, 7, H.wk.data() + (size_t)n_su * 2);
 }

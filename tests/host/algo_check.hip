@@ -129,7 +129,7 @@ static int check_sptab(const char* path) {
     MT.n_jihai = (uint32_t)ji.size();
     SpTabHost H;
     if (!sp_tab_build(su.data(), MT.n_suhai, ji.data(), MT.n_jihai, H)) { printf("sp_tab_build: %s\n", H.error.c_str()); return 21; }
-    SpTabDev T{H.id_su.data(), H.id_ji.data(), H.mrg.data(), H.opt.data(), H.wk_su.data(), H.wk_ji.data(), MT.n_suhai, MT.n_jihai, H.zero_id};
+    SpTabDev T{H.id.data(), H.mrg.data(), H.opt.data(), H.wk.data(), MT.n_suhai, MT.n_jihai, H.zero_id};
     printf("sp tables: %u distinct rows, merge closure %zu vectors\n", H.n_rows, H.vec.size());
     // merge / final tables == the nibble arithmetic of mj_algo.h, for every (vector, row) and every len_div3
     for (size_t v = 0; v < H.vec.size(); v++)
