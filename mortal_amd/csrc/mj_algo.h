@@ -69,6 +69,15 @@ MJD float sp_div(float a, float b, float r1) {
     const float e2 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(e2, r1, q1);
 }
+// The first correction step alone: q1 is already the correctly rounded quotient for EVERY operand pair the SP kernel divides
+// (prob = tsumo_prob[c][j] * not_tsumo[s][j] / not_tsumo[s][i], calc.rs:135-167,486-548: 4.3 M pairs over all wall sizes,
+// required-tile sums, counts and turn pairs, for r0 = RN(1/b) and both neighbours — enumerated in tests/host/algo_check.hip);
+// it is NOT a general division (random operands need the second step about once in 10^3).
+MJD float sp_div_domain(float a, float b, float r1) {
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e1, r1, q0);
+}
 
 
 enum : int { T_5M = 4, T_5P = 13, T_5S = 22, T_E = 27, T_S = 28, T_W = 29, T_N = 30, T_P = 31, T_F = 32, T_C = 33,

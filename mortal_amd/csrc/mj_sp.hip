@@ -36,7 +36,7 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #define SP_NS 16               // states per expansion chunk (one chunk per wavefront)
 #endif
 #ifndef SP_ITEM_CAP
-#define SP_ITEM_CAP 128        // draw items (state, required tile) per sub-batch of a chunk
+#define SP_ITEM_CAP 64         // draw items (state, required tile) per sub-batch of a chunk: one lane each
 #endif
 #ifndef SP_WGS
 #define SP_WGS 4               // resident workgroups per CU the kernel is compiled for (register budget 512 / SP_WGS per lane)
@@ -392,9 +392,11 @@ struct SpChunk {
     u8 fin[SP_NS];          // normal-form final value (shanten + 1)
     u8 fb[SP_NS];           // brute-force path
     u8 n_tiles[SP_NS];      // required draws
+    u32 gcs[SP_NS][4];      // per suit group of the hand: tiles held once | twice << 9 | at all << 18 (sp_group_count_sets)
+    unsigned short wnz[SP_NS][4];  // per suit group: tiles left in the wall
+    u64 cs[SP_NS][3];       // the hand's tiles held once / twice / at all (34-bit sets)
     int child_base[SP_NS];
-    int etot[SP_NS];        // kept (draw, discard) pairs of the state
-    // the draw items (state, required tile) of the current sub-batch of states
+    // the draw items (state, required tile) of the current sub-batch of states: one lane each
     u64 kept[SP_ITEM_CAP];                  // shanten-keeping discards after the draw
     unsigned short item[SP_ITEM_CAP];       // state | tile << 4
     unsigned short coff[SP_ITEM_CAP];       // offset of the item's first child inside the state's child list
@@ -402,7 +404,7 @@ struct SpChunk {
 };
 #define SP_NT 64  // co-operating threads of a chunk
 static_assert(SP_NS <= 16, "item entries hold the state in 4 bits");
-static_assert(SP_ITEM_CAP >= 34 && SP_ITEM_CAP <= 1024, "a sub-batch holds at least one state's draws");
+static_assert(SP_ITEM_CAP == SP_NT, "one lane per draw item: the layout pass is a wavefront scan");
 
 MJD SpState sp_chunk_state(const SpChunk* C, int s) {
     SpState S;
@@ -441,6 +443,8 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         C->key[s][i] = key;
         C->id[s][i] = (u8)spt_id(TG, i, key);
         C->cnt[s][i] = (u8)(i == 0 ? S.h.n_pairs() : i == 1 ? S.h.n_kinds() : i == 2 ? S.h.n_yao_pairs() : S.h.n_yao_kinds());
+        C->gcs[s][i] = sp_group_count_sets(sp_group_fields(S.h, i));
+        C->wnz[s][i] = (unsigned short)((sp_group_count_sets(sp_group_fields(S.w, i)) >> 18) & 0x1FF);
     }
     mj_team_sync<SP_NT>();
     for (int task = tid; task < n * 4; task += SP_NT) {
@@ -468,10 +472,18 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
         const u32 w0 = C->wn[s][0], w1 = C->wn[s][1], w2 = C->wn[s][2], w3 = C->wn[s][3];
         const bool fb = ((w0 | w1 | w2 | w3) & 0x8000u) != 0;
         const u64 waitN = (u64)(w0 & 0x1FF) | ((u64)(w1 & 0x1FF) << 9) | ((u64)(w2 & 0x1FF) << 18) | ((u64)(w3 & 0x1FF) << 27);
+        const u32 g0 = C->gcs[s][0], g1 = C->gcs[s][1], g2 = C->gcs[s][2], g3 = C->gcs[s][3];
+        SpCountSets cs;
+        cs.c1 = (u64)(g0 & 0x1FF) | ((u64)(g1 & 0x1FF) << 9) | ((u64)(g2 & 0x1FF) << 18) | ((u64)(g3 & 0x1FF) << 27);
+        cs.c2 = (u64)((g0 >> 9) & 0x1FF) | ((u64)((g1 >> 9) & 0x1FF) << 9) | ((u64)((g2 >> 9) & 0x1FF) << 18) | ((u64)((g3 >> 9) & 0x1FF) << 27);
+        cs.nz = (u64)(g0 >> 18) | ((u64)(g1 >> 18) << 9) | ((u64)(g2 >> 18) << 18) | ((u64)(g3 >> 18) << 27);
+        C->cs[s][0] = cs.c1;
+        C->cs[s][1] = cs.c2;
+        C->cs[s][2] = cs.nz;
         u64 req;
         if (fb) req = sp_req_brute_dev(S.h, ld3, L);
-        else req = sp_req_set(ld3, L, (int)C->fin[s], waitN, (int)C->cnt[s][0], (int)C->cnt[s][1], (int)C->cnt[s][2], (int)C->cnt[s][3], sp_count_sets(S.h));
-        req &= S.w.nonzero_mask();
+        else req = sp_req_set(ld3, L, (int)C->fin[s], waitN, (int)C->cnt[s][0], (int)C->cnt[s][1], (int)C->cnt[s][2], (int)C->cnt[s][3], cs);
+        req &= (u64)C->wnz[s][0] | ((u64)C->wnz[s][1] << 9) | ((u64)C->wnz[s][2] << 18) | ((u64)C->wnz[s][3] << 27);
         C->req[s] = req;
         C->fb[s] = (u8)fb;
         C->n_tiles[s] = (u8)__popcll(req);
@@ -542,36 +554,50 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     if (prof) tq1 = wall_clock64();
     const long long t_probe = tq1 - tq0;
 
-    // The draw items (state, required tile) are processed in sub-batches of whole states with at most SP_ITEM_CAP items.
+    // The draw items (state, required tile) are processed in sub-batches of whole states with at most SP_ITEM_CAP = 64 items:
+    // one lane per item.  A chunk with more items is split into sub-batches of about equal size.
+    int total_items = 0;
+    for (int s = 0; s < n; s++) total_items += (int)C->n_tiles[s];
+    const int n_sub = (total_items + SP_ITEM_CAP - 1) / SP_ITEM_CAP, target = n_sub > 1 ? (total_items + n_sub - 1) / n_sub : SP_ITEM_CAP;
     for (int sb = 0; sb < n;) {
         long long tp0 = prof ? wall_clock64() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
         int se = sb, n_items = 0;  // uniform over the wavefront
         int my_first = 0;
         for (int s = sb; s < n; s++) {
             const int nt = (int)C->n_tiles[s];
-            if (s > sb && n_items + nt > SP_ITEM_CAP) break;
+            if (s > sb && (n_items + nt > SP_ITEM_CAP || n_items >= target)) break;
             if (s == tid) my_first = n_items;
             n_items += nt;
             se = s + 1;
         }
-        // item list: one lane per state walks its required-draw set (ascending)
+        // item list: one lane per state walks its required-draw set (ascending); a state without draws left gets its header now
         if (tid >= sb && tid < se) {
             const int s = tid;
             int it = my_first;
             for (u64 rest = C->req[s]; rest; rest &= rest - 1) C->item[it++] = (unsigned short)(s | ((__ffsll((long long)rest) - 1) << 4));
+            if (it == my_first) {
+                SP_HBM SpNode& node = Wg->node[C->slot[s]];
+                node.child_off = 0;
+                node.n_ch = 0;
+                node.sumreq = 0;
+                node.n_ent = 0;
+            }
         }
         mj_team_sync<SP_NT>();
         if (prof) tp1 = wall_clock64();
-        // P2: the shanten-keeping discards of g = h + t
-        for (int it = tid; it < n_items; it += SP_NT) {
-            const int e = C->item[it], s = e & 15, t = e >> 4;
-            const SpState S = sp_chunk_state(C, s);
-            Hand g = S.h;
-            g.inc(t);
+        // P2: the shanten-keeping discards of g = h + t, lane = item
+        const bool has_item = tid < n_items;
+        const int my_e = has_item ? (int)C->item[tid] : 0, my_s = my_e & 15, my_t = my_e >> 4;
+        const SpState S = sp_chunk_state(C, my_s);
+        u64 kept = 0;
+        if (has_item) {
+            const int s = my_s, t = my_t;
             const int st = sh_suit(t);
             const u32 key1 = C->key[s][st] + sh_pow(t);
-            u64 kept;
+            const int hc = S.h.get(t);
             if (C->fb[s] || !spt_in_table(TG, st, key1)) {
+                Hand g = S.h;
+                g.inc(t);
                 kept = sp_keep_brute_dev(g, ld3, L - 1);
             } else {
                 const u32 id1 = spt_id(TG, st, key1);
@@ -579,60 +605,67 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
                 u64 keepN = (u64)spt_keep_tiles(spt_rec(TG, st, key1, 1), o1) << (9 * st);
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
-                    const int u = q + (q >= st);                                    // q-th suit != st
+                    const int u = q + (q >= st);                                                   // q-th suit != st
                     const u32 others = spt_merge(TG, (u32)C->r2[s][5 - sh_pair_idx(st, u)], id1);  // the two untouched suits + the new row
                     const SpRec o = spt_opt(TG, ld3, others, (u32)C->id[s][u]);
                     keepN |= (u64)spt_keep_tiles(C->keep[s][u], o) << (9 * u);
                 }
-                const int hc = S.h.get(t), yao = (int)((YAOKYUU_MASK >> t) & 1);
+                const int yao = (int)((YAOKYUU_MASK >> t) & 1);
+                SpCountSets cs;
+                cs.c1 = C->cs[s][0];
+                cs.c2 = C->cs[s][1];
+                cs.nz = C->cs[s][2];
                 kept = sp_keep_set(ld3, L - 1, spt_fin(o1), keepN, (int)C->cnt[s][0] + (hc == 1), (int)C->cnt[s][1] + (hc == 0),
-                                   (int)C->cnt[s][2] + (yao && hc == 1), (int)C->cnt[s][3] + (yao && hc == 0), sp_count_sets(g));
+                                   (int)C->cnt[s][2] + (yao && hc == 1), (int)C->cnt[s][3] + (yao && hc == 0), sp_count_sets_add(cs, t, hc));
             }
-            C->kept[it] = kept & ~(1ull << t);  // d == t gives the state itself back
+            kept &= ~(1ull << t);  // d == t gives the state itself back
+            C->kept[tid] = kept;
         }
-        mj_team_sync<SP_NT>();
         if (prof) tp2 = wall_clock64();
-        // P3: child list layout per state (for each required tile `variants(t) * kept discards` entries) + node header
-        int my_edges = 0;
-        if (tid >= sb && tid < se) {
-            const int s = tid;
-            const SpState S = sp_chunk_state(C, s);
-            int total = 0, sumreq = 0, n_ent = 0;
-            const int nt = C->n_tiles[s];
-            for (int q = 0; q < nt; q++) {
-                const int it = my_first + q, t = C->item[it] >> 4, wc = S.w.get(t);
-                const int nvar = sp_aka_in_wall(S, t) ? (wc >= 2 ? 2 : 1) : 1;
-                C->coff[it] = (unsigned short)total;
-                const int nkeep = __popcll(C->kept[it]);
-                total += nvar * nkeep;
-                n_ent += nkeep ? nvar : 0;
-                sumreq += wc;
-                my_edges += nkeep;
-            }
-            int child_base = atomicAdd(&X->n_pool, total);
-            if (child_base + total > SP_POOL) { X->overflow = 1; child_base = 0; total = 0; my_edges = -1; }
-            C->child_base[s] = child_base;
-            C->etot[s] = max(my_edges, 0);
-            SP_HBM SpNode& node = Wg->node[C->slot[s]];
-            node.child_off = (u32)child_base;
-            node.n_ch = (unsigned short)total;
-            node.sumreq = (u8)(sumreq & 0xFF);
-            node.n_ent = (u8)min(n_ent, 255);
-        }
-        mj_team_sync<SP_NT>();
-        int n_edges = 0;  // uniform
+        // P3: child list layout (for each required tile `variants(t) * kept discards` entries) + node header: an inclusive wavefront
+        // scan over the item lanes of (entries, kept discards) and (wall copies, draw entries); a state's items are contiguous lanes
+        int n_edges;
         {
-            int ebase = 0;
-            for (int s = sb; s < se; s++) {
-                if (s == tid) ebase = n_edges;
-                n_edges += C->etot[s];
+            const int wc = has_item ? S.w.get(my_t) : 0;
+            const int nvar = has_item && sp_aka_in_wall(S, my_t) ? (wc >= 2 ? 2 : 1) : 1;
+            const int nkeep = __popcll(kept);
+            u32 pa = (u32)(nvar * nkeep) | ((u32)nkeep << 16), pb = (u32)wc | ((u32)(nkeep ? nvar : 0) << 16);
+            if (!has_item) pa = pb = 0;
+#pragma unroll
+            for (int d = 1; d < SP_NT; d <<= 1) {
+                const u32 qa = __shfl_up(pa, d), qb = __shfl_up(pb, d);
+                if (tid >= d) { pa += qa; pb += qb; }
             }
-            if (tid >= sb && tid < se) {
-                const int nt = C->n_tiles[tid];
-                int off = ebase;
-                for (int q = 0; q < nt; q++) {
-                    C->eoff[my_first + q] = (unsigned short)off;
-                    off += my_edges < 0 ? 0 : __popcll(C->kept[my_first + q]);
+            // this state's lanes: [first, last]; totals = prefix(last) - prefix(first - 1)
+            int s_first = 0, s_last = 0;
+            {
+                // first lane of my state = number of items of the states before it in this sub-batch
+                int acc = 0;
+                for (int s = sb; s < se; s++) {
+                    const int nt = (int)C->n_tiles[s];
+                    if (s == my_s) { s_first = acc; s_last = acc + nt - 1; }
+                    acc += nt;
+                }
+            }
+            const u32 base_a = __shfl(pa, max(s_first - 1, 0)), base_b = __shfl(pb, max(s_first - 1, 0));
+            const u32 tot_a = __shfl(pa, s_last), tot_b = __shfl(pb, s_last);
+            const u32 ba = s_first > 0 ? base_a : 0u, bb = s_first > 0 ? base_b : 0u;
+            n_edges = (int)(__shfl(pa, SP_NT - 1) >> 16);
+            if (has_item) {
+                const int my_ent = nvar * nkeep;
+                C->coff[tid] = (unsigned short)(((pa - ba) & 0xFFFFu) - (u32)my_ent);
+                C->eoff[tid] = (unsigned short)((pa >> 16) - (u32)nkeep);
+                if (tid == s_last) {  // one lane per state: the pool space and the node header
+                    int total = (int)((tot_a - ba) & 0xFFFFu);
+                    const int sumreq = (int)((tot_b - bb) & 0xFFFFu), n_ent = (int)((tot_b - bb) >> 16);
+                    int child_base = atomicAdd(&X->n_pool, total);
+                    if (child_base + total > SP_POOL) { X->overflow = 1; child_base = SP_POOL; total = 0; }
+                    C->child_base[my_s] = child_base;
+                    SP_HBM SpNode& node = Wg->node[C->slot[my_s]];
+                    node.child_off = (u32)min(child_base, SP_POOL - 1);
+                    node.n_ch = (unsigned short)total;
+                    node.sumreq = (u8)(sumreq & 0xFF);
+                    node.n_ent = (u8)min(n_ent, 255);
                 }
             }
             if (tid == 0) C->eoff[n_items] = (unsigned short)n_edges;
@@ -655,24 +688,24 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
                 for (int r = rank; r > 0; r--) mrest &= mrest - 1;
                 const int d = __ffsll((long long)mrest) - 1;
                 const int s = C->item[it] & 15, t = C->item[it] >> 4;
-                const SpState S = sp_chunk_state(C, s);
+                const SpState Sx = sp_chunk_state(C, s);
                 const int nk = __popcll(bits);
-                const int cnt = S.w.get(t);
-                const bool aka = sp_aka_in_wall(S, t);
+                const int cnt = Sx.w.get(t);
+                const bool aka = sp_aka_in_wall(Sx, t);
                 for (int variant = 0; variant < 2; variant++) {
                     int vidx, count;  // index of this variant among the tile's existing draw entries; copies of that entry
                     if (!aka) { if (variant == 1) continue; vidx = 0; count = cnt; }
                     else if (variant == 0) { if (cnt < 2) continue; vidx = 0; count = cnt - 1; }
                     else { vidx = cnt >= 2 ? 1 : 0; count = 1; }
                     const int tile = (aka && variant == 1) ? akaize(t) : t;
-                    const u32 akas1 = is_aka(tile) ? (S.akas | (1u << (tile - T_5MR))) : S.akas;  // akas_in_hand after the draw
-                    const int c = S.h.get(d);  // d != t: the draw does not change its count
+                    const u32 akas1 = is_aka(tile) ? (Sx.akas | (1u << (tile - T_5MR))) : Sx.akas;  // akas_in_hand after the draw
+                    const int c = Sx.h.get(d);  // d != t: the draw does not change its count
                     int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
                     if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
                     else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
                     else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
                     bool fresh;
-                    const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), S, tile, dt, fresh);
+                    const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), Sx, tile, dt, fresh);
                     if (fresh && cs >= 0) {
                         const int idx = atomicAdd(&X->n_list, 1);
                         if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
@@ -825,7 +858,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
             sp_static_for<0, TN>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if (j >= T) return;  // uniform (T is a constant of the row)
-                float prob = sp_div(Ac[j], my_m, my_r);
+                float prob = sp_div_domain(Ac[j], my_m, my_r);
                 prob = eff_ln <= j ? prob : 0.f;
                 if constexpr (LK == 0) {
                     const int hp = hp_base + (int)(assume_riichi && j == ln) + (int)(haitei && j == T - 1);
@@ -1266,8 +1299,11 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
             // expand top-down
             for (int lv = cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                for (int c0 = b + SP_NS * (tid / SP_NT); c0 < e; c0 += SP_NS * (SP_THREADS / SP_NT))  // every wavefront its own chunks
-                    sp_expand_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(SP_NS, e - c0), lv);
+                // every wavefront its own chunks; a level too small for four full chunks is split four ways (a chunk pass costs
+                // the same for 4 states as for 16, so idle wavefronts are the only thing to lose)
+                const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
+                for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
+                    sp_expand_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(ns, e - c0), lv);
                 __syncthreads();
                 if (tid == 0) {
                     X.lvl_begin[lv - 1] = e;
@@ -1282,8 +1318,9 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
-                    for (int c0 = b + SP_NS * (tid / SP_NT); c0 < e; c0 += SP_NS * (SP_THREADS / SP_NT))
-                        sp_l0_probe_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(SP_NS, e - c0));
+                    const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
+                    for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
+                        sp_l0_probe_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(ns, e - c0));
                     __syncthreads();
                     const long long t_2a = wall_clock64();
                     const int n_items = min(X.n_items, SP_ITEMS);

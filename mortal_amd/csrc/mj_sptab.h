@@ -124,6 +124,41 @@ MJD SpCountSets sp_count_sets(Hand h) {
     return s;
 }
 constexpr u64 SP_ALL34 = (1ull << 34) - 1;
+// The same per suit group, in 32-bit arithmetic: the group's nine 3-bit count fields (bit 3j = tile j) -> 9-bit tile masks.
+constexpr __host__ __device__ u32 sp_compress9(u32 x) {  // bit 3j -> bit j, j = 0..8
+    x &= 0x01249249u;
+    x = (x ^ (x >> 2)) & 0x010C30C3u;
+    x = (x ^ (x >> 4)) & 0x0100F00Fu;
+    x = (x ^ (x >> 8)) & 0x010000FFu;
+    return (x ^ (x >> 16)) & 0x1FFu;
+}
+constexpr bool sp_compress9_ok() {
+    for (u32 m = 0; m < 512; m++) {
+        u32 x = 0;
+        for (int j = 0; j < 9; j++)
+            if ((m >> j) & 1) x |= 1u << (3 * j);
+        if (sp_compress9(x | 0xFE000000u) != m) return false;
+    }
+    return true;
+}
+static_assert(sp_compress9_ok(), "sp_compress9");
+// fields = the group's 27 bits of a packed hand: count == 1 | count == 2 << 9 | count >= 1 << 18
+MJD u32 sp_group_count_sets(u32 fields) {
+    const u32 M = 0x01249249u, b0 = fields & M, b1 = (fields >> 1) & M, b2 = (fields >> 2) & M;
+    return sp_compress9(b0 & ~b1 & ~b2) | (sp_compress9(b1 & ~b0 & ~b2) << 9) | (sp_compress9(b0 | b1 | b2) << 18);
+}
+MJD u32 sp_group_fields(Hand h, int group) {  // the 27 (honours: 21) field bits of suit group 0..3
+    const u64 w = group < 2 ? h.mp : h.sz;
+    return (u32)(w >> ((group & 1) * 27)) & 0x7FFFFFFu;
+}
+// count classes of h + t from those of h (hc = copies of t in h)
+MJD SpCountSets sp_count_sets_add(SpCountSets cs, int t, int hc) {
+    const u64 bit = 1ull << t;
+    if (hc == 0) { cs.c1 |= bit; cs.nz |= bit; }
+    else if (hc == 1) { cs.c1 &= ~bit; cs.c2 |= bit; }
+    else if (hc == 2) cs.c2 &= ~bit;
+    return cs;
+}
 
 // calc_all's combination of the three forms (shanten.rs:139-150), closed hands (len_div3 == 4)
 MJD int sp_finish3(int sn, int c, int k) {

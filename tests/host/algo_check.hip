@@ -281,6 +281,19 @@ int main(int argc, char** argv) {
         }
         return sp_div(a, b, sp_rcp_refined(b)) == want;
     };
+    auto check_div_domain = [](float a, float b) -> bool {  // the 3-instruction form the kernel uses: its true operand domain only
+        const float want = a / b;
+        const float r = 1.0f / b;
+        for (int k = -1; k <= 1; k++) {
+            const float r0 = k < 0 ? nextafterf(r, 0.f) : k > 0 ? nextafterf(r, 2.f * r) : r;
+            const float e0 = __builtin_fmaf(-b, r0, 1.0f), r1 = __builtin_fmaf(e0, r0, r0);
+            if (sp_div_domain(a, b, r1) != want) {
+                printf("sp_div_domain mismatch: a=%a b=%a k=%d want %a got %a\n", a, b, k, want, sp_div_domain(a, b, r1));
+                return false;
+            }
+        }
+        return true;
+    };
     long nd = 0;
     for (int n_left = 1; n_left <= 123; n_left++)
         for (int sumreq = 0; sumreq <= n_left; sumreq++) {
@@ -296,7 +309,7 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < T; i++)
                     for (int j = i; j < T; j++) {
                         if (nt[i] == 0.f) continue;
-                        if (!check_div(tp[c][j] * nt[j], nt[i])) return 4;
+                        if (!check_div(tp[c][j] * nt[j], nt[i]) || !check_div_domain(tp[c][j] * nt[j], nt[i])) return 4;
                         nd++;
                     }
         }
@@ -310,6 +323,6 @@ int main(int argc, char** argv) {
         if (!check_div(a, b)) return 5;
         nd++;
     }
-    printf("sp_div == IEEE division on %ld operand pairs\n", nd);
+    printf("sp_div == IEEE division on %ld operand pairs (sp_div_domain on the kernel's whole operand domain)\n", nd);
     return 0;
 }
