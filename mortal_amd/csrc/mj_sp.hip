@@ -68,7 +68,7 @@ struct SpWork {                // per-workgroup scratch in HBM (persistent workg
     u64 tag[SP_CAP];           // 0 = empty, else state id | 1 << 63
     SpNode node[SP_CAP];
     u32 list[SP_CAP];          // slots grouped by level: level L occupies [lvl_begin[L], lvl_end[L])
-    u32 elist[SP_CAP + 8192];  // evaluation order of the current level: grouped by required-tile sum, padded per group (sp_sort_level)
+    u32 elist[SP_CAP];         // the same ranges ordered by child-list length for the evaluation (sp_sort_level)
     u32 pool[SP_POOL];         // child lists
     u32 items[SP_ITEMS];       // level 0: (state, winning tile, variant) work items of the dense scoring pass
 };
@@ -748,23 +748,19 @@ MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_const
     }
 }
 
-// LDS of the evaluation, per WAVEFRONT: the probability matrices P[count][j][i] of the wavefront's current required-tile sum
-// (see sp_eval_wave) followed by, per team, the folded child values of the current draw entry (double buffered: one team
-// hand-off per entry).  A team is exactly T lanes wide (T = draws left, a constant of the row): floor(64 / T) teams per
-// wavefront, so rows with 9 draws left run 7 states per wavefront instead of 4.
-MJD int sp_eval_team_floats(int T) { return 8 * (T + 1); }                                  // nx[2][T + 1][4]
-MJD int sp_eval_wave_floats(int T) { return 4 * T * T + (64 / T) * sp_eval_team_floats(T); }  // <= 1652 (T = 17; T = 1: 1028)
-#define SP_EVAL_WAVE_FLOATS 1664
-#define SP_EVAL_LDS_FLOATS ((SP_THREADS / 64) * SP_EVAL_WAVE_FLOATS)
-#define SP_EV_INVALID 0xFFFFFFFFu   // padding entry of the evaluation order (sp_sort_level)
-#define SP_ELIST (SP_CAP + 8192)    // evaluation order: a level's states + at most 124 x 63 padding entries
+// Per-team LDS of the evaluation: the folded child values of the current draw entry (double buffered: one team hand-off
+// per entry) and the numerators A[c][j] = tsumo_prob[c][j] * not_tsumo[j] of the state's probability table.  A team is
+// exactly T lanes wide (T = draws left, a constant of the row): floor(64 / T) teams per wavefront, so rows with 9 draws
+// left run 7 states per wavefront instead of 4.  Team scratch: nx[2][T + 1][4] then A[4][T] floats.
+#define SP_EVAL_LDS_FLOATS (3072 + 2048)            /* (256 / T) teams x (12 T + 8) floats, T >= 1 */
+MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
 #ifndef SP_CH
 #define SP_CH (SP_WGS > 4 ? 4 : 8)  // children (or level-0 draw entries) fetched per round trip
 #endif
 
-// Evaluate the states elist[begin .. end) of one level with the TEAMS of one wavefront (team tw takes begin + tw, + tpw, ...),
-// lane i of a team = turn i: tenpai / win / EV of calc.rs:447-561 into node.val[i].  LK = min(level, 2); TN = 8 / 16 / 17 bounds
-// the unrolled turn loop (rows with at most 8 / 16 / 17 draws left).
+// Evaluate the states list[first], list[first + stride], ... (< end) of one level with a TEAM of T lanes, lane i = turn i:
+// tenpai / win / EV of calc.rs:447-561 into node.val[i].  LK = min(level, 2); TN = 8 / 16 / 17 bounds the unrolled turn loop
+// (rows with at most 8 / 16 / 17 draws left).
 //   level 0 : for every draw entry with a yaku, accumulate its scores;
 //   level > 0: walk the state's child list (written by sp_expand_chunk in the reference's order); per turn fold the
 //              children of a draw entry like discard_slow (max of (int)EV, then discard priority), then accumulate.
@@ -772,11 +768,6 @@ MJD int sp_eval_wave_floats(int T) { return 4 * T * T + (64 / T) * sp_eval_team_
 // not_tsumo[j] / not_tsumo[i] times next[j + 1] — terms the reference skips (`break` on a zero probability, j < i for a
 // lane that runs all j) are added as +0.0 products instead of being branched over (x + 0.0 == x for the non-negative
 // sums here), so the unrolled j loop has no divergent control flow.
-// prob(i, j) depends on the state only through its required-tile sum (the row of the not_tsumo table) and the entry's count:
-// the evaluation order groups the states of a level by that sum (sp_sort_level), a wavefront walks whole groups, and the four
-// matrices P[count][j][i] (zero below the diagonal and past the last possible draw) are built ONCE per group in the
-// wavefront's LDS — a turn of the accumulate is then one LDS read instead of an IEEE division (3 mul/fma on the hoisted
-// reciprocal + a select).  The division itself is unchanged (sp_div_domain), so the sums are bit-identical.
 // A state costs three DEPENDENT round trips to HBM / L2 (list -> node header -> child list -> child values) and little
 // arithmetic, so the loop is software-pipelined: while state k is being folded, the child list (level 0: scores) of state
 // k + 1 and the header of state k + 2 are already in flight.
@@ -786,27 +777,23 @@ struct SpEvalFetch {  // what is prefetched per state
     u32 ent[SP_CH];       // level > 0: first SP_CH child-list entries
 };
 template <int TN, int LK>
-__device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WM, int begin, int end) {
+__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int first, int end, int stride, int ln) {
     SP_ASSUME_LDS(X);
-    SP_ASSUME_LDS(WM);
+    SP_ASSUME_LDS(TM);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int T = X->T;
-    const int wl = threadIdx.x & 63, tpw = 64 / T, tw_raw = wl / T;
-    const bool team_on = tw_raw < tpw;                 // the leftover lanes of a wavefront only help to build P
-    const int tw = team_on ? tw_raw : 0, ln = team_on ? wl - tw_raw * T : 0;
-    float* const Pw = WM;                                              // P[c][j][i]
-    float* const nxb = WM + 4 * T * T + tw * sp_eval_team_floats(T);   // nx[buf][k][4]
+    float* const nxb = TM;                  // nx[buf][k][4]
+    float* const Ab = TM + 8 * (T + 1);     // A[c][j]
     const bool assume_riichi = X->is_menzen && X->prefer_riichi;
     const int hp_base = (int)(assume_riichi && X->calc_double_riichi && ln == 0);
     const bool haitei = X->calc_haitei != 0;
-    int cached_sr = -1;
+    const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
 
-    auto fetch_slot = [&](int i) -> u32 { return (team_on && i < end) ? Wg->elist[i] : SP_EV_INVALID; };
+    auto fetch_slot = [&](int i) -> u32 { return Wg->elist[min(i, end - 1)]; };
     auto fetch_hdr = [&](u32 slot) -> u64 {
         // one 8-byte load (level 0: past the L1 — the yaku bits were set by L2 atomics of the scoring pass)
-        SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot == SP_EV_INVALID ? 0u : slot].child_off);
-        const u64 h = LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return slot == SP_EV_INVALID ? 0ull : h;  // a padding entry is a state without children
+        SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off);
+        return LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto fetch_ent = [&](SpEvalFetch& f) {
         if constexpr (LK > 0) {
@@ -815,15 +802,14 @@ __device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WM, int be
         }
     };
     SpEvalFetch cur, nxt;
-    cur.slot = fetch_slot(begin + tw);
-    nxt.slot = fetch_slot(begin + tpw + tw);
+    cur.slot = fetch_slot(first);
+    nxt.slot = fetch_slot(first + stride);
     cur.hdr = fetch_hdr(cur.slot);
     nxt.hdr = fetch_hdr(nxt.slot);
     fetch_ent(cur);
 
-    for (int i0 = begin; i0 < end; i0 += tpw) {  // uniform over the wavefront
-        const bool valid = cur.slot != SP_EV_INVALID;
-        SP_HBM SpNode& node = Wg->node[valid ? cur.slot : 0u];
+    for (int i = first; i < end; i += stride) {
+        SP_HBM SpNode& node = Wg->node[cur.slot];
         const u32 child_off = (u32)cur.hdr;
         const int n_ch = (int)((cur.hdr >> 32) & 0xFFFF);
         // level > 0: the child values of the first batch; level 0: the scores / counts of the first draw entries
@@ -847,46 +833,33 @@ __device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WM, int be
         }
         // in flight behind them: the next state's child list and the header of the state after it
         SpEvalFetch nn;
-        nn.slot = fetch_slot(i0 + 2 * tpw + tw);
+        nn.slot = fetch_slot(i + 2 * stride);
         fetch_ent(nxt);
         nn.hdr = fetch_hdr(nn.slot);
 
-        // the batch's required-tile sum (the first team of a batch is never padding); a new sum -> rebuild P
-        const int my_sr = min((int)((cur.hdr >> 48) & 0xFF), 123);
-        const int sr = __shfl(my_sr, 0);
-#ifdef MJ_EMU
-        if (valid && my_sr != sr) X->overflow = 1;  // the evaluation order keeps a batch inside one group
-#endif
-        mj_team_sync<64>();  // every team is done with the previous state's nx[] (and with P, if it is rebuilt now)
-        if (sr != cached_sr) {
-            cached_sr = sr;
-            const float* nt = X->not_tsumo[sr];
-            for (int pass = 0; pass < 2; pass++) {  // lanes 0..31: count 2 pass + 1, lanes 32..63: count 2 pass + 2; lane & 31 = turn i
-                const int cc = 2 * pass + (wl >> 5), i = wl & 31;
-                if (i < T) {
-                    const float m_raw = nt[i];  // not_tsumo_probs[i]
-                    const bool on = m_raw != 0.f;
-                    const float m = on ? m_raw : 1.f, r = sp_rcp_refined(m);
-                    const float* tp = X->tsumo_prob[cc];
-                    float* dst = Pw + cc * T * T + i;
-                    for (int j = 0; j < T; j++) {
-                        const float a = tp[j] * nt[j];  // 0 once the required tiles may all be drawn (calc.rs:498-503)
-                        dst[j * T] = (on && i <= j) ? sp_div_domain(a, m, r) : 0.f;
-                    }
-                }
-            }
-            mj_team_sync<64>();
-        }
+        const float* nt = X->not_tsumo[min((int)((cur.hdr >> 48) & 0xFF), 123)];
+        const float m_raw = nt[ln];  // not_tsumo_probs[i] of this lane's turn
+        const bool lane_on = m_raw != 0.f;
+        const float my_m = lane_on ? m_raw : 1.f;
+        const float my_r = sp_rcp_refined(my_m);
+        const int eff_ln = lane_on ? ln : 127;  // `eff_ln <= j` == this lane has a term at turn j
+        mj_team_sync_n(T);  // the team's previous state is done with A[] / nx[]
+        Ab[ln] = tp0 * m_raw;
+        Ab[T + ln] = tp1 * m_raw;
+        Ab[2 * T + ln] = tp2 * m_raw;
+        Ab[3 * T + ln] = tp3 * m_raw;
+        mj_team_sync_n(T);
         float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
 
         // one draw entry: scores (level 0) or the folded child values in nx[buf] (level > 0)
         auto accumulate = [&](int count, int buf, float s0, float s1, float s2, float s3) {
-            const float* Pc = Pw + (count - 1) * T * T + ln;
+            const float* Ac = Ab + (count - 1) * T;
             const float* nx = nxb + buf * 4 * (T + 1);
             sp_static_for<0, TN>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if (j >= T) return;  // uniform (T is a constant of the row)
-                const float prob = Pc[j * T];
+                float prob = sp_div_domain(Ac[j], my_m, my_r);
+                prob = eff_ln <= j ? prob : 0.f;
                 if constexpr (LK == 0) {
                     const int hp = hp_base + (int)(assume_riichi && j == ln) + (int)(haitei && j == T - 1);
                     acc_w += prob;
@@ -968,63 +941,39 @@ __device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WM, int be
                 }
             }
         }
-        if (valid) {
-            SP_HBM float* dst = node.val[ln];
-            dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
-        }
+        SP_HBM float* dst = node.val[ln];
+        dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
         cur = nxt;
         nxt = nn;
     }
 }
 
-// Evaluation order of a level: the states are grouped by their required-tile sum (the row of the not_tsumo table, i.e. the
-// probability matrices of sp_eval_wave), the groups are dealt round-robin to the four wavefronts (neighbouring sums cost about the
-// same), every wavefront's groups lie back to back in elist, and every group is padded to a whole number of batches
-// (tpw = teams per wavefront) so that a batch never straddles two groups.  ev_range[w] = the wavefront's part of elist.
-// The order of states inside a level does not touch the results (each state is evaluated on its own).
-__device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [3 * 128] */, int* ev_range /* LDS [8] */, int b, int e, int tpw) {
+// The teams of a wavefront evaluate consecutive states of a level, and the wavefront runs as long as its slowest team: order
+// the level by child-list length (counting sort over 64 buckets, workgroup-wide) so that neighbours cost about the same (key: children + 4 x draw entries).  The
+// order of states inside a level does not touch the results (each state is evaluated on its own).
+__device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] */, int b, int e) {
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int tid = threadIdx.x;
-    int* const cnt = hist;           // states per sum
-    int* const start = hist + 128;   // first elist index of the group
-    int* const cursor = hist + 256;
-    if (tid < 128) { cnt[tid] = 0; cursor[tid] = 0; }
+    if (tid < 64) hist[tid] = 0;
     __syncthreads();
-    auto sum_of = [&](u32 slot) { return min((int)Wg->node[slot].sumreq, 123); };
-    for (int i = b + tid; i < e; i += SP_THREADS) atomicAdd(&cnt[sum_of(Wg->list[i])], 1);
+    auto cost_key = [&](u32 slot) {  // ~ fold work (children) + accumulate work (draw entries), longest first
+        const SP_HBM SpNode& nd = Wg->node[slot];
+        return 63 - min(((int)nd.n_ch + 4 * (int)nd.n_ent) >> 1, 63);
+    };
+    for (int i = b + tid; i < e; i += SP_THREADS) atomicAdd(&hist[cost_key(Wg->list[i])], 1);
     __syncthreads();
     if (tid == 0) {
-        constexpr int NW = SP_THREADS / 64;
-        int wtot[NW];
-        for (int w = 0; w < NW; w++) wtot[w] = 0;
-        int k = 0;
-        for (int q = 0; q < 124; q++) {
-            const int c = cnt[q];
-            if (c == 0) continue;
-            const int w = k % NW;
-            start[q] = wtot[w] | (w << 24);  // offset inside the wavefront's part, for now
-            wtot[w] += (c + tpw - 1) / tpw * tpw;
-            k++;
+        int off = 0;
+        for (int k = 0; k < 64; k++) {
+            const int c = hist[k];
+            hist[k] = off;
+            off += c;
         }
-        int base[NW], off = 0;
-        for (int w = 0; w < NW; w++) {
-            base[w] = off;
-            ev_range[2 * w] = off;
-            off += wtot[w];
-            ev_range[2 * w + 1] = off;
-        }
-        for (int q = 0; q < 124; q++)
-            if (cnt[q]) start[q] = base[start[q] >> 24] + (start[q] & 0xFFFFFF);
     }
     __syncthreads();
     for (int i = b + tid; i < e; i += SP_THREADS) {
         const u32 slot = Wg->list[i];
-        const int q = sum_of(slot);
-        Wg->elist[start[q] + atomicAdd(&cursor[q], 1)] = slot;
-    }
-    if (tid < 124 && cnt[tid]) {  // the padding of the group's last batch
-        const int c = cnt[tid], padded = (c + tpw - 1) / tpw * tpw;
-        for (int k = c; k < padded; k++) Wg->elist[start[tid] + k] = SP_EV_INVALID;
+        Wg->elist[b + atomicAdd(&hist[cost_key(slot)], 1)] = slot;
     }
     __syncthreads();
 }
@@ -1109,7 +1058,6 @@ __global__ __launch_bounds__(256) void mj_k_order_scatter(const uint8_t* cls, in
 __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ int s_row;
-    __shared__ int s_ev_range[2 * (SP_THREADS / 64)];
     __shared__ union SpTeams {
         TableOne st;                                 // the decision's table record: read during the row set-up only
         SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
@@ -1383,26 +1331,25 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
                         atomicAdd(&P.err[18], (unsigned long long)(wall_clock64() - t_2a));
                     }
                 }
+                sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
                 {
-                    // teams of exactly T lanes, floor(64 / T) per wavefront; every wavefront evaluates its own part of the order
-                    const int tpw = 64 / T, wv = tid >> 6;
-                    sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), s_ev_range, b, e, tpw);
-                    const int eb = s_ev_range[2 * wv], ee = s_ev_range[2 * wv + 1];
-                    __syncthreads();  // the sort's LDS scratch becomes the evaluation scratch
-                    float* lds = s_tm.ev + wv * SP_EVAL_WAVE_FLOATS;
-                    if (eb < ee) {
+                    // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
+                    const int wl = tid & 63, tpw = 64 / T, tw = wl / T, ln = wl - tw * T;
+                    const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
+                    float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
+                    if (tw < tpw && b + team < e) {
                         if (T <= 8) {
-                            if (lv == 0) sp_eval_wave<8, 0>(W, &X, lds, eb, ee);
-                            else if (lv == 1) sp_eval_wave<8, 1>(W, &X, lds, eb, ee);
-                            else sp_eval_wave<8, 2>(W, &X, lds, eb, ee);
+                            if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln);
+                            else if (lv == 1) sp_eval_team<8, 1>(W, &X, lds, b + team, e, n_teams, ln);
+                            else sp_eval_team<8, 2>(W, &X, lds, b + team, e, n_teams, ln);
                         } else if (T <= 16) {
-                            if (lv == 0) sp_eval_wave<16, 0>(W, &X, lds, eb, ee);
-                            else if (lv == 1) sp_eval_wave<16, 1>(W, &X, lds, eb, ee);
-                            else sp_eval_wave<16, 2>(W, &X, lds, eb, ee);
+                            if (lv == 0) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln);
+                            else if (lv == 1) sp_eval_team<16, 1>(W, &X, lds, b + team, e, n_teams, ln);
+                            else sp_eval_team<16, 2>(W, &X, lds, b + team, e, n_teams, ln);
                         } else {
-                            if (lv == 0) sp_eval_wave<17, 0>(W, &X, lds, eb, ee);
-                            else if (lv == 1) sp_eval_wave<17, 1>(W, &X, lds, eb, ee);
-                            else sp_eval_wave<17, 2>(W, &X, lds, eb, ee);
+                            if (lv == 0) sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln);
+                            else if (lv == 1) sp_eval_team<17, 1>(W, &X, lds, b + team, e, n_teams, ln);
+                            else sp_eval_team<17, 2>(W, &X, lds, b + team, e, n_teams, ln);
                         }
                     }
                 }

@@ -167,7 +167,7 @@ inline int log2i(int w) { return w; }  // lane groups of ANY width (team k = lan
 inline int group_alive(int wave, int width, int grp) {
     State& s = S();
     int n = 0;
-    for (int l = grp * width; l < (grp + 1) * width && l < WAVE; l++) {  // a trailing partial group ends with its wavefront
+    for (int l = grp * width; l < (grp + 1) * width; l++) {
         const int t = wave * WAVE + l;
         if (t < s.n_threads && !s.fibers[t].done) n++;
     }
