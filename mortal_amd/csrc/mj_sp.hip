@@ -28,7 +28,10 @@
 
 __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_upload)
 
-#define SP_THREADS 256
+#define SP_THREADS 64           // ONE decision row per WAVEFRONT: a workgroup is one wavefront, SP_WPS * 4 of them per CU.  The rows are
+                                // independent and plentiful (tens of thousands per launch), so the parallelism that fills the chip is
+                                // across rows; inside a row every phase is wavefront-wide and nothing ever waits at a workgroup barrier
+                                // for the slowest of several wavefronts (round 2: four wavefronts per row, idle ~40 % of their time)
 #define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
@@ -38,9 +41,10 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #ifndef SP_ITEM_CAP
 #define SP_ITEM_CAP 64         // draw items (state, required tile) per sub-batch of a chunk: one lane each
 #endif
-#ifndef SP_WGS
-#define SP_WGS 4               // resident workgroups per CU the kernel is compiled for (register budget 512 / SP_WGS per lane)
+#ifndef SP_WPS
+#define SP_WPS 4               // resident wavefronts per SIMD the kernel is compiled for (register budget 512 / SP_WPS per lane)
 #endif
+#define SP_WGS (4 * SP_WPS)    // resident workgroups (= wavefronts) per CU
 
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
@@ -71,6 +75,7 @@ struct SpWork {                // per-workgroup scratch in HBM (persistent workg
     u32 elist[SP_CAP];         // the same ranges ordered by child-list length for the evaluation (sp_sort_level)
     u32 pool[SP_POOL];         // child lists
     u32 items[SP_ITEMS];       // level 0: (state, winning tile, variant) work items of the dense scoring pass
+    float not_tsumo[124][SP_T + 3];  // MAX_TILES_LEFT + 1 = 123 rows (calc.rs:14,148-167); row = sum of required tiles (80-byte rows)
 };
 
 struct SpParams {
@@ -144,7 +149,6 @@ struct SpCtx {  // per-decision constants (LDS)
         prefer_riichi, T, n_left;
     int dora_ind[5];
     float tsumo_prob[4][SP_T];
-    float not_tsumo[124][SP_T];   // MAX_TILES_LEFT + 1 = 123 rows (calc.rs:14,148-167); row = sum of required tiles
     // level bookkeeping
     int lvl_begin[5], lvl_end[5];
     int n_list;
@@ -752,10 +756,10 @@ MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_const
 // per entry) and the numerators A[c][j] = tsumo_prob[c][j] * not_tsumo[j] of the state's probability table.  A team is
 // exactly T lanes wide (T = draws left, a constant of the row): floor(64 / T) teams per wavefront, so rows with 9 draws
 // left run 7 states per wavefront instead of 4.  Team scratch: nx[2][T + 1][4] then A[4][T] floats.
-#define SP_EVAL_LDS_FLOATS (3072 + 2048)            /* (256 / T) teams x (12 T + 8) floats, T >= 1 */
+#define SP_EVAL_LDS_FLOATS 1280                     /* (64 / T) teams x (12 T + 8) floats, T >= 1 */
 MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
 #ifndef SP_CH
-#define SP_CH (SP_WGS > 4 ? 4 : 8)  // children (or level-0 draw entries) fetched per round trip
+#define SP_CH (SP_WPS > 4 ? 4 : 8)  // children (or level-0 draw entries) fetched per round trip
 #endif
 
 // Evaluate the states list[first], list[first + stride], ... (< end) of one level with a TEAM of T lanes, lane i = turn i:
@@ -837,8 +841,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
         fetch_ent(nxt);
         nn.hdr = fetch_hdr(nn.slot);
 
-        const float* nt = X->not_tsumo[min((int)((cur.hdr >> 48) & 0xFF), 123)];
-        const float m_raw = nt[ln];  // not_tsumo_probs[i] of this lane's turn
+        const float m_raw = Wg->not_tsumo[min((int)((cur.hdr >> 48) & 0xFF), 123)][ln];  // not_tsumo_probs[i] of this lane's turn
         const bool lane_on = m_raw != 0.f;
         const float my_m = lane_on ? m_raw : 1.f;
         const float my_r = sp_rcp_refined(my_m);
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(256) void mj_k_order_scatter(const uint8_t* cls, in
     if (i < n) order[base[c] + r] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
+__global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ int s_row;
     __shared__ union SpTeams {
@@ -1067,9 +1070,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
     const int tid = threadIdx.x;
     constexpr int O_SP = 889;  // Lay<4>::sp
 
-    // the hash tags must start empty
-    for (int i = tid; i < SP_CAP; i += SP_THREADS) W->tag[i] = 0ull;
-    __syncthreads();
+    // the hash tags start empty: zeroed once when the work area is allocated, and every row clears the tags it set
 
     const long long t_wg0 = P.prof ? wall_clock64() : 0;  // MJ_SP_PROF: workgroup lifetime / queue + reset time (err[19..22])
     long long t_pop = 0, t_reset = 0;
@@ -1209,17 +1210,21 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
         __syncthreads();
         const int T = X.T, n_left = X.n_left;
         // build_tsumo_prob_table / build_not_tsumo_prob_table (calc.rs:135-167)
-        if (tid < 4 * SP_T) {
-            int i = tid / SP_T, j = tid % SP_T;
+        for (int q = tid; q < 4 * SP_T; q += SP_THREADS) {
+            int i = q / SP_T, j = q % SP_T;
             X.tsumo_prob[i][j] = j < T ? (float)(i + 1) / (float)(n_left - j) : 0.f;
         }
-        if (tid < 124) {
-            float* r = X.not_tsumo[tid];
-            for (int j = 0; j < SP_T; j++) r[j] = 0.f;
-            if (tid <= 122 && tid < n_left + 1) {
-                r[0] = 1.f;
-                int lim = min(T - 1, n_left - tid);
-                for (int j = 0; j < lim; j++) r[j + 1] = r[j] * (float)(n_left - tid - j) / (float)(n_left - j);
+        // the not_tsumo rows live in the wavefront's HBM work area (read once per evaluated state); only rows up to the wall size
+        // can be addressed by a required-tile sum
+        for (int q = tid; q < 124; q += SP_THREADS) {
+            SP_HBM float* r = ((SP_HBM SpWork*)W)->not_tsumo[q];
+            const bool row_on = q <= 122 && q < n_left + 1;
+            const int lim = min(T - 1, n_left - q);
+            float cur = row_on ? 1.f : 0.f;
+            r[0] = cur;
+            for (int j = 0; j < SP_T - 1; j++) {
+                cur = (row_on && j < lim) ? cur * (float)(n_left - q - j) / (float)(n_left - j) : 0.f;
+                r[j + 1] = cur;
             }
         }
         __syncthreads();
@@ -1437,11 +1442,11 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
                 // take_while(p > 0) on the tenpai probs becomes an AND over the lower turns' flags (instead of a chain of up to
                 // 17 dependent loads per thread)
                 float* tv = s_tm.ev;  // [candidate slot * SP_T + turn][4]: tenpai, win, ev, alive
-                static_assert(SP_EVAL_LDS_FLOATS >= (SP_THREADS / SP_T) * SP_T * 4, "table staging fits the evaluation scratch");
+                static_assert(SP_EVAL_LDS_FLOATS >= SP_MAX_CAND * SP_T * 4, "table staging fits the evaluation scratch");
                 const int n_src = can_discard0 ? n_cand : 1;
-                {
-                    const int c = tid / SP_T, turn = tid % SP_T;
-                    if (c < n_src && c < SP_THREADS / SP_T) {
+                for (int q = tid; q < n_src * SP_T; q += SP_THREADS) {
+                    const int c = q / SP_T, turn = q % SP_T;
+                    {
                         float tpv = 0.f, wpv = 0.f, evv = 0.f;
                         if (turn < T) {
                             const SpNode& nd = W->node[X.cand_slot[can_discard0 ? c : first]];
@@ -1460,13 +1465,15 @@ __global__ __launch_bounds__(SP_THREADS, SP_WGS) void mj_k_sp(SpParams P) {
                     return alive;
                 };
                 if (can_discard0) {
-                    const int c = tid / SP_T, turn = tid % SP_T;
-                    if (c < n_cand && c < SP_THREADS / SP_T && turn < T && alive_upto(c, turn)) {
-                        const int col = after_riichi ? deaka(last_tsumo) : deaka(X.cand_tile[c]);
-                        const float* src = tv + (c * SP_T + turn) * 4;
-                        out[(O_SP + 72 + turn) * 34 + col] = src[0];
-                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
-                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
+                    for (int q = tid; q < n_cand * SP_T; q += SP_THREADS) {
+                        const int c = q / SP_T, turn = q % SP_T;
+                        if (turn < T && alive_upto(c, turn)) {
+                            const int col = after_riichi ? deaka(last_tsumo) : deaka(X.cand_tile[c]);
+                            const float* src = tv + (c * SP_T + turn) * 4;
+                            out[(O_SP + 72 + turn) * 34 + col] = src[0];
+                            out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
+                            out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
+                        }
                     }
                 } else {
                     for (int w = tid; w < SP_T * 34; w += SP_THREADS) {
