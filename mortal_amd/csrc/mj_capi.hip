@@ -580,7 +580,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     HIP_OK(hipGetLastError());
     if (ep.version == 4) {  // SP block, rows 889..1011 (mj_sp.hip)
         if (!P->sp_work) {
-            P->sp_grid = 256 * SP_WGS;  // persistent single-wavefront workgroups: SP_WGS per CU, one decision row each at a time
+            P->sp_grid = 256 * SP_WGS;  // persistent workgroups: SP_WGS per CU, one decision row each at a time
             if (P->sp_grid > P->max_rows) P->sp_grid = P->max_rows;  // never more rows than that in a launch (small pools: small work area)
             HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
             for (int g = 0; g < P->sp_grid; g++) HIP_OK(hipMemsetAsync(P->sp_work[g].tag, 0, sizeof(P->sp_work[g].tag), s));  // empty hash sets

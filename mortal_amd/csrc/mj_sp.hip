@@ -28,10 +28,12 @@
 
 __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_upload)
 
-#define SP_THREADS 64           // ONE decision row per WAVEFRONT: a workgroup is one wavefront, SP_WPS * 4 of them per CU.  The rows are
-                                // independent and plentiful (tens of thousands per launch), so the parallelism that fills the chip is
-                                // across rows; inside a row every phase is wavefront-wide and nothing ever waits at a workgroup barrier
-                                // for the slowest of several wavefronts (round 2: four wavefronts per row, idle ~40 % of their time)
+#ifndef SP_THREADS
+#define SP_THREADS 256          // threads per workgroup = per decision row in flight.  Measured in round 3 (-DSP_THREADS=64: one row per
+                                // wavefront, 16 single-wavefront workgroups per CU): the summed wavefront time drops by 14 % (nothing waits
+                                // at workgroup barriers), but the heaviest rows (~6 k states) then take ~23 ms on their single wavefront
+                                // and the launch lasts as long as they do: 39.5 vs 22.5 ms.  Four wavefronts per row it stays.
+#endif
 #define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
@@ -44,7 +46,7 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #ifndef SP_WPS
 #define SP_WPS 4               // resident wavefronts per SIMD the kernel is compiled for (register budget 512 / SP_WPS per lane)
 #endif
-#define SP_WGS (4 * SP_WPS)    // resident workgroups (= wavefronts) per CU
+#define SP_WGS (4 * SP_WPS * 64 / SP_THREADS)  // resident workgroups per CU
 
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
@@ -756,7 +758,7 @@ MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_const
 // per entry) and the numerators A[c][j] = tsumo_prob[c][j] * not_tsumo[j] of the state's probability table.  A team is
 // exactly T lanes wide (T = draws left, a constant of the row): floor(64 / T) teams per wavefront, so rows with 9 draws
 // left run 7 states per wavefront instead of 4.  Team scratch: nx[2][T + 1][4] then A[4][T] floats.
-#define SP_EVAL_LDS_FLOATS 1280                     /* (64 / T) teams x (12 T + 8) floats, T >= 1 */
+#define SP_EVAL_LDS_FLOATS ((SP_THREADS / 64) * 1280)  /* per wavefront (64 / T) teams x (12 T + 8) floats, T >= 1 */
 MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
 #ifndef SP_CH
 #define SP_CH (SP_WPS > 4 ? 4 : 8)  // children (or level-0 draw entries) fetched per round trip
