@@ -151,6 +151,31 @@ size_t mj_debug_table_size(void);
 const char* mj_debug_layout(void);
 int mj_obs_rows(int version);
 
+/* Debug/test: the pure rule functions of the device code applied to explicit inputs, one device thread per query (no pool
+ * needed, only mj_tables_upload).  This is how the reference's own known-answer tests reach the HIP code
+ * (algo/shanten.rs:158-201, algo/agari.rs:920-1379, algo/point.rs:121-153; tests/test_gpu_kats.py).
+ *   op 0 calc_shanten(tehai, len_div3)                       -> r0 = shanten            (algo/shanten.rs:139-150)
+ *   op 1 AgariCalculator::search_yakus                        -> r0 = kind (0 none, 1 fu/han, 2 yakuman), r1 = fu, r2 = han or
+ *                                                                yakuman count           (algo/agari.rs:260-288)
+ *   op 2 AgariCalculator::has_yaku                            -> r0 = 0 / 1
+ *   op 3 AgariCalculator::agari(additional_hans, doras)       -> r0..r2 as op 1; r3 = 1   (algo/agari.rs:228-258)
+ *        followed by Agari::point(arg0 = is_oya)              -> p0 = ron, p1 = tsumo_ko, p2 = tsumo_oya
+ *   op 4 check_ankan_after_riichi(tehai incl. the drawn tile, len_div3, arg0 = tile), non-strict -> r0 (algo/agari.rs:854-912)
+ *   op 5 Point::calc(arg0 = is_oya, arg1 = fu, arg2 = han)    -> p0..p2                   (algo/point.rs:13-112)
+ * Queries and results are host arrays. */
+typedef struct MjAlgoQuery {
+    uint8_t tehai[34];                                  /* tile counts, red fives counted as fives (34-tile form) */
+    uint8_t chis[4], pons[4], minkans[4], ankans[4];    /* deaka'd tile ids (lowest tile of a chi) */
+    uint8_t n_chis, n_pons, n_minkans, n_ankans;
+    uint8_t len_div3, is_menzen, bakaze, jikaze, winning_tile, is_ron, additional_hans, doras;
+    uint8_t op, arg0, arg1, arg2;
+    uint8_t pad[6];
+} MjAlgoQuery;                                          /* 72 bytes */
+typedef struct MjAlgoResult {
+    int32_t r0, r1, r2, r3, p0, p1, p2, p3;
+} MjAlgoResult;
+int mj_algo_query(const MjAlgoQuery* queries_host, int n, MjAlgoResult* results_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,53 @@
 #include "mj_encode.hip"
 #include "mj_sp.hip"
 
+static_assert(sizeof(MjAlgoQuery) == 72, "MjAlgoQuery layout");
+// include/mortal_amd.h mj_algo_query: one thread per query, the same device functions the step / encode / SP kernels call
+__global__ __launch_bounds__(64) void mj_k_algo_query(const MjAlgoQuery* q, int n, MjAlgoResult* out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const MjAlgoQuery Q = q[i];
+    MjAlgoResult R = {0, 0, 0, 0, 0, 0, 0, 0};
+    Hand h = {0, 0};
+    for (int t = 0; t < 34; t++)
+        for (int c = 0; c < (int)Q.tehai[t] && c < 4; c++) h.inc(t);
+    AgariIn in;
+    in.tehai = h;
+    for (int k = 0; k < 4; k++) {
+        in.m.chis[k] = Q.chis[k];
+        in.m.pons[k] = Q.pons[k];
+        in.m.minkans[k] = Q.minkans[k];
+        in.m.ankans[k] = Q.ankans[k];
+    }
+    in.m.n_chis = Q.n_chis;
+    in.m.n_pons = Q.n_pons;
+    in.m.n_minkans = Q.n_minkans;
+    in.m.n_ankans = Q.n_ankans;
+    in.is_menzen = Q.is_menzen != 0;
+    in.bakaze = Q.bakaze;
+    in.jikaze = Q.jikaze;
+    in.winning_tile = Q.winning_tile;
+    in.is_ron = Q.is_ron != 0;
+    auto put = [&](const Agari& a) { R.r0 = a.kind; R.r1 = a.fu; R.r2 = a.han; };
+    auto put_point = [&](const Point& p) { R.p0 = p.ron; R.p1 = p.tsumo_ko; R.p2 = p.tsumo_oya; };
+    switch (Q.op) {
+        case 0: R.r0 = calc_all(c_mj_tables, h, Q.len_div3); break;
+        case 1: put(agari_search(c_mj_tables, in, false)); break;
+        case 2: R.r0 = agari_search(c_mj_tables, in, true).kind != 0; break;
+        case 3: {
+            const Agari a = agari_full(c_mj_tables, in, Q.additional_hans, Q.doras);
+            put(a);
+            R.r3 = 1;
+            if (a.kind) put_point(agari_point(a, Q.arg0 != 0));
+            break;
+        }
+        case 4: R.r0 = check_ankan_after_riichi(c_mj_tables, h, Q.len_div3, Q.arg0); break;
+        case 5: put_point(point_calc(Q.arg0 != 0, Q.arg1, Q.arg2)); break;
+        default: R.r3 = -1; break;
+    }
+    out[i] = R;
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -126,6 +173,24 @@ const char* mj_last_error(void) { return g_err.c_str(); }
 int mj_abi_version(void) { return 1; }
 int mj_obs_rows(int version) { return version == 1 ? 938 : version == 2 ? 942 : version == 3 ? 934 : version == 4 ? 1012 : -1; }
 size_t mj_debug_table_size(void) { return sizeof(TableOne); }
+int mj_algo_query(const MjAlgoQuery* queries_host, int n, MjAlgoResult* results_host, void* stream) {
+    if (!g_tables.ready) return fail("mj_tables_upload has not been called");
+    if (n <= 0) return 0;
+    if (!queries_host || !results_host) return fail("null query / result buffer");
+    MjAlgoQuery* dq = nullptr;
+    MjAlgoResult* dr = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_OK(hipMalloc(&dq, (size_t)n * sizeof(MjAlgoQuery)));
+    HIP_OK(hipMalloc(&dr, (size_t)n * sizeof(MjAlgoResult)));
+    HIP_OK(hipMemcpyAsync(dq, queries_host, (size_t)n * sizeof(MjAlgoQuery), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(mj_k_algo_query, dim3((n + 63) / 64), dim3(64), 0, s, dq, n, dr);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(results_host, dr, (size_t)n * sizeof(MjAlgoResult), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    hipFree(dq);
+    hipFree(dr);
+    return 0;
+}
 // "name:elem_size:count:offset;..." of struct TableOne, so a host tool can decode mj_debug_table() generically
 const char* mj_debug_layout(void) {
     static std::string s;

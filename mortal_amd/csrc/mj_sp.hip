@@ -781,6 +781,7 @@ struct SpEvalFetch {  // what is prefetched per state
     u32 slot;
     u64 hdr;              // child_off | n_ch << 32 | sumreq << 48
     u32 ent[SP_CH];       // level > 0: first SP_CH child-list entries
+    float m;              // not_tsumo_probs[turn of this lane] of the state's required-tile sum (a row of the HBM table)
 };
 template <int TN, int LK>
 __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int first, int end, int stride, int ln) {
@@ -801,7 +802,8 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
         SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off);
         return LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    auto fetch_ent = [&](SpEvalFetch& f) {
+    auto fetch_ent = [&](SpEvalFetch& f) {  // what the header addresses: the child list and the not_tsumo row
+        f.m = Wg->not_tsumo[min((int)((f.hdr >> 48) & 0xFF), 123)][ln];
         if constexpr (LK > 0) {
 #pragma unroll
             for (int q = 0; q < SP_CH; q++) f.ent[q] = Wg->pool[min((int)(u32)f.hdr + q, SP_POOL - 1)];
@@ -843,7 +845,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
         fetch_ent(nxt);
         nn.hdr = fetch_hdr(nn.slot);
 
-        const float m_raw = Wg->not_tsumo[min((int)((cur.hdr >> 48) & 0xFF), 123)][ln];  // not_tsumo_probs[i] of this lane's turn
+        const float m_raw = cur.m;  // not_tsumo_probs[i] of this lane's turn
         const bool lane_on = m_raw != 0.f;
         const float my_m = lane_on ? m_raw : 1.f;
         const float my_r = sp_rcp_refined(my_m);

@@ -149,3 +149,16 @@ def test_emu_reference_state_scenarios_and_bot(oracle, emu):
             G.test_reference_bench_kyoku_obs_device_vs_oracle(oracle, pid)
     finally:
         PlayerState.pool_cls = old
+
+
+def test_emu_reference_kats_and_generated_hands(oracle, emu):
+    """tests/test_gpu_kats.py on the emulated kernels: the reference's shanten / ankan / agari / point KATs through
+    `mj_algo_query`, and generated complete hands with random melds device vs oracle (reduced count)."""
+    import test_gpu_kats as K
+
+    lib = emu._L
+    st = K.check_reference_kats(oracle, lib)
+    assert st["shanten"] == 19 and st["agari"] == 25 and st["open"] >= 5
+    assert K.check_point_sweep(lib) > 250
+    st = K.check_generated_hands(oracle, 4000, 7, lib)
+    assert st["open"] > 1000 and st["kans"] > 500 and st["yakuman"] > 30 and st["none"] > 30, st
