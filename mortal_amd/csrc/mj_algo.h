@@ -442,10 +442,15 @@ MJD Point point_yakuman(bool is_oya, int n) {
 MJD int tsumo_total(Point p, bool is_oya) { return is_oya ? p.tsumo_ko * 3 : p.tsumo_ko * 2 + p.tsumo_oya; }
 
 // ---------------------------------------------------------------- agari (agari.rs)
-struct Melds {  // own open/closed sets, deaka'd tile ids (lowest tile for chi)
-    u8 chis[4], pons[4], minkans[4], ankans[4];
+// Everything below lives in registers: the up to four sets of a hand (and its up to 14 distinct tiles) are byte lists packed in
+// 32 / 64-bit words, never arrays — a dynamically indexed local array is scratch memory, and round 2's array-based version
+// spent most of the level-0 scoring pass of the SP kernel waiting for it.
+#define PK8(p, i) ((int)(((p) >> (8 * (i))) & 0xFFu))
+struct Melds {  // own open/closed sets, deaka'd tile ids (lowest tile for chi), one byte per set
+    u32 chis, pons, minkans, ankans;
     u8 n_chis, n_pons, n_minkans, n_ankans;
 };
+MJD void melds_put(u32& list, int i, int tile) { list = (list & ~(0xFFu << (8 * i))) | ((u32)(tile & 0xFF) << (8 * i)); }
 struct AgariIn {
     Hand tehai;  // 3n+2 incl. the winning tile
     Melds m;
@@ -465,44 +470,34 @@ MJD bool agari_better(Agari a, Agari b) {  // a > b per agari.rs:180-195
     return a.fu > b.fu;
 }
 
-// agari.rs:767-838: distinct tiles in ascending id + run-length key
-MJDN u32 tile14_and_key(Hand h, u8 tile14[14]) {
-    int n14 = 0;
-    u32 key = 0;
-    int bit = -1;
-    bool prev = false;
-    for (int t = 0; t < 27; t++) {
-        int c = h.get(t);
-        if (c > 0) {
-            prev = true;
-            tile14[n14++] = (u8)t;
-            bit += 1;
-            if (c == 2) { key |= 0b11u << bit; bit += 2; }
-            else if (c == 3) { key |= 0b1111u << bit; bit += 4; }
-            else if (c == 4) { key |= 0b111111u << bit; bit += 6; }
-        } else if (prev) {
-            prev = false;
+// agari.rs:767-838: the distinct tiles in ascending id (byte i of lo | hi << 64) + the run-length key.  The reference walks all
+// 34 kinds and closes a run at the first empty kind, at a suit boundary and after every honour; walking only the held kinds,
+// a run is closed right before the next one opens and once at the end — the same bit positions.
+struct Tile14 {
+    u64 lo, hi;
+    MJD int at(u32 i) const { return (int)(((i < 8 ? lo : hi) >> (8 * (i & 7))) & 0xFF); }
+};
+MJD u32 tile14_and_key(Hand h, Tile14& t14) {
+    t14.lo = t14.hi = 0;
+    u32 key = 0, n14 = 0;
+    int bit = -1, prev = -2;
+    for (u64 m = h.nonzero_mask(); m; m &= m - 1) {
+        const int t = __ffsll((long long)m) - 1, c = h.get(t);
+        const bool same_run = t < 27 && t == prev + 1 && (t % 9) != 0;
+        if (prev >= 0 && !same_run) {  // close the previous run
             key |= 1u << bit;
             bit += 1;
         }
-        if (t % 9 == 8 && prev) {
-            prev = false;
-            key |= 1u << bit;
-            bit += 1;
-        }
-    }
-    for (int t = 27; t < 34; t++) {
-        int c = h.get(t);
-        if (c == 0) continue;
-        tile14[n14++] = (u8)t;
+        if (n14 < 8) t14.lo |= (u64)t << (8 * n14);
+        else t14.hi |= (u64)t << (8 * (n14 - 8));
+        n14++;
         bit += 1;
         if (c == 2) { key |= 0b11u << bit; bit += 2; }
         else if (c == 3) { key |= 0b1111u << bit; bit += 4; }
         else if (c == 4) { key |= 0b111111u << bit; bit += 6; }
-        key |= 1u << bit;
-        bit += 1;
+        prev = t;
     }
-    for (int i = n14; i < 14; i++) tile14[i] = 0;
+    if (prev >= 0) key |= 1u << bit;
     return key;
 }
 MJD int agari_find(const MjTablesDev& T, u32 key) {  // index or -1; hashed (1-2 gathers instead of a 14-step bisection)
@@ -518,33 +513,41 @@ MJD int agari_find(const MjTablesDev& T, u32 key) {  // index or -1; hashed (1-2
 
 // One decomposition of the concealed part + the caller's melds (agari.rs:100-124, 287-761).
 struct DivWork {
-    const AgariIn* in;
+    u32 kotsu;      // byte list: menzen kotsu, then pons, minkans, ankans (at most four sets in all)
+    u32 shuntsu;    // byte list: menzen shuntsu, then chis
+    int n_mk, n_kotsu, n_ms, n_shuntsu;
     int pair_tile;
-    u8 kotsu[8];    // menzen kotsu, then pons, minkans, ankans
-    int n_mk, n_kotsu;
-    u8 shuntsu[8];  // menzen shuntsu, then chis
-    int n_ms, n_shuntsu;
-    u8 seven[7];    // chitoi pairs
     bool has_chitoi, has_chuuren, has_ittsuu, has_ryanpeikou, has_ipeikou;
     bool wt_minkou;  // winning_tile_makes_minkou
 };
-MJDN void div_init(DivWork& w, const AgariIn& in, const u8 tile14[14], u32 v) {  // agari.rs:126-157, 288-338
-    w.in = &in;
-    w.pair_tile = tile14[(v >> 6) & 15];
-    int nk = v & 7, ns = (v >> 3) & 7;
+MJD DivWork div_init(const AgariIn& in, const Tile14& t14, u32 v) {  // agari.rs:126-157, 288-338
+    DivWork w;
+    w.pair_tile = t14.at((v >> 6) & 15);
+    const int nk = v & 7, ns = (v >> 3) & 7;
     w.n_mk = nk;
     w.n_ms = ns;
-    for (int i = 0; i < nk; i++) w.kotsu[i] = tile14[(v >> (10 + i * 4)) & 15];
-    for (int i = 0; i < ns; i++) w.shuntsu[i] = tile14[(v >> (10 + (nk + i) * 4)) & 15];
+    w.kotsu = w.shuntsu = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < nk) melds_put(w.kotsu, i, t14.at((v >> (10 + i * 4)) & 15));
+        if (i < ns) melds_put(w.shuntsu, i, t14.at((v >> (10 + (nk + i) * 4)) & 15));
+    }
     int k = nk;
-    for (int i = 0; i < in.m.n_pons; i++) w.kotsu[k++] = in.m.pons[i];
-    for (int i = 0; i < in.m.n_minkans; i++) w.kotsu[k++] = in.m.minkans[i];
-    for (int i = 0; i < in.m.n_ankans; i++) w.kotsu[k++] = in.m.ankans[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < (int)in.m.n_pons && k < 4) melds_put(w.kotsu, k++, PK8(in.m.pons, i));
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < (int)in.m.n_minkans && k < 4) melds_put(w.kotsu, k++, PK8(in.m.minkans, i));
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < (int)in.m.n_ankans && k < 4) melds_put(w.kotsu, k++, PK8(in.m.ankans, i));
     w.n_kotsu = k;
     k = ns;
-    for (int i = 0; i < in.m.n_chis; i++) w.shuntsu[k++] = in.m.chis[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < (int)in.m.n_chis && k < 4) melds_put(w.shuntsu, k++, PK8(in.m.chis, i));
     w.n_shuntsu = k;
-    for (int i = 0; i < 7; i++) w.seven[i] = tile14[i];
     w.has_chitoi = (v >> 26) & 1;
     w.has_chuuren = (v >> 27) & 1;
     w.has_ittsuu = (v >> 28) & 1;
@@ -554,33 +557,40 @@ MJDN void div_init(DivWork& w, const AgariIn& in, const u8 tile14[14], u32 v) { 
     bool r = false;
     if (in.is_ron) {
         bool in_kotsu = false;
-        for (int i = 0; i < nk; i++) in_kotsu |= w.kotsu[i] == in.winning_tile;
+#pragma unroll
+        for (int i = 0; i < 4; i++) in_kotsu |= i < nk && PK8(w.kotsu, i) == in.winning_tile;
         if (in_kotsu) {
             if (in.winning_tile >= 27) r = true;
             else {
-                int kind = in.winning_tile / 9, num = in.winning_tile % 9;
-                int low = kind * 9 + (num >= 2 ? num - 2 : 0), high = kind * 9 + min(num, 6);
+                const int kind = in.winning_tile / 9, num = in.winning_tile % 9;
+                const int low = kind * 9 + (num >= 2 ? num - 2 : 0), high = kind * 9 + min(num, 6);
                 bool covered = false;
-                for (int i = 0; i < ns; i++) covered |= w.shuntsu[i] >= low && w.shuntsu[i] <= high;
+#pragma unroll
+                for (int i = 0; i < 4; i++) covered |= i < ns && PK8(w.shuntsu, i) >= low && PK8(w.shuntsu, i) <= high;
                 r = !covered;
             }
         }
     }
     w.wt_minkou = r;
+    return w;
 }
-MJDN int div_calc_fu(const DivWork& w, bool has_pinfu) {  // agari.rs:367-452
-    const AgariIn& in = *w.in;
+MJD int div_calc_fu(const AgariIn& in, const DivWork& w, bool has_pinfu) {  // agari.rs:367-452
     if (w.has_chitoi) return 25;
     int fu = 20;
-    for (int i = 0; i < w.n_mk; i++) {
-        int t = w.kotsu[i];
-        bool mink = w.wt_minkou && t == in.winning_tile, yao = is_yaokyuu(t);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i >= w.n_mk) continue;
+        const int t = PK8(w.kotsu, i);
+        const bool mink = w.wt_minkou && t == in.winning_tile, yao = is_yaokyuu(t);
         fu += (!mink && yao) ? 8 : (mink && !yao) ? 2 : 4;
     }
-    for (int i = 0; i < in.m.n_pons; i++) fu += is_yaokyuu(in.m.pons[i]) ? 4 : 2;
-    for (int i = 0; i < in.m.n_ankans; i++) fu += is_yaokyuu(in.m.ankans[i]) ? 32 : 16;
-    for (int i = 0; i < in.m.n_minkans; i++) fu += is_yaokyuu(in.m.minkans[i]) ? 16 : 8;
-    int pt = w.pair_tile;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < (int)in.m.n_pons) fu += is_yaokyuu(PK8(in.m.pons, i)) ? 4 : 2;
+        if (i < (int)in.m.n_ankans) fu += is_yaokyuu(PK8(in.m.ankans, i)) ? 32 : 16;
+        if (i < (int)in.m.n_minkans) fu += is_yaokyuu(PK8(in.m.minkans, i)) ? 16 : 8;
+    }
+    const int pt = w.pair_tile;
     if (pt >= T_P && pt <= T_C) fu += 2;
     else {
         if (pt == in.bakaze) fu += 2;
@@ -597,10 +607,11 @@ MJDN int div_calc_fu(const DivWork& w, bool has_pinfu) {  // agari.rs:367-452
         if (pt == in.winning_tile) fu += 2;
         else {
             bool kp = false;
-            for (int i = 0; i < w.n_ms; i++) {
-                int s = w.shuntsu[i];
-                kp |= s + 1 == in.winning_tile || (s % 9 == 0 && s + 2 == in.winning_tile) ||
-                      (s % 9 == 6 && s == in.winning_tile);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i >= w.n_ms) continue;
+                const int s = PK8(w.shuntsu, i);
+                kp |= s + 1 == in.winning_tile || (s % 9 == 0 && s + 2 == in.winning_tile) || (s % 9 == 6 && s == in.winning_tile);
             }
             if (kp) fu += 2;
         }
@@ -608,74 +619,66 @@ MJDN int div_calc_fu(const DivWork& w, bool has_pinfu) {  // agari.rs:367-452
     return ((fu - 1) / 10 + 1) * 10;
 }
 
-// Yaku search of one decomposition.  `any_only`: stop at the first yaku found (has_yaku path).
-// Unlike the reference's early-return macro we simply test han|yakuman after each group — the
-// boolean answer is identical because every check only ever adds.
-MJDN Agari div_search_yakus(const DivWork& w, bool any_only) {  // agari.rs:454-761
-    const AgariIn& in = *w.in;
+// Yaku search of one decomposition.  `any_only`: the caller only wants to know whether there is a yaku (has_yaku path) — every
+// check only ever adds, so the reference's early returns change nothing but the time; fu is skipped then.
+// `hand_nz`: the concealed hand's held kinds (the seven pairs of a chitoi decomposition).
+MJD Agari div_search_yakus(const AgariIn& in, const DivWork& w, u64 hand_nz, bool any_only) {  // agari.rs:454-761
     int han = 0, yakuman = 0;
     const int pt = w.pair_tile;
     const bool pair_is_dragon = pt >= T_P && pt <= T_C;
     bool has_pinfu = false;
     if (w.n_ms == 4 && !pair_is_dragon && pt != in.bakaze && pt != in.jikaze) {
+#pragma unroll
         for (int i = 0; i < 4; i++) {
-            int s = w.shuntsu[i], num = s % 9 + 1;
+            const int s = PK8(w.shuntsu, i), num = s % 9 + 1;
             has_pinfu |= (num <= 6 && s == in.winning_tile) || (num >= 2 && s + 2 == in.winning_tile);
         }
     }
-#define DONE_IF_ANY() if (any_only && (han | yakuman)) goto done
     if (has_pinfu) han += 1;
     if (w.has_chitoi) han += 2;
     if (w.has_ryanpeikou) han += 3;
     if (w.has_chuuren) yakuman += 1;
-    DONE_IF_ANY();
+    // tile sets as bit masks over the 34 kinds: kotsu (+ pair), shuntsu starts
+    u64 kmask = 0;
+    u32 s_bits = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < w.n_kotsu) kmask |= 1ull << PK8(w.kotsu, i);
+        if (i < w.n_shuntsu) s_bits |= 1u << PK8(w.shuntsu, i);  // tile ids < 27
+    }
+    constexpr u64 SIMPLES = 0x7FFFFFFull & ~((1ull << 0) | (1ull << 8) | (1ull << 9) | (1ull << 17) | (1ull << 18) | (1ull << 26));  // 2..8 of each suit
+    constexpr u64 HONOURS = 0x7Full << 27;
+    constexpr u32 SEQ_SIMPLE = 0b000111110u | (0b000111110u << 9) | (0b000111110u << 18);  // sequences 234 .. 678 (start 2..6)
     {
-        bool has_tanyao = true, has_toitoi, all_yao = true, yao_jihai = false;
-        u32 kinds_seen = 0;  // bit kind (0..2) for suited, bit 3 for honours, over every set + pair
-        if (w.has_chitoi) {
-            for (int i = 0; i < 7; i++) {
-                int t = w.seven[i], kind = t / 9, num = t % 9;
-                has_tanyao &= kind < 3 && num > 0 && num < 8;
-                bool y = kind >= 3 || num == 0 || num == 8;
-                all_yao &= y;
-                yao_jihai |= kind >= 3;
-                kinds_seen |= 1u << min(kind, 3);
-            }
-        } else {
-            for (int i = 0; i < w.n_shuntsu; i++) {
-                int s = w.shuntsu[i], num = s % 9;
-                has_tanyao &= num > 0 && num < 6;
-                kinds_seen |= 1u << (s / 9);
-            }
-            for (int i = 0; i <= w.n_kotsu; i++) {
-                int t = i < w.n_kotsu ? w.kotsu[i] : pt, kind = t / 9, num = t % 9;
-                has_tanyao &= kind < 3 && num > 0 && num < 8;
-                bool y = kind >= 3 || num == 0 || num == 8;
-                all_yao &= y;
-                yao_jihai |= kind >= 3;
-                kinds_seen |= 1u << min(kind, 3);
-            }
-        }
+        bool has_tanyao, all_yao, yao_jihai;
+        u32 kinds_seen;  // bit kind (0..2) for suited, bit 3 for honours, over every set + pair
+        const u64 solid = w.has_chitoi ? hand_nz : (kmask | (1ull << pt));  // the tiles of the pairs / triplets / the head
+        const u32 seqs = w.has_chitoi ? 0u : s_bits;
+        has_tanyao = (solid & ~SIMPLES) == 0 && (seqs & ~SEQ_SIMPLE) == 0;
+        all_yao = (solid & ~YAOKYUU_MASK) == 0;
+        yao_jihai = (solid & HONOURS) != 0;
+        kinds_seen = ((solid & 0x1FFull) ? 1u : 0u) | ((solid & (0x1FFull << 9)) ? 2u : 0u) | ((solid & (0x1FFull << 18)) ? 4u : 0u) |
+                     ((solid & HONOURS) ? 8u : 0u) | ((seqs & 0x1FFu) ? 1u : 0u) | ((seqs & (0x1FFu << 9)) ? 2u : 0u) | ((seqs & (0x1FFu << 18)) ? 4u : 0u);
         if (has_tanyao) han += 1;
-        has_toitoi = !w.has_chitoi && w.n_ms == 0 && in.m.n_chis == 0;
+        const bool has_toitoi = !w.has_chitoi && w.n_ms == 0 && in.m.n_chis == 0;
         if (has_toitoi) han += 2;
         // 字一色 / 混一色 / 清一色 (agari.rs:533-571)
         {
-            u32 suits = kinds_seen & 7;
-            bool has_jihai = (kinds_seen >> 3) & 1;
+            const u32 suits = kinds_seen & 7;
+            const bool has_jihai = (kinds_seen >> 3) & 1;
             if (suits == 0) yakuman += 1;
             else if ((suits & (suits - 1)) == 0) han += (has_jihai ? 2 : 5) + (in.is_menzen ? 1 : 0);
         }
-        DONE_IF_ANY();
-
         if (!w.has_chitoi) {
             // 一盃口 (agari.rs:573-596)
             if (w.has_ipeikou) han += 1;
             else if (in.m.n_ankans > 0 && in.is_menzen && w.n_ms >= 2) {
                 u32 marks = 0;
                 bool dup = false;
-                for (int i = 0; i < w.n_ms; i++) {
-                    u32 b = 1u << w.shuntsu[i];  // tile ids < 27
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (i >= w.n_ms) continue;
+                    const u32 b = 1u << PK8(w.shuntsu, i);
                     dup |= (marks & b) != 0;
                     marks |= b;
                 }
@@ -685,52 +688,43 @@ MJDN Agari div_search_yakus(const DivWork& w, bool any_only) {  // agari.rs:454-
             if (in.is_menzen && w.has_ittsuu) han += 2;
             else if (in.m.n_chis == 0 && w.has_ittsuu) han += 1;
             else if (w.n_shuntsu >= 3) {
-                u32 starts = 0;
-                for (int i = 0; i < w.n_shuntsu; i++) starts |= 1u << w.shuntsu[i];
                 bool itt = false;
-                for (int k = 0; k < 3; k++) itt |= ((starts >> (9 * k)) & 0b1001001u) == 0b1001001u;
+#pragma unroll
+                for (int k = 0; k < 3; k++) itt |= ((s_bits >> (9 * k)) & 0b1001001u) == 0b1001001u;
                 if (itt) han += 1;
             }
             // 三色同順 / 三色同刻 (agari.rs:621-647)
             {
-                u32 s_bits = 0, k_bits = 0;
-                for (int i = 0; i < w.n_shuntsu; i++) s_bits |= 1u << w.shuntsu[i];
-                for (int i = 0; i < w.n_kotsu; i++)
-                    if (w.kotsu[i] < 27) k_bits |= 1u << w.kotsu[i];
-                u32 s3 = s_bits & (s_bits >> 9) & (s_bits >> 18) & 0x1FF;
-                u32 k3 = k_bits & (k_bits >> 9) & (k_bits >> 18) & 0x1FF;
+                const u32 k_bits = (u32)(kmask & 0x7FFFFFFull);
+                const u32 s3 = s_bits & (s_bits >> 9) & (s_bits >> 18) & 0x1FF;
+                const u32 k3 = k_bits & (k_bits >> 9) & (k_bits >> 18) & 0x1FF;
                 if (s3) han += in.is_menzen ? 2 : 1;
                 else if (k3) han += 2;
             }
             // 暗刻 / 槓子 (agari.rs:649-666)
-            int ankous = in.m.n_ankans + w.n_mk - (w.wt_minkou ? 1 : 0);
+            const int ankous = in.m.n_ankans + w.n_mk - (w.wt_minkou ? 1 : 0);
             if (ankous == 4) yakuman += 1;
             else if (ankous == 3) han += 2;
-            int kans = in.m.n_ankans + in.m.n_minkans;
+            const int kans = in.m.n_ankans + in.m.n_minkans;
             if (kans == 4) yakuman += 1;
             else if (kans == 3) han += 2;
             // 緑一色 (agari.rs:668-676)
             {
-                const u64 GREEN = (1ull << 19) | (1ull << 20) | (1ull << 21) | (1ull << 23) | (1ull << 25) | (1ull << T_F);
-                bool g = (GREEN >> pt) & 1;
-                for (int i = 0; i < w.n_kotsu; i++) g &= (GREEN >> w.kotsu[i]) & 1;
-                for (int i = 0; i < w.n_shuntsu; i++) g &= w.shuntsu[i] == 19;
+                constexpr u64 GREEN = (1ull << 19) | (1ull << 20) | (1ull << 21) | (1ull << 23) | (1ull << 25) | (1ull << T_F);
+                const bool g = ((kmask | (1ull << pt)) & ~GREEN) == 0 && (s_bits & ~(1u << 19)) == 0;
                 if (g) yakuman += 1;
             }
-            DONE_IF_ANY();
             if (!has_tanyao) {  // 役牌, 三元, 四喜 (agari.rs:678-721)
-                u32 jz = 0;
-                for (int i = 0; i < w.n_kotsu; i++)
-                    if (w.kotsu[i] >= 27) jz |= 1u << (w.kotsu[i] - 27);
+                const u32 jz = (u32)(kmask >> 27) & 0x7F;
                 if ((jz >> (in.bakaze - 27)) & 1) han += 1;
                 if ((jz >> (in.jikaze - 27)) & 1) han += 1;
-                int saneins = __popc(jz & 0b1110000);
+                const int saneins = __popc(jz & 0b1110000);
                 if (saneins > 0) {
                     han += saneins;
                     if (saneins == 3) yakuman += 1;
                     else if (saneins == 2 && pair_is_dragon) han += 2;
                 }
-                int winds = __popc(jz & 0b0001111);
+                const int winds = __popc(jz & 0b0001111);
                 if (winds == 4) yakuman += 1;
                 else if (winds == 3 && pt >= T_E && pt <= T_N) yakuman += 1;
             }
@@ -740,20 +734,14 @@ MJDN Agari div_search_yakus(const DivWork& w, bool any_only) {  // agari.rs:454-
                 if (yao_jihai) han += 2;
                 else yakuman += 1;
             } else {
-                bool jc = true;
-                for (int i = 0; i < w.n_shuntsu; i++) {
-                    int num = w.shuntsu[i] % 9;
-                    jc &= num == 0 || num == 6;
-                }
-                if (jc) han += (yao_jihai ? 1 : 2) + (in.is_menzen ? 1 : 0);
+                constexpr u32 SEQ_TERMINAL = 0b001000001u | (0b001000001u << 9) | (0b001000001u << 18);  // 123 / 789
+                if ((s_bits & ~SEQ_TERMINAL) == 0) han += (yao_jihai ? 1 : 2) + (in.is_menzen ? 1 : 0);
             }
         }
     }
-done:
-#undef DONE_IF_ANY
     Agari a;
     if (yakuman > 0) { a.kind = 2; a.fu = 0; a.han = yakuman; }
-    else if (han > 0) { a.kind = 1; a.han = han; a.fu = (any_only || han >= 5) ? 0 : div_calc_fu(w, has_pinfu); }
+    else if (han > 0) { a.kind = 1; a.han = han; a.fu = (any_only || han >= 5) ? 0 : div_calc_fu(in, w, has_pinfu); }
     else { a.kind = 0; a.fu = a.han = 0; }
     return a;
 }
@@ -766,16 +754,16 @@ MJDN Agari agari_search(const MjTablesDev& T, const AgariIn& in, bool any_only) 
         best.han = 1;
         return best;
     }
-    u8 t14[14];
-    u32 key = tile14_and_key(in.tehai, t14);
-    int idx = agari_find(T, key);
+    Tile14 t14;
+    const u32 key = tile14_and_key(in.tehai, t14);
+    const int idx = agari_find(T, key);
     if (idx < 0) return best;
     const u32* rec = T.agari_divs + (size_t)idx * 5;
-    int n = (int)rec[0];
+    const int n = (int)rec[0];
+    const u64 hand_nz = in.tehai.nonzero_mask();
     for (int i = 0; i < n; i++) {
-        DivWork w;
-        div_init(w, in, t14, rec[1 + i]);
-        Agari a = div_search_yakus(w, any_only);
+        const DivWork w = div_init(in, t14, rec[1 + i]);
+        const Agari a = div_search_yakus(in, w, hand_nz, any_only);
         if (a.kind == 0) continue;
         if (any_only) return a;
         if (best.kind == 0 || !agari_better(best, a)) best = a;
@@ -790,17 +778,13 @@ MJDN Agari agari_full(const MjTablesDev& T, const AgariIn& in, int additional_ha
     Agari none = {0, 0, 0};
     if (additional_hans == 0) return none;
     if (additional_hans + doras >= 5) { Agari r = {1, 0, additional_hans + doras}; return r; }
-    u8 t14[14];
-    u32 key = tile14_and_key(in.tehai, t14);
-    int idx = agari_find(T, key);
+    Tile14 t14;
+    const u32 key = tile14_and_key(in.tehai, t14);
+    const int idx = agari_find(T, key);
     if (idx < 0) return none;
     const u32* rec = T.agari_divs + (size_t)idx * 5;
     int fu = -1;
-    for (int i = 0; i < (int)rec[0]; i++) {
-        DivWork w;
-        div_init(w, in, t14, rec[1 + i]);
-        fu = max(fu, div_calc_fu(w, false));
-    }
+    for (int i = 0; i < (int)rec[0]; i++) fu = max(fu, div_calc_fu(in, div_init(in, t14, rec[1 + i]), false));
     if (fu < 0) return none;
     Agari r = {1, fu, additional_hans + doras};
     return r;
@@ -823,7 +807,7 @@ MJDN bool check_ankan_after_riichi(const MjTablesDev& T, Hand tehai, int len_div
         Hand after = tehai;
         after.clear(tid);
         after.inc(t);
-        u8 t14[14];
+        Tile14 t14;
         if (agari_find(T, tile14_and_key(after, t14)) < 0) return false;
     }
     return true;

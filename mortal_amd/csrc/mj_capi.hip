@@ -27,11 +27,12 @@ __global__ __launch_bounds__(64) void mj_k_algo_query(const MjAlgoQuery* q, int 
         for (int c = 0; c < (int)Q.tehai[t] && c < 4; c++) h.inc(t);
     AgariIn in;
     in.tehai = h;
+    in.m.chis = in.m.pons = in.m.minkans = in.m.ankans = 0;
     for (int k = 0; k < 4; k++) {
-        in.m.chis[k] = Q.chis[k];
-        in.m.pons[k] = Q.pons[k];
-        in.m.minkans[k] = Q.minkans[k];
-        in.m.ankans[k] = Q.ankans[k];
+        melds_put(in.m.chis, k, Q.chis[k]);
+        melds_put(in.m.pons, k, Q.pons[k]);
+        melds_put(in.m.minkans, k, Q.minkans[k]);
+        melds_put(in.m.ankans, k, Q.ankans[k]);
     }
     in.m.n_chis = Q.n_chis;
     in.m.n_pons = Q.n_pons;

@@ -97,12 +97,13 @@ template <class LN> MJD Melds load_melds(const LN& L, int s) {
     m.n_pons = F2(n_melds, s, 1);
     m.n_minkans = F2(n_melds, s, 2);
     m.n_ankans = F2(n_melds, s, 3);
+    m.chis = m.pons = m.minkans = m.ankans = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        m.chis[i] = F2(chis, s, i);
-        m.pons[i] = F2(pons, s, i);
-        m.minkans[i] = F2(minkans, s, i);
-        m.ankans[i] = F2(ankans, s, i);
+        melds_put(m.chis, i, F2(chis, s, i));
+        melds_put(m.pons, i, F2(pons, s, i));
+        melds_put(m.minkans, i, F2(minkans, s, i));
+        melds_put(m.ankans, i, F2(ankans, s, i));
     }
     return m;
 }
