@@ -805,8 +805,8 @@ int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
         out[7] = e2[1];
         if (getenv("MJ_SP_PROF"))
             fprintf(stderr, "[sp prof] rows %llu setup %llu expand %llu evalL0 %llu evalL>0 %llu encode %llu states %llu (wall_clock64 ticks, 100 MHz) | "
-                    "expand passes: probes %llu lists+V %llu td-probes %llu layout %llu inserts %llu; items %llu expanded %llu edges %llu l0-entries %llu; level-0 probe %llu scoring %llu; workgroup lifetimes: sum %llu max %llu queue pops %llu hash resets %llu\n",
-                    e2[1], e2[2], e2[3], e2[4], e2[5], e2[6], e2[7], e2[8], e2[9], e2[10], e2[11], e2[12], e2[13], e2[14], e2[15], e2[16], e2[17], e2[18], e2[19], e2[20], e2[21], e2[22]);
+                    "expand passes: probes %llu lists+V %llu td-probes %llu layout %llu inserts %llu; items %llu expanded %llu edges %llu l0-entries %llu; level-0 probe %llu scoring %llu; workgroup lifetimes: sum %llu max %llu queue pops %llu hash resets %llu; eval wavefront time %llu\n",
+                    e2[1], e2[2], e2[3], e2[4], e2[5], e2[6], e2[7], e2[8], e2[9], e2[10], e2[11], e2[12], e2[13], e2[14], e2[15], e2[16], e2[17], e2[18], e2[19], e2[20], e2[21], e2[22], e2[23]);
     }
     return 0;
 }

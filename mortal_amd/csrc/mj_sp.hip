@@ -368,6 +368,35 @@ __device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const
     }
 }
 
+template <int J, int N, class F>
+MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_constant<N - 1>): the index is a compile-time constant
+    if constexpr (J < N) {
+        f(std::integral_constant<int, J>{});
+        sp_static_for<J + 1, N>(f);
+    }
+}
+
+// Inclusive prefix sum over the 64 lanes of a wavefront (every lane active).  On the device: six DPP steps inside the VALU
+// (row_shr 1 / 2 / 4 / 8 within the rows of 16, then row_bcast 15 / 31 across them) instead of six LDS-crossbar shuffles.
+MJD u32 sp_wave_scan_incl(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MJ_EMU)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+#else
+    const int lane = (int)(threadIdx.x & 63);
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 q = __shfl_up(v, d);
+        if (lane >= d) v += q;
+    }
+    return v;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense expansion / level-0 probe: SP_NS states of one level at a time PER WAVEFRONT, every phase a THREAD-PER-TASK pass
 // over the 64 lanes, separated by wave-level LDS hand-offs (mj_team_sync<64>): no workgroup barrier inside a level, four
@@ -397,7 +426,7 @@ struct SpChunk {
     u8 cnt[SP_NS][4];       // pairs, kinds, yaokyuu pairs, yaokyuu kinds (shanten.rs:104-137)
     u8 fin[SP_NS];          // normal-form final value (shanten + 1)
     u8 fb[SP_NS];           // brute-force path
-    u8 n_tiles[SP_NS];      // required draws
+    alignas(16) u8 n_tiles[SP_NS];  // required draws (read as one 16-byte word)
     u32 gcs[SP_NS][4];      // per suit group of the hand: tiles held once | twice << 9 | at all << 18 (sp_group_count_sets)
     unsigned short wnz[SP_NS][4];  // per suit group: tiles left in the wall
     u64 cs[SP_NS][3];       // the hand's tiles held once / twice / at all (34-bit sets)
@@ -406,7 +435,7 @@ struct SpChunk {
     u64 kept[SP_ITEM_CAP];                  // shanten-keeping discards after the draw
     unsigned short item[SP_ITEM_CAP];       // state | tile << 4
     unsigned short coff[SP_ITEM_CAP];       // offset of the item's first child inside the state's child list
-    unsigned short eoff[SP_ITEM_CAP + 2];   // prefix sums of the kept discards over the items
+    unsigned short eoff[SP_ITEM_CAP + 2];   // prefix sums of the child entries over the items
 };
 #define SP_NT 64  // co-operating threads of a chunk
 static_assert(SP_NS <= 16, "item entries hold the state in 4 bits");
@@ -561,20 +590,36 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     const long long t_probe = tq1 - tq0;
 
     // The draw items (state, required tile) are processed in sub-batches of whole states with at most SP_ITEM_CAP = 64 items:
-    // one lane per item.  A chunk with more items is split into sub-batches of about equal size.
+    // one lane per item.  A chunk with more items is split into sub-batches of about equal size.  The per-state item counts
+    // are read ONCE (16 bytes) and every prefix below is register arithmetic over static indices, not a chain of LDS reads.
+    static_assert(SP_NS == 16, "n_tiles is read as one 16-byte word");
+    u32 ntw[4];
+    {
+        const SpRec raw = *reinterpret_cast<const SpRec*>(C->n_tiles);  // one 16-byte LDS read
+        ntw[0] = raw.x; ntw[1] = raw.y; ntw[2] = raw.z; ntw[3] = raw.w;
+    }
+    auto nt_of = [&](auto sc) -> int {  // static state index
+        constexpr int q = decltype(sc)::value;
+        return q < SP_NS ? (int)((ntw[q >> 2] >> (8 * (q & 3))) & 0xFFu) : 0;
+    };
     int total_items = 0;
-    for (int s = 0; s < n; s++) total_items += (int)C->n_tiles[s];
+    sp_static_for<0, SP_NS>([&](auto sc) { if (decltype(sc)::value < n) total_items += nt_of(sc); });
     const int n_sub = (total_items + SP_ITEM_CAP - 1) / SP_ITEM_CAP, target = n_sub > 1 ? (total_items + n_sub - 1) / n_sub : SP_ITEM_CAP;
     for (int sb = 0; sb < n;) {
         long long tp0 = prof ? wall_clock64() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
         int se = sb, n_items = 0;  // uniform over the wavefront
-        int my_first = 0;
-        for (int s = sb; s < n; s++) {
-            const int nt = (int)C->n_tiles[s];
-            if (s > sb && (n_items + nt > SP_ITEM_CAP || n_items >= target)) break;
-            if (s == tid) my_first = n_items;
-            n_items += nt;
-            se = s + 1;
+        int my_first = 0;          // first item of state `tid`
+        {
+            bool stopped = false;
+            sp_static_for<0, SP_NS>([&](auto sc) {
+                constexpr int q = decltype(sc)::value;
+                if (q < sb || q >= n || stopped) return;
+                const int nt = nt_of(sc);
+                if (q > sb && (n_items + nt > SP_ITEM_CAP || n_items >= target)) { stopped = true; return; }
+                if (q == tid) my_first = n_items;
+                n_items += nt;
+                se = q + 1;
+            });
         }
         // item list: one lane per state walks its required-draw set (ascending); a state without draws left gets its header now
         if (tid >= sb && tid < se) {
@@ -628,42 +673,34 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             C->kept[tid] = kept;
         }
         if (prof) tp2 = wall_clock64();
-        // P3: child list layout (for each required tile `variants(t) * kept discards` entries) + node header: an inclusive wavefront
-        // scan over the item lanes of (entries, kept discards) and (wall copies, draw entries); a state's items are contiguous lanes
-        int n_edges;
+        // P3: child list layout (for each required tile `variants(t) * kept discards` entries) + node header: one inclusive
+        // wavefront scan over the item lanes of (child entries | wall copies << 16 | draw entries << 24); a state's items are
+        // contiguous lanes, so its totals are a difference of two prefix values
+        int n_entries;
         {
             const int wc = has_item ? S.w.get(my_t) : 0;
             const int nvar = has_item && sp_aka_in_wall(S, my_t) ? (wc >= 2 ? 2 : 1) : 1;
-            const int nkeep = __popcll(kept);
-            u32 pa = (u32)(nvar * nkeep) | ((u32)nkeep << 16), pb = (u32)wc | ((u32)(nkeep ? nvar : 0) << 16);
-            if (!has_item) pa = pb = 0;
-#pragma unroll
-            for (int d = 1; d < SP_NT; d <<= 1) {
-                const u32 qa = __shfl_up(pa, d), qb = __shfl_up(pb, d);
-                if (tid >= d) { pa += qa; pb += qb; }
-            }
-            // this state's lanes: [first, last]; totals = prefix(last) - prefix(first - 1)
-            int s_first = 0, s_last = 0;
-            {
-                // first lane of my state = number of items of the states before it in this sub-batch
-                int acc = 0;
-                for (int s = sb; s < se; s++) {
-                    const int nt = (int)C->n_tiles[s];
-                    if (s == my_s) { s_first = acc; s_last = acc + nt - 1; }
-                    acc += nt;
-                }
-            }
-            const u32 base_a = __shfl(pa, max(s_first - 1, 0)), base_b = __shfl(pb, max(s_first - 1, 0));
-            const u32 tot_a = __shfl(pa, s_last), tot_b = __shfl(pb, s_last);
-            const u32 ba = s_first > 0 ? base_a : 0u, bb = s_first > 0 ? base_b : 0u;
-            n_edges = (int)(__shfl(pa, SP_NT - 1) >> 16);
+            const int nkeep = __popcll(kept), my_ent = nvar * nkeep;
+            const u32 pv = sp_wave_scan_incl(has_item ? ((u32)my_ent | ((u32)wc << 16) | ((u32)(nkeep ? nvar : 0) << 24)) : 0u);
+            int s_first = 0, s_n = 0;  // this lane's state: first item lane, items
+            sp_static_for<0, SP_NS>([&](auto sc) {
+                constexpr int q = decltype(sc)::value;
+                if (q < sb || q >= se) return;
+                const int nt = nt_of(sc);
+                if (q < my_s) s_first += nt;
+                if (q == my_s) s_n = nt;
+            });
+            const int s_last = s_first + s_n - 1;
+            const u32 before = __shfl(pv, max(s_first - 1, 0)), upto = __shfl(pv, max(s_last, 0)), all = __shfl(pv, SP_NT - 1);
+            const u32 base = s_first > 0 ? before : 0u;
+            n_entries = (int)(all & 0xFFFFu);
             if (has_item) {
-                const int my_ent = nvar * nkeep;
-                C->coff[tid] = (unsigned short)(((pa - ba) & 0xFFFFu) - (u32)my_ent);
-                C->eoff[tid] = (unsigned short)((pa >> 16) - (u32)nkeep);
+                C->coff[tid] = (unsigned short)(((pv - base) & 0xFFFFu) - (u32)my_ent);
+                C->eoff[tid] = (unsigned short)((pv & 0xFFFFu) - (u32)my_ent);
                 if (tid == s_last) {  // one lane per state: the pool space and the node header
-                    int total = (int)((tot_a - ba) & 0xFFFFu);
-                    const int sumreq = (int)((tot_b - bb) & 0xFFFFu), n_ent = (int)((tot_b - bb) >> 16);
+                    const u32 tot = upto - base;
+                    int total = (int)(tot & 0xFFFFu);
+                    const int sumreq = (int)((tot >> 16) & 0xFFu), n_ent = (int)(tot >> 24);
                     int child_base = atomicAdd(&X->n_pool, total);
                     if (child_base + total > SP_POOL) { X->overflow = 1; child_base = SP_POOL; total = 0; }
                     C->child_base[my_s] = child_base;
@@ -674,54 +711,51 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
                     node.n_ent = (u8)min(n_ent, 255);
                 }
             }
-            if (tid == 0) C->eoff[n_items] = (unsigned short)n_edges;
+            if (tid == 0) C->eoff[n_items] = (unsigned short)n_entries;
         }
         mj_team_sync<SP_NT>();
         if (prof) tp3 = wall_clock64();
-        // P4: children, one lane per kept (draw, discard) pair: it inserts its child state(s) (one per existing draw variant of
-        // t) into the hash set and leaves its child-list entry at its place of the reference's order (t, variant, d ascending).
-        for (int e0 = 0; e0 < n_edges; e0 += SP_NT) {
+        // P4: children, one lane per CHILD ENTRY (draw variant x kept discard): it inserts its child state into the hash set and
+        // leaves its child-list entry at its place of the reference's order (t, variant, d ascending).
+        for (int e0 = 0; e0 < n_entries; e0 += SP_NT) {
             const int e = e0 + tid;
-            if (e < n_edges) {
+            if (e < n_entries) {
                 int lo = 0, hi = n_items;  // largest item with eoff[item] <= e
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if ((int)C->eoff[mid] <= e) lo = mid; else hi = mid;
                 }
-                const int it = lo, rank = e - (int)C->eoff[it];
+                const int it = lo, local = e - (int)C->eoff[it];
                 const u64 bits = C->kept[it];
+                const int nk = __popcll(bits), vidx = local >= nk ? 1 : 0, rank = local - vidx * nk;
                 u64 mrest = bits;
                 for (int r = rank; r > 0; r--) mrest &= mrest - 1;
                 const int d = __ffsll((long long)mrest) - 1;
                 const int s = C->item[it] & 15, t = C->item[it] >> 4;
                 const SpState Sx = sp_chunk_state(C, s);
-                const int nk = __popcll(bits);
                 const int cnt = Sx.w.get(t);
                 const bool aka = sp_aka_in_wall(Sx, t);
-                for (int variant = 0; variant < 2; variant++) {
-                    int vidx, count;  // index of this variant among the tile's existing draw entries; copies of that entry
-                    if (!aka) { if (variant == 1) continue; vidx = 0; count = cnt; }
-                    else if (variant == 0) { if (cnt < 2) continue; vidx = 0; count = cnt - 1; }
-                    else { vidx = cnt >= 2 ? 1 : 0; count = 1; }
-                    const int tile = (aka && variant == 1) ? akaize(t) : t;
-                    const u32 akas1 = is_aka(tile) ? (Sx.akas | (1u << (tile - T_5MR))) : Sx.akas;  // akas_in_hand after the draw
-                    const int c = Sx.h.get(d);  // d != t: the draw does not change its count
-                    int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
-                    if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
-                    else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
-                    else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
-                    bool fresh;
-                    const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), Sx, tile, dt, fresh);
-                    if (fresh && cs >= 0) {
-                        const int idx = atomicAdd(&X->n_list, 1);
-                        if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
-                        else X->overflow = 1;
-                    }
-                    const int pos = C->child_base[s] + (int)C->coff[it] + vidx * nk + rank;
-                    const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(dt) << 14) | (rank == nk - 1 ? SP_ENT_LAST : 0u) |
-                                    ((u32)count << 24);
-                    if (pos < SP_POOL) Wg->pool[pos] = ent;
+                // the tile's draw entries: plain (all copies but the red one) if any, then the red five
+                const bool red = aka && (vidx == 1 || cnt < 2);
+                const int count = !aka ? cnt : red ? 1 : cnt - 1;
+                const int tile = red ? akaize(t) : t;
+                const u32 akas1 = red ? (Sx.akas | (1u << (tile - T_5MR))) : Sx.akas;  // akas_in_hand after the draw
+                const int c = Sx.h.get(d);  // d != t: the draw does not change its count
+                int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+                if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
+                else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
+                else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
+                bool fresh;
+                const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), Sx, tile, dt, fresh);
+                if (fresh && cs >= 0) {
+                    const int idx = atomicAdd(&X->n_list, 1);
+                    if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
+                    else X->overflow = 1;
                 }
+                const int pos = C->child_base[s] + (int)C->coff[it] + local;
+                const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(dt) << 14) | (rank == nk - 1 ? SP_ENT_LAST : 0u) |
+                                ((u32)count << 24);
+                if (pos < SP_POOL) Wg->pool[pos] = ent;
             }
         }
         mj_team_sync<SP_NT>();
@@ -732,7 +766,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             acc_layout += tp3 - tp2;
             acc_ins += tp4 - tp3;
             n_items_total += n_items;
-            n_edges_total += n_edges;
+            n_edges_total += n_entries;
         }
         sb = se;
     }
@@ -744,13 +778,6 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         atomicAdd(&X->pt[4], (unsigned long long)acc_ins);       // P4 inserts
         atomicAdd(&X->pt[5], (unsigned long long)n_items_total); // draw items
         atomicAdd(&X->pt[6], (unsigned long long)n);             // states expanded
-    }
-}
-template <int J, int N, class F>
-MJD void sp_static_for(F&& f) {  // f(integral_constant<J>) ... f(integral_constant<N - 1>): the index is a compile-time constant
-    if constexpr (J < N) {
-        f(std::integral_constant<int, J>{});
-        sp_static_for<J + 1, N>(f);
     }
 }
 
@@ -1346,6 +1373,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                     const int wl = tid & 63, tpw = 64 / T, tw = wl / T, ln = wl - tw * T;
                     const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
                     float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
+                    const long long t_ev0 = P.prof ? wall_clock64() : 0;
                     if (tw < tpw && b + team < e) {
                         if (T <= 8) {
                             if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln);
@@ -1361,6 +1389,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                             else sp_eval_team<17, 2>(W, &X, lds, b + team, e, n_teams, ln);
                         }
                     }
+                    if (P.prof && (tid & 63) == 0) atomicAdd(&P.err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
                 }
                 __syncthreads();
                 if (lv == 0) t_3 = wall_clock64();
