@@ -224,6 +224,26 @@ def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmu
     return res
 
 
+def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs):
+    """BASELINE configs[2] as a driver-timed workload: the policy/value net is PyTorch's (out of this path's scope), so what the
+    entry shows is the end-to-end rate and how small the environment's share of that cycle is."""
+    import torch
+
+    from mortal_amd.policy import DeviceEngine, PolicyNet
+
+    try:
+        torch.manual_seed(0)
+        engine = DeviceEngine(PolicyNet(version=4), 4, dev, enable_amp=True)
+        r = _measure(pool_cls, N, g0, world, dev, 4, preroll, "brain", 2, 1, bufs, engine)
+    except Exception as e:  # noqa: BLE001 - an extra workload must never cost the headline line
+        return {"error": repr(e)[:300]}
+    out = _brief(r)
+    env_ms = out["kernel_ms_per_step"]["mj_k_encode"] + out["kernel_ms_per_step"]["mj_k_sp"] + 0.6  # + step / snapshot / bookkeeping
+    out["env_share_of_cycle"] = env_ms / out["ms_per_step"]
+    out["net"] = "random-init Brain + DQN, 192 ch x 40 blocks, bf16 autocast, greedy"
+    return out
+
+
 def _brief(r):
     """A workload-matrix entry: the same quantities as the headline, for another workload (all driver-timed)."""
     return {"value": r["steps"] / r["dt"], "unit": "env steps/s", "ms_per_step": r["dt"] / r["n_cycles"] * 1e3,
@@ -235,7 +255,7 @@ def _brief(r):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU")
     ap.add_argument("--version", type=int, default=4, help="obs version (consts.rs:20-28); 4 = reference default incl. SP tables")
@@ -352,7 +372,11 @@ def main():
             "obs_v3_random": _brief(_measure(TablePool, N, g0, world, dev, 3, args.preroll, "random", 10 * k, 10, bufs)),
             "obs_v4_random_no_preroll": _brief(_measure(TablePool, N, g0, world, dev, 4, 0, "random", k, 3, bufs)),
             "obs_v4_greedy": _brief(_measure(TablePool, N, g0, world, dev, 4, args.preroll, "greedy", k, 3, bufs)),
-            "note": "obs_v3_random = env-step + encode only (no SP block); obs_v4_random_no_preroll = every table in the first "
+            "brain_v4": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs),
+            "note": "brain_v4 = BASELINE configs[2]: full self-play cycle with a random-init net of the reference's Brain/DQN shape "
+                    "(192 channels x 40 blocks, bf16 autocast, greedy argmax) consuming the encoded batch in place on the same GPU; "
+                    "2 timed cycles (the net takes seconds per 65 k-row batch); env_share = (step + encode + SP kernels) / cycle; "
+                    "obs_v3_random = env-step + encode only (no SP block); obs_v4_random_no_preroll = every table in the first "
                     "turns of E1 (17 draws left: the heaviest SP phase); obs_v4_greedy = tenpai-seeking policy on device "
                     "(mj_greedy_policy; pre-rolled with the same policy): hands at 0..3 shanten, the largest SP state graphs",
         }

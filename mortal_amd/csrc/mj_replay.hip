@@ -78,19 +78,35 @@ template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uin
                 }
             }
             F1(wall, 60) = (u8)ev.pai;
+            int aug_seed_dora = MJ_NONE;
             if ((w[0] >> LG_SK_DEAL_BIT) & 1) {
                 // trust_seed (invisible.rs:36-71): the game came from this engine, rebuild the whole wall from its seed
                 u8 logged[52];
                 for (int i = 0; i < 52; i++) logged[i] = F1(wall, i);
                 // the pool's shuffle first, then the other one: logs of either rand generation of the reference arena load
+                // GameplayLoader(oracle, trust_seed, augmented) (dataset/gameplay.rs:126-164 + invisible.rs:36-71): the events are
+                // augmented (Tile::augment, tile.rs:154-167: manzu <-> pinzu) but Invisible::new deals the wall from the seed as
+                // it was — the reference mixes the two, and so does this: the logged haipai / dora marker are compared through
+                // the swap and then kept, yama / rinshan / further indicators / ura stay as dealt
+                const bool aug = (w[0] >> LG_SK_AUG_BIT) & 1;
+                auto through = [&](int t) -> int {
+                    if (!aug || t >= 37) return t;
+                    const int d = deaka(t), sw = d < 9 ? d + 9 : d < 18 ? d - 9 : d;
+                    return is_aka(t) ? akaize(sw) : sw;
+                };
                 bool same = false;
                 for (int attempt = 0; attempt < 2 && !same; attempt++) {
                     deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, L.deal, L.l, F(seed_nonce), F(seed_key), F(kyoku), F(honba),
                               attempt == 0 ? deal_algo : 1 - deal_algo);
-                    same = F1(wall, 60) == ev.pai;
-                    for (int i = 0; i < 52; i++) same = same && logged[i] == F1(wall, i);
+                    same = through(F1(wall, 60)) == ev.pai;
+                    for (int i = 0; i < 52; i++) same = same && logged[i] == through(F1(wall, i));
                 }
                 if (!same) set_err(L, MJ_ERR_WALL);  // the seed does not reproduce the logged haipai under either shuffle
+                else if (aug) {
+                    for (int i = 0; i < 52; i++) F1(wall, i) = logged[i];
+                    aug_seed_dora = F1(wall, 60);  // the invisible side keeps the seed's own first indicator
+                    F1(wall, 60) = (u8)ev.pai;
+                }
             } else if ((w[0] >> LG_SK_WALL_BIT) & 1) {
                 for (int k = 0; k < 17; k++) {
                     const uint64_t v = w[10 + k];
@@ -98,6 +114,7 @@ template <class LN> MJDN void rp_apply(const LN& L, const RpEvent& ev, const uin
                 }
             }
             kyoku_init(L);
+            if (aug_seed_dora != MJ_NONE) F1(wall, 60) = (u8)aug_seed_dora;
             F(flags) |= TF_HAIPAI_DONE;
             break;
         }

@@ -433,12 +433,13 @@ struct SpChunk {
     int child_base[SP_NS];
     // the draw items (state, required tile) of the current sub-batch of states: one lane each
     u64 kept[SP_ITEM_CAP];                  // shanten-keeping discards after the draw
-    unsigned short item[SP_ITEM_CAP];       // state | tile << 4
+    unsigned short item[SP_ITEM_CAP];       // state | tile << SP_SB
     unsigned short coff[SP_ITEM_CAP];       // offset of the item's first child inside the state's child list
     unsigned short eoff[SP_ITEM_CAP + 2];   // prefix sums of the child entries over the items
 };
 #define SP_NT 64  // co-operating threads of a chunk
-static_assert(SP_NS <= 16, "item entries hold the state in 4 bits");
+#define SP_SB (SP_NS > 16 ? 5 : 4)  // bits of the state index inside an item
+static_assert(SP_NS == 16 || SP_NS == 32, "n_tiles is read in 16-byte words; item entries hold the state in SP_SB bits");
 static_assert(SP_ITEM_CAP == SP_NT, "one lane per draw item: the layout pass is a wavefront scan");
 
 MJD SpState sp_chunk_state(const SpChunk* C, int s) {
@@ -592,11 +593,11 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     // The draw items (state, required tile) are processed in sub-batches of whole states with at most SP_ITEM_CAP = 64 items:
     // one lane per item.  A chunk with more items is split into sub-batches of about equal size.  The per-state item counts
     // are read ONCE (16 bytes) and every prefix below is register arithmetic over static indices, not a chain of LDS reads.
-    static_assert(SP_NS == 16, "n_tiles is read as one 16-byte word");
-    u32 ntw[4];
-    {
-        const SpRec raw = *reinterpret_cast<const SpRec*>(C->n_tiles);  // one 16-byte LDS read
-        ntw[0] = raw.x; ntw[1] = raw.y; ntw[2] = raw.z; ntw[3] = raw.w;
+    u32 ntw[SP_NS / 4];
+#pragma unroll
+    for (int w = 0; w < SP_NS / 16; w++) {
+        const SpRec raw = reinterpret_cast<const SpRec*>(C->n_tiles)[w];  // 16-byte LDS reads
+        ntw[4 * w] = raw.x; ntw[4 * w + 1] = raw.y; ntw[4 * w + 2] = raw.z; ntw[4 * w + 3] = raw.w;
     }
     auto nt_of = [&](auto sc) -> int {  // static state index
         constexpr int q = decltype(sc)::value;
@@ -625,7 +626,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         if (tid >= sb && tid < se) {
             const int s = tid;
             int it = my_first;
-            for (u64 rest = C->req[s]; rest; rest &= rest - 1) C->item[it++] = (unsigned short)(s | ((__ffsll((long long)rest) - 1) << 4));
+            for (u64 rest = C->req[s]; rest; rest &= rest - 1) C->item[it++] = (unsigned short)(s | ((__ffsll((long long)rest) - 1) << SP_SB));
             if (it == my_first) {
                 SP_HBM SpNode& node = Wg->node[C->slot[s]];
                 node.child_off = 0;
@@ -638,7 +639,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         if (prof) tp1 = wall_clock64();
         // P2: the shanten-keeping discards of g = h + t, lane = item
         const bool has_item = tid < n_items;
-        const int my_e = has_item ? (int)C->item[tid] : 0, my_s = my_e & 15, my_t = my_e >> 4;
+        const int my_e = has_item ? (int)C->item[tid] : 0, my_s = my_e & (SP_NS - 1), my_t = my_e >> SP_SB;
         const SpState S = sp_chunk_state(C, my_s);
         u64 kept = 0;
         if (has_item) {
@@ -731,7 +732,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
                 u64 mrest = bits;
                 for (int r = rank; r > 0; r--) mrest &= mrest - 1;
                 const int d = __ffsll((long long)mrest) - 1;
-                const int s = C->item[it] & 15, t = C->item[it] >> 4;
+                const int s = C->item[it] & (SP_NS - 1), t = C->item[it] >> SP_SB;
                 const SpState Sx = sp_chunk_state(C, s);
                 const int cnt = Sx.w.get(t);
                 const bool aka = sp_aka_in_wall(Sx, t);

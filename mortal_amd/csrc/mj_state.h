@@ -197,6 +197,7 @@ enum MjLogType : uint32_t {
 #define LG_HONBA_SHIFT 44  /* start_kyoku: honba (8 bits); kyoku (0..11) travels in the c0 field, dora marker in pai */
 #define LG_KYOTAKU_SHIFT 52
 /* start_kyoku words of a REPLAY script only (dataset loader with oracle=True, dataset/invisible.rs): */
+#define LG_SK_AUG_BIT 61   /* with LG_SK_DEAL_BIT: the script's tiles are suit-augmented (manzu <-> pinzu), the seed's wall is not */
 #define LG_SK_DEAL_BIT 62  /* rebuild the whole wall from the table's seed (trust_seed) */
 #define LG_SK_WALL_BIT 63  /* 17 more payload words follow: the full 136-tile wall, 8 tiles per word */
 

@@ -185,9 +185,8 @@ class GameplayLoader:
         # trust_seed: wall shuffle tried first when rebuilding a kyoku from its seed (None = pool.default_deal_algo());
         # the replay kernel falls back to the other rand generation before reporting MJ_ERR_WALL
         self.deal_algo = deal_algo
-        if self.oracle and self.trust_seed and self.augmented:
-            raise NotImplementedError("oracle=True with trust_seed=True and augmented=True: the seed rebuilds the "
-                                      "un-augmented wall (the reference mixes the two as well); drop one of the flags")
+        # oracle + trust_seed + augmented: the reference augments the events but deals the invisible wall from the seed as it
+        # was (gameplay.rs:126-164, invisible.rs:36-71); the replay kernel does the same (LG_SK_AUG_BIT)
 
     def __repr__(self):
         return (f"GameplayLoader {{ version: {self.version}, oracle: {self.oracle}, player_names: {self.player_names}, "

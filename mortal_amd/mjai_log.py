@@ -156,7 +156,7 @@ def encode_events(events, augmented=False, walls=None, deal_from_seed=False):
             for k in range(7):
                 out.append(sum((tiles[k * 8 + b] if k * 8 + b < 52 else 0) << (8 * b) for b in range(8)))
             if deal_from_seed:
-                out[-10] |= 1 << 62
+                out[-10] |= (1 << 62) | ((1 << 61) if augmented else 0)  # LG_SK_DEAL_BIT, LG_SK_AUG_BIT
             elif walls is not None:
                 wall = [int(x) for x in walls[n_kyoku]]
                 if len(wall) != 136 or wall[:52] != tiles:

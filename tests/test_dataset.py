@@ -105,18 +105,30 @@ def test_gameplay_loader_invisible_obs(oracle, version):
     assert check_invisible(oracle, version, 5) > 500
 
 
-def check_invisible(oracle, version, n_logs):
+@pytest.mark.gpu
+def test_gameplay_loader_oracle_trust_seed_augmented(oracle):
+    """The one flag combination round 2 refused: accepted by the reference (dataset/gameplay.rs:126-164)."""
+    assert check_invisible(oracle, 4, 3, augmented=True) > 300
+
+
+def check_invisible(oracle, version, n_logs, augmented=False):
+    """augmented=True: GameplayLoader(oracle, trust_seed, augmented), which the reference accepts (gameplay.rs:126-164): the
+    events are suit-swapped, the invisible wall is dealt from the seed as it was (invisible.rs:36-71)."""
     import dataset_ref
     from libriichi.dataset import GameplayLoader
+    from mortal_amd import mjai_log
 
     logs = _oracle_logs(oracle, n_logs, "greedy", 31337)
     names = ["a", "c"]
-    trusted = GameplayLoader(version, oracle=True, trust_seed=True, player_names=names).load_logs(logs)
-    blind = GameplayLoader(version, oracle=True, trust_seed=False, player_names=names).load_logs(logs)
+    trusted = GameplayLoader(version, oracle=True, trust_seed=True, player_names=names, augmented=augmented).load_logs(logs)
+    blind = GameplayLoader(version, oracle=True, trust_seed=False, player_names=names, augmented=augmented).load_logs(logs)
     opp_rows = 45 if version == 1 else 51
     n = 0
     for raw, gt, gb in zip(logs, trusted, blind):
         events = [json.loads(l) for l in raw.splitlines()]
+        if augmented:
+            head = events[0]
+            events = [head] + mjai_log.decode_events(mjai_log.encode_events(events, augmented=True)) + [{"type": "end_game"}]
         for a, b in zip(gt, gb):
             ref = dataset_ref.load_invisible_by_player(oracle, events, a.player_id, version)
             inv_a, inv_b = a.take_invisible_obs(), b.take_invisible_obs()

@@ -125,6 +125,7 @@ def test_emu_dataset_loader(oracle, emu):
         n_samples, _ = TD.check_loader(oracle, 2, True, True, 1, 0)
         assert n_samples > 80
         assert TD.check_invisible(oracle, 4, 1) > 60
+        assert TD.check_invisible(oracle, 3, 1, augmented=True) > 60  # oracle + trust_seed + augmented (gameplay.rs:126-164)
     finally:
         GameplayLoader.pool_cls = old
 
