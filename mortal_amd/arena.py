@@ -118,6 +118,8 @@ class BatchRunner:
                 self.player_index[a][(g, seat)] = len(player_ids[a])
                 player_ids[a].append(seat)
         self._kyoku_ends = {}  # game -> end_kyoku events already reported to the mjai-log engines
+        self._log_cache = {}   # game -> (words decoded, events): the mjai-log agents' view of the device event log
+        self._lens, self._lens_cycle = None, -1
         for a, eng in enumerate(engines):
             if self.cfg[a]["mjai_log"]:
                 if callable(getattr(eng, "set_player_ids", None)):
@@ -177,16 +179,29 @@ class BatchRunner:
             lines.append(f"  (state dump unavailable: {ex})")
         return MortalAmdError("\n".join(lines))
 
+    def _log_lengths(self):
+        """Event-log lengths of every table: read ONCE per cycle (the mjai-log agents of a cycle share it)."""
+        if self._lens_cycle != self.cycles:
+            lens = np.zeros(self.pool.n_tables, dtype=np.uint32)
+            check(self.pool._L.mj_log_lengths(self.pool.h, lens.ctypes.data, self.pool._stream()))
+            self._lens, self._lens_cycle = lens, self.cycles
+        return self._lens
+
     def _game_log(self, g):
+        """The decoded event log of game g, kept across cycles: only the words appended since the last look are decoded (a log
+        always ends on an event boundary), instead of the whole hanchan every cycle."""
         from . import mjai_log
 
-        lens = np.zeros(self.pool.n_tables, dtype=np.uint32)
-        buf = np.empty((1, self.pool.log_cap), dtype=np.uint64)
-        check(self.pool._L.mj_log_lengths(self.pool.h, lens.ctypes.data, self.pool._stream()))
-        check(self.pool._L.mj_log_read(self.pool.h, int(g), 1, buf.ctypes.data, self.pool._stream()))
-        if lens[g] > self.pool.log_cap:
+        n = int(self._log_lengths()[g])
+        if n > self.pool.log_cap:
             raise MortalAmdError(f"event log overflow on table {g}")
-        return mjai_log.decode_events(buf[0, :lens[g]])
+        done, events = self._log_cache.get(g, (0, []))
+        if n > done:
+            buf = np.empty((1, self.pool.log_cap), dtype=np.uint64)
+            check(self.pool._L.mj_log_read(self.pool.h, int(g), 1, buf.ctypes.data, self.pool._stream()))
+            events = events + mjai_log.decode_events(buf[0, done:n])
+            self._log_cache[g] = (n, events)
+        return events
 
     def _report_kyoku_ends(self, g, events):
         """end_kyoku(player index) for every kyoku of game g that has ended since the last look (game.rs:113-118)."""

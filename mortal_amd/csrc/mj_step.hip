@@ -65,9 +65,31 @@ template <class LN> MJD u64 discard_candidates_aka(const LN& L, int s) {  // 37-
 }
 
 // ---------------------------------------------------------------- action id -> reaction (mortal.rs:338-573)
-// An explicit reaction of seat s (mjai-log engines): the LG_* header word of the event.  The host has already run
-// PlayerState::validate_reaction on it (state/action.rs:91-228, as BoardState::step does, board.rs:524-533); here only the
-// actor and the reaction type are checked against the seat's candidates.
+// The consumed tiles (raw ids, red fives as 34..36) are all in the seat's hand, copies and red flags counted.
+template <class LN> MJD bool hand_holds(const LN& L, int s, int a, int b, int c /* MJ_NONE = absent */) {
+    const Hand h = load_hand(L, s);
+    const int akas = F1(akas_in_hand, s);
+    const int tiles[3] = {a, b, c};
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int x = tiles[i];
+        if (x == MJ_NONE) continue;
+        if (x >= 37) { ok = false; continue; }
+        const int d = deaka(x);
+        int need = 0, need_red = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (tiles[j] != MJ_NONE && tiles[j] < 37 && deaka(tiles[j]) == d) { need++; need_red += is_aka(tiles[j]); }
+        const int have = h.get(d), have_red = (d == T_5M || d == T_5P || d == T_5S) ? ((akas >> (d == T_5M ? 0 : d == T_5P ? 1 : 2)) & 1) : 0;
+        ok = ok && need_red <= have_red && need - need_red <= have - have_red;
+    }
+    return ok;
+}
+// An explicit reaction of seat s (mjai-log engines): the LG_* header word of the event.  The Python host runs
+// PlayerState::validate_reaction on it first (state/action.rs:91-228, as BoardState::step does, board.rs:524-533), but a C-ABI
+// caller may not: the word is checked here against the seat's candidates AND its tiles (legal discard set, consumed tiles
+// held with their red flags, the called tile, the shape of a chi / pon / kan) before anything touches the packed hand.
 template <class LN> MJDN Reaction reaction_from_word(const LN& L, int s, uint64_t w) {
     Reaction r = {RX_NONE, (u8)s, 0, MJ_NONE, MJ_NONE, MJ_NONE, MJ_NONE, 0, 0ull};
     const int t = (int)(w & 15);
@@ -77,14 +99,41 @@ template <class LN> MJDN Reaction reaction_from_word(const LN& L, int s, uint64_
     const int c0 = (int)((w >> 14) & 63), c1 = (int)((w >> 20) & 63), c2 = (int)((w >> 26) & 63);
     r.target = (u8)((w >> 6) & 3);
     bool ok = actor == s || t == LG_RYUKYOKU;
+    const int lkt = F1(last_kawa_tile, s);
+    const bool called = pai < 37 && lkt != MJ_NONE && pai == lkt;  // the call names the tile just discarded
     switch (t) {
-        case LG_DAHAI: r.type = RX_DAHAI; r.pai = (u8)pai; r.tsumogiri = (u8)((w >> 38) & 1); ok = ok && (cans & CAN_DISCARD); break;
+        case LG_DAHAI:
+            r.type = RX_DAHAI; r.pai = (u8)pai; r.tsumogiri = (u8)((w >> 38) & 1);
+            ok = ok && (cans & CAN_DISCARD) && pai < 37 && ((discard_candidates_aka(L, s) >> pai) & 1);
+            break;
         case LG_REACH: r.type = RX_REACH; ok = ok && (cans & CAN_RIICHI); break;
-        case LG_CHI: r.type = RX_CHI; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; ok = ok && (cans & (CAN_CHI_LOW | CAN_CHI_MID | CAN_CHI_HIGH)); break;
-        case LG_PON: r.type = RX_PON; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; ok = ok && (cans & CAN_PON); break;
-        case LG_DAIMINKAN: r.type = RX_DAIMINKAN; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; r.c2 = (u8)c2; ok = ok && (cans & CAN_DAIMINKAN); break;
-        case LG_KAKAN: r.type = RX_KAKAN; r.pai = (u8)pai; ok = ok && (cans & CAN_KAKAN); break;
-        case LG_ANKAN: r.type = RX_ANKAN; r.pai = (u8)deaka(c0); ok = ok && (cans & CAN_ANKAN); break;
+        case LG_CHI: {
+            r.type = RX_CHI; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1;
+            ok = ok && (cans & (CAN_CHI_LOW | CAN_CHI_MID | CAN_CHI_HIGH)) && called && c0 < 37 && c1 < 37 && hand_holds(L, s, c0, c1, MJ_NONE);
+            if (ok) {  // three consecutive tiles of one number suit
+                const int x = deaka(pai), y = deaka(c0), z = deaka(c1);
+                const int lo = min(x, min(y, z)), hi = max(x, max(y, z)), mid = x + y + z - lo - hi;
+                ok = hi < 27 && lo / 9 == hi / 9 && mid == lo + 1 && hi == lo + 2;
+            }
+            break;
+        }
+        case LG_PON:
+            r.type = RX_PON; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1;
+            ok = ok && (cans & CAN_PON) && called && c0 < 37 && c1 < 37 && deaka(c0) == deaka(pai) && deaka(c1) == deaka(pai) && hand_holds(L, s, c0, c1, MJ_NONE);
+            break;
+        case LG_DAIMINKAN:
+            r.type = RX_DAIMINKAN; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; r.c2 = (u8)c2;
+            ok = ok && (cans & CAN_DAIMINKAN) && called && c0 < 37 && c1 < 37 && c2 < 37 && deaka(c0) == deaka(pai) && deaka(c1) == deaka(pai) &&
+                 deaka(c2) == deaka(pai) && hand_holds(L, s, c0, c1, c2);
+            break;
+        case LG_KAKAN:
+            r.type = RX_KAKAN; r.pai = (u8)pai;
+            ok = ok && (cans & CAN_KAKAN) && pai < 37 && ((F1(kakan_cand, s) >> deaka(pai)) & 1) && hand_holds(L, s, pai, MJ_NONE, MJ_NONE);
+            break;
+        case LG_ANKAN:
+            r.type = RX_ANKAN; r.pai = (u8)deaka(c0);
+            ok = ok && (cans & CAN_ANKAN) && c0 < 37 && ((F1(ankan_cand, s) >> deaka(c0)) & 1) && load_hand(L, s).get(deaka(c0)) == 4;
+            break;
         case LG_HORA: r.type = RX_HORA; ok = ok && (r.target == s ? (cans & CAN_TSUMO_AGARI) : (cans & CAN_RON_AGARI)); break;
         case LG_RYUKYOKU: r.type = RX_RYUKYOKU; ok = ok && (cans & CAN_RYUKYOKU); break;
         default: ok = false; break;

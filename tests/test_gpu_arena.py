@@ -75,12 +75,38 @@ def test_one_vs_three_py_vs_py_matches_oracle(oracle, device_path):
     assert got == want
 
 
-def test_two_vs_two_runs(oracle):
+def test_two_vs_two_matches_oracle_loop(oracle):
+    """TwoVsTwo.py_vs_py returns None like the reference (two_vs_two.rs:17-110); the hanchan it played are compared with the
+    oracle's BatchGame loop under the reference's plan (two_vs_two.rs:138-190): two games per seed, split A = challenger at seats
+    0 and 2, split B = seats 1 and 3, the same two networks deciding."""
+    import torch
+
     from libriichi.arena import TwoVsTwo
+    from mortal_amd.pool import default_deal_algo
 
     a, _ = _engine(3, 3, "a", True)
     b, _ = _engine(3, 4, "b", True)
-    assert TwoVsTwo(disable_progress_bar=True).py_vs_py(a, b, (20000, KEY), 2) is None
+    env = TwoVsTwo(disable_progress_bar=True)
+    seed_start, seed_count = (20000, KEY), 3
+    assert env.py_vs_py(a, b, seed_start, seed_count) is None
+    n = seed_count * 2
+    seeds = [(seed_start[0] + g // 2, seed_start[1]) for g in range(n)]
+    arena = oracle.Arena(seeds, deal_algo=default_deal_algo(), enable_quick_eval=True, version=3, keep_log=False)
+    while arena.n_live > 0:
+        rows = arena.poll()
+        k = len(rows)
+        obs, masks = arena.encode(0, k, want_obs=True)
+        act = np.full(k, 45, dtype=np.int32)
+        if k:
+            is_chal = (rows[:, 1] % 2) == (rows[:, 0] % 2)  # split A (even game): seats 0, 2; split B: seats 1, 3
+            for eng, sel in ((a, is_chal), (b, ~is_chal)):
+                if sel.any():
+                    o = torch.from_numpy(obs[sel]).cuda()
+                    m = torch.from_numpy(masks[sel].astype(bool)).cuda()
+                    act[sel] = eng.react_batch_device(o, m).cpu().numpy()
+        arena.commit(act)
+    want = np.array([arena.result(g)[0] for g in range(n)])
+    assert np.array_equal(np.asarray(env.last_scores), want), (env.last_scores, want)
 
 
 def test_is_oracle_and_guard_engine_contract(oracle):
