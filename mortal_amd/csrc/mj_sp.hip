@@ -989,24 +989,45 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
 __device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] */, int b, int e) {
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int tid = threadIdx.x;
+    if (e - b <= 8) {  // a handful of states (the root level): one round of teams whatever the order
+        if (b + tid < e) Wg->elist[b + tid] = Wg->list[b + tid];
+        __syncthreads();
+        return;
+    }
     if (tid < 64) hist[tid] = 0;
     __syncthreads();
     auto cost_key = [&](u32 slot) {  // ~ fold work (children) + accumulate work (draw entries), longest first
         const SP_HBM SpNode& nd = Wg->node[slot];
         return 63 - min(((int)nd.n_ch + 4 * (int)nd.n_ent) >> 1, 63);
     };
-    for (int i = b + tid; i < e; i += SP_THREADS) atomicAdd(&hist[cost_key(Wg->list[i])], 1);
+    // a thread's first four states keep their slot and key in registers between the two passes (levels up to 4 x 256 states:
+    // one dependent load chain instead of two)
+    u32 my_slot[4];
+    int my_key[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = b + tid + q * SP_THREADS;
+        my_slot[q] = i < e ? Wg->list[i] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = b + tid + q * SP_THREADS;
+        my_key[q] = i < e ? cost_key(my_slot[q]) : 0;
+        if (i < e) atomicAdd(&hist[my_key[q]], 1);
+    }
+    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) atomicAdd(&hist[cost_key(Wg->list[i])], 1);
     __syncthreads();
-    if (tid == 0) {
-        int off = 0;
-        for (int k = 0; k < 64; k++) {
-            const int c = hist[k];
-            hist[k] = off;
-            off += c;
-        }
+    if (tid < 64) {  // exclusive prefix over the 64 buckets: one wavefront scan
+        const int c = hist[tid];
+        hist[tid] = (int)sp_wave_scan_incl((u32)c) - c;
     }
     __syncthreads();
-    for (int i = b + tid; i < e; i += SP_THREADS) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = b + tid + q * SP_THREADS;
+        if (i < e) Wg->elist[b + atomicAdd(&hist[my_key[q]], 1)] = my_slot[q];
+    }
+    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) {
         const u32 slot = Wg->list[i];
         Wg->elist[b + atomicAdd(&hist[cost_key(slot)], 1)] = slot;
     }
@@ -1090,43 +1111,41 @@ __global__ __launch_bounds__(256) void mj_k_order_scatter(const uint8_t* cls, in
     if (i < n) order[base[c] + r] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
-    __shared__ SpCtx X;
-    __shared__ int s_row;
-    __shared__ union SpTeams {
-        TableOne st;                                 // the decision's table record: read during the row set-up only
-        SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
-        float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
-    } s_tm;
-    SpWork* W = P.work + blockIdx.x;
-    const int tid = threadIdx.x;
+template <class P> struct SpF4Of { typedef const SpRec* type; };                    // 16-byte view of a table record pointer,
+template <> struct SpF4Of<const SP_HBM TableOne*> { typedef const SP_HBM SpRec* type; };  // in the pointer's own address space
+struct SpRowInfo {  // what the row set-up hands to the graph phases and to the encoder
+    bool ok, can_discard0, can_discard, after_riichi, with_probs;
+    int last_tsumo, cur_shanten, T, n_cand, ld3;
+    u32 cans;
+    SpState root;
+};
+template <bool WAVE> MJD void sp_sync() {  // the threads that process ONE row: a workgroup, or (rows without a state graph) a wavefront
+    if constexpr (WAVE) mj_team_sync<64>();
+    else __syncthreads();
+}
+// Row set-up: the table record, the preconditions of single_player_tables, the calculator's constants and the candidates with
+// their required tiles.  NT threads (tid = 0 .. NT - 1) work on the row: the whole workgroup, or one wavefront in the tail of the
+// queue where the rows have no state graph (sp_row_class == 7) and four of them are processed side by side.
+template <bool WAVE, int NT, class RowsP, class SnapP, class OutP>
+__device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork* W, SpCtx& X, TableOne* st, const int tid, const int row, OutP out,
+                                                  unsigned long long* prof) {  // (never a reference to the kernel's parameter block: hipcc would copy it to scratch)
     constexpr int O_SP = 889;  // Lay<4>::sp
-
-    // the hash tags start empty: zeroed once when the work area is allocated, and every row clears the tags it set
-
-    const long long t_wg0 = P.prof ? wall_clock64() : 0;  // MJ_SP_PROF: workgroup lifetime / queue + reset time (err[19..22])
-    long long t_pop = 0, t_reset = 0;
-    for (;;) {
-        const long long t_a = P.prof ? wall_clock64() : 0;
-        if (tid == 0) s_row = atomicAdd(P.queue, 1);
-        __syncthreads();
-        if (s_row >= P.n_rows) break;
-        const int row = (int)P.order[s_row];
-        if (P.prof) t_pop += wall_clock64() - t_a;
-        const uint32_t desc = P.rows[row];
-        const int table = ROW_TABLE(desc), p = ROW_SEAT(desc);
-        long long t_0 = wall_clock64(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0;
+    SpRowInfo R;
+    R.ok = false;
+    R.with_probs = false;
+    R.n_cand = 0;
+    const uint32_t desc = rows[row];
+    const int table = ROW_TABLE(desc), p = ROW_SEAT(desc);
         {
-            const float4* src = reinterpret_cast<const float4*>(P.snap + table);
-            float4* d4 = reinterpret_cast<float4*>(&s_tm.st);
-            for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += SP_THREADS) d4[i] = src[i];
+            const auto src = reinterpret_cast<typename SpF4Of<SnapP>::type>(snap + table);
+            SpRec* d4 = reinterpret_cast<SpRec*>(st);
+            for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += NT) d4[i] = spt_load(&src[i]);
         }
-        __syncthreads();
+        sp_sync<WAVE>();
         LaneT<TableOne> L;
-        L.B = &s_tm.st;
+        L.B = st;
         L.l = 0;
         L.T = &c_mj_tables;
-        float* out = P.obs + (size_t)row * (1012 * 34);
         const u32 cans = F1(cans, p);
         const bool can_discard0 = (cans & CAN_DISCARD) != 0;
         const Hand h0 = load_hand(L, p);
@@ -1153,7 +1172,8 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             calc_haitei = at_next % 4 == 0;
         }
         const bool ok = tiles_left >= 4 && cur_shanten >= 0 && tsumos_left >= 1;
-        __syncthreads();
+        R.ok = ok;
+        sp_sync<WAVE>();
         if (!ok) {
             // Err path (obs_repr.rs:612-623): max EV = minimal tsumo agari points, everything else zero
             if (tid == 0) {
@@ -1167,14 +1187,14 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                 }
                 X.cand_ev0[0] = v;
             }
-            __syncthreads();
+            sp_sync<WAVE>();
             const float v = X.cand_ev0[0];
             if (tid < 34) {
                 out[(O_SP + 0) * 34 + tid] = fminf(fmaxf(v, 0.f), 100000.f) / 100000.f;
                 out[(O_SP + 1) * 34 + tid] = fminf(fmaxf(v, 0.f), 30000.f) / 30000.f;
             }
-            __syncthreads();
-            continue;
+            sp_sync<WAVE>();
+            return R;
         }
 
         // ---- calculator set-up (agent_helper.rs:532-586, calc.rs:84-167)
@@ -1234,32 +1254,37 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             X.n_list = 0;
             X.n_pool = 0;
             X.overflow = 0;
-            X.prof = P.prof;
+            X.prof = prof;
             for (int k = 0; k < 8; k++) X.pt[k] = 0;
             X.n_cand = 0;
             for (int l = 0; l < 5; l++) X.lvl_begin[l] = X.lvl_end[l] = 0;
         }
-        __syncthreads();
+        sp_sync<WAVE>();
         const int T = X.T, n_left = X.n_left;
-        // build_tsumo_prob_table / build_not_tsumo_prob_table (calc.rs:135-167)
-        for (int q = tid; q < 4 * SP_T; q += SP_THREADS) {
-            int i = q / SP_T, j = q % SP_T;
-            X.tsumo_prob[i][j] = j < T ? (float)(i + 1) / (float)(n_left - j) : 0.f;
-        }
-        // the not_tsumo rows live in the wavefront's HBM work area (read once per evaluated state); only rows up to the wall size
-        // can be addressed by a required-tile sum
-        for (int q = tid; q < 124; q += SP_THREADS) {
-            SP_HBM float* r = ((SP_HBM SpWork*)W)->not_tsumo[q];
-            const bool row_on = q <= 122 && q < n_left + 1;
-            const int lim = min(T - 1, n_left - q);
-            float cur = row_on ? 1.f : 0.f;
-            r[0] = cur;
-            for (int j = 0; j < SP_T - 1; j++) {
-                cur = (row_on && j < lim) ? cur * (float)(n_left - q - j) / (float)(n_left - j) : 0.f;
-                r[j + 1] = cur;
+        // fewer draws left than the shanten number: tenpai / win / EV are exactly zero for every candidate (reaching tenpai
+        // takes cur_shanten draws), so neither the probability tables nor the state graph are needed at all
+        const bool with_probs = cur_shanten <= 3 && T >= cur_shanten;
+        if (with_probs) {
+            // build_tsumo_prob_table / build_not_tsumo_prob_table (calc.rs:135-167)
+            for (int q = tid; q < 4 * SP_T; q += NT) {
+                int i = q / SP_T, j = q % SP_T;
+                X.tsumo_prob[i][j] = j < T ? (float)(i + 1) / (float)(n_left - j) : 0.f;
             }
+            // the not_tsumo rows live in the wavefront's HBM work area (read once per evaluated state); only rows up to the wall size
+            // can be addressed by a required-tile sum
+            for (int q = tid; q < 124; q += NT) {
+                SP_HBM float* r = ((SP_HBM SpWork*)W)->not_tsumo[q];
+                const bool row_on = q <= 122 && q < n_left + 1;
+                const int lim = min(T - 1, n_left - q);
+                float cur = row_on ? 1.f : 0.f;
+                r[0] = cur;
+                for (int j = 0; j < SP_T - 1; j++) {
+                    cur = (row_on && j < lim) ? cur * (float)(n_left - q - j) / (float)(n_left - j) : 0.f;
+                    r[j + 1] = cur;
+                }
+            }
+            sp_sync<WAVE>();
         }
-        __syncthreads();
 
         // ---- candidates: analyze_discard / analyze_draw (+ *_simple for shanten > 3)  (calc.rs:205-312), from the table-id
         // sets of mj_sptab.h: the discards of the root hand that keep its shanten number, then one lane per candidate for the
@@ -1289,7 +1314,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             }
             X.n_cand = n;
         }
-        __syncthreads();
+        sp_sync<WAVE>();
         const int n_cand = X.n_cand;
         // required tiles of every candidate (state.rs:176-200): draws t that lower the shanten number of root - d (+ t)
         if (tid < n_cand) {
@@ -1309,11 +1334,212 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             X.cand_slot[tid] = -1;
             X.cand_tp0[tid] = X.cand_wp0[tid] = X.cand_ev0[tid] = 0.f;
         }
-        __syncthreads();
+        sp_sync<WAVE>();
+        R.cans = cans;
+        R.can_discard0 = can_discard0;
+        R.can_discard = can_discard;
+        R.after_riichi = after_riichi;
+        R.last_tsumo = last_tsumo;
+        R.cur_shanten = cur_shanten;
+        R.T = T;
+        R.n_cand = n_cand;
+        R.ld3 = ld3;
+        R.root = root;
+        R.with_probs = with_probs;
+        return R;
+}
 
+// Sorting of the candidates + the encoder block of obs v4 (rows 889..1011).
+template <bool WAVE, int NT, class OutP>
+__device__ __forceinline__ void sp_row_write(SpWork* W, SpCtx& X, const SpRowInfo& R, const int tid, OutP out, float* tv_area) {
+    constexpr int O_SP = 889;  // Lay<4>::sp
+    const int n_cand = R.n_cand, cur_shanten = R.cur_shanten, T = R.T, last_tsumo = R.last_tsumo;
+    const bool with_probs = WAVE ? false : R.with_probs;  // a row processed by one wavefront never has a state graph
+    const bool can_discard0 = R.can_discard0, after_riichi = R.after_riichi;
+        // ---- sort (calc.rs:181-188 / 196-199) + encode (obs_repr.rs:564-692)
+        if (tid < n_cand) {  // one lane per candidate fetches its turn-0 values (side by side, not a chain of dependent loads)
+            const int c = tid;
+            X.order[c] = c;
+            const int slot = X.cand_slot[c];
+            if (with_probs && slot >= 0) {  // Candidate::from clamps (candidate.rs:46-70); shanten 0 => tenpai = 1
+                const SpNode& nd = W->node[slot];
+                const float tp = cur_shanten == 0 ? 1.f : nd.val[0][0];
+                X.cand_tp0[c] = fminf(fmaxf(tp, 0.f), 1.f);
+                X.cand_wp0[c] = fminf(fmaxf(nd.val[0][1], 0.f), 1.f);
+                X.cand_ev0[c] = fmaxf(nd.val[0][2], 0.f);
+            }
+        }
+        sp_sync<WAVE>();
+        if (tid == 0) {
+            auto cmp = [&](int l, int r, int by) -> int {  // candidate.rs:73-106, by: 0 EV, 3 NotShantenDown
+                if (X.cand_tile[l] == X.cand_tile[r]) return 0;
+                int o;
+                if (by <= 0 && (o = f32_total_cmp(X.cand_ev0[l], X.cand_ev0[r])) != 0) return o;
+                if (by <= 1 && (o = f32_total_cmp(X.cand_wp0[l], X.cand_wp0[r])) != 0) return o;
+                if (by <= 2 && (o = f32_total_cmp(X.cand_tp0[l], X.cand_tp0[r])) != 0) return o;
+                if (!X.cand_down[l] && X.cand_down[r]) return 1;
+                if (X.cand_down[l] && !X.cand_down[r]) return -1;
+                if (X.cand_nreq[l] != X.cand_nreq[r]) return X.cand_nreq[l] < X.cand_nreq[r] ? -1 : 1;
+                return cmp_discard_priority(X.cand_tile[l], X.cand_tile[r]);
+            };
+            const int by = with_probs ? 0 : 3;
+            for (int i = 1; i < n_cand; i++) {  // stable insertion sort, descending: before(l, r) = cmp(r, l) < 0
+                int v = X.order[i], j = i - 1;
+                while (j >= 0 && cmp(X.order[j], v, by) < 0) {
+                    X.order[j + 1] = X.order[j];
+                    j--;
+                }
+                X.order[j + 1] = v;
+            }
+            // the candidate with the most required tiles: Iterator::max_by keeps the LAST maximum (obs_repr.rs:589-596)
+            int best = -1;
+            for (int k = 0; k < n_cand; k++) {
+                int c = X.order[k];
+                if (best < 0 || cmp(c, best, 3) >= 0) best = c;
+            }
+            X.lvl_begin[4] = best;
+        }
+        sp_sync<WAVE>();
+        {
+            const int first = n_cand > 0 ? X.order[0] : -1;
+            const float max_ev = (with_probs && first >= 0 && T > 0) ? X.cand_ev0[first] : 0.f;
+            if (tid < 34) {
+                out[(O_SP + 0) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 100000.f) / 100000.f;
+                out[(O_SP + 1) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 30000.f) / 30000.f;
+            }
+            // required tiles
+            if (can_discard0 && !after_riichi) {
+                for (int c = tid / 34; c < n_cand; c += NT / 34) {
+                    int t = tid % 34;
+                    if (tid >= (NT / 34) * 34) break;
+                    if ((X.cand_req[c] >> t) & 1) {
+                        int dtid = deaka(X.cand_tile[c]);
+                        out[(O_SP + 2 + (X.cand_down[c] ? 34 : 0) + dtid) * 34 + t] = 1.f;
+                    }
+                }
+                if (tid == 0 && X.lvl_begin[4] >= 0) out[(O_SP + 70) * 34 + deaka(X.cand_tile[X.lvl_begin[4]])] = 1.f;
+            } else if (can_discard0) {
+                // discard after riichi: `cans.can_discard` is still true in the encoder (obs_repr.rs:580), the single
+                // candidate's tile was patched to the drawn tile (agent_helper.rs:588-590)
+                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 2 + deaka(last_tsumo)) * 34 + tid] = 1.f;
+                if (tid == 0) out[(O_SP + 70) * 34 + deaka(last_tsumo)] = 1.f;
+            } else {
+                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 71) * 34 + tid] = 1.f;
+            }
+            // sp table (obs_repr.rs:644-692)
+            const float ev_scale = max_ev < 1.f ? 0.f : 1.f / max_ev;
+            bool table_ok = with_probs && first >= 0 && X.cand_tp0[first] > 0.f;
+            if (table_ok) {  // uniform over the workgroup
+                // one load per (candidate, turn): the clamped values go to the LDS (the evaluation scratch is free now), and
+                // take_while(p > 0) on the tenpai probs becomes an AND over the lower turns' flags (instead of a chain of up to
+                // 17 dependent loads per thread)
+                float* tv = tv_area;  // [candidate slot * SP_T + turn][4]: tenpai, win, ev, alive
+                static_assert(SP_EVAL_LDS_FLOATS >= SP_MAX_CAND * SP_T * 4, "table staging fits the evaluation scratch");
+                const int n_src = can_discard0 ? n_cand : 1;
+                for (int q = tid; q < n_src * SP_T; q += NT) {
+                    const int c = q / SP_T, turn = q % SP_T;
+                    {
+                        float tpv = 0.f, wpv = 0.f, evv = 0.f;
+                        if (turn < T) {
+                            const SpNode& nd = W->node[X.cand_slot[can_discard0 ? c : first]];
+                            tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[turn][0], 0.f), 1.f);
+                            wpv = fminf(fmaxf(nd.val[turn][1], 0.f), 1.f);
+                            evv = fmaxf(nd.val[turn][2], 0.f);
+                        }
+                        float* dst = tv + (c * SP_T + turn) * 4;
+                        dst[0] = tpv; dst[1] = wpv; dst[2] = fminf(evv * ev_scale, 1.f); dst[3] = tpv > 0.f ? 1.f : 0.f;
+                    }
+                }
+                sp_sync<WAVE>();
+                auto alive_upto = [&](int c, int turn) {
+                    bool alive = true;
+                    for (int q = 0; q <= turn; q++) alive = alive && tv[(c * SP_T + q) * 4 + 3] != 0.f;
+                    return alive;
+                };
+                if (can_discard0) {
+                    for (int q = tid; q < n_cand * SP_T; q += NT) {
+                        const int c = q / SP_T, turn = q % SP_T;
+                        if (turn < T && alive_upto(c, turn)) {
+                            const int col = after_riichi ? deaka(last_tsumo) : deaka(X.cand_tile[c]);
+                            const float* src = tv + (c * SP_T + turn) * 4;
+                            out[(O_SP + 72 + turn) * 34 + col] = src[0];
+                            out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
+                            out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
+                        }
+                    }
+                } else {
+                    for (int w = tid; w < SP_T * 34; w += NT) {
+                        const int turn = w / 34, col = w % 34;
+                        if (turn >= T || !alive_upto(0, turn)) continue;
+                        const float* src = tv + turn * 4;
+                        out[(O_SP + 72 + turn) * 34 + col] = src[0];
+                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
+                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
+                    }
+                }
+            }
+        }
+}
+
+// A row without a state graph (queue tail, sp_row_class == 7), processed by ONE wavefront with its own context: set-up and encoder only.
+struct SpWaveArea {
+    TableOne st;
+    SpCtx X;
+};
+__device__ __noinline__ void sp_light_row(const uint32_t* rows, const TableOne* snap, float* obs, unsigned long long* err, SpWork* W, SpWaveArea* A, int row) {
+    SP_ASSUME_LDS(A);
+    const int lane = threadIdx.x & 63;
+    SP_HBM float* out = (SP_HBM float*)obs + (size_t)row * (1012 * 34);
+    const long long t0 = wall_clock64();
+    const SpRowInfo R = sp_row_front<true, 64>((const SP_HBM uint32_t*)rows, (const SP_HBM TableOne*)snap, W, A->X, &A->st, lane, row, out, nullptr);
+    if (R.ok) {
+        if (R.with_probs) A->X.overflow = 1;  // cannot happen: the row order put a row WITH a graph into the tail of the queue
+        sp_row_write<true, 64>(W, A->X, R, lane, out, nullptr);
+        if (A->X.overflow && lane == 0) __hip_atomic_fetch_add(&((SP_HBM unsigned long long*)err)[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+        __hip_atomic_fetch_add(&((SP_HBM unsigned long long*)err)[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&((SP_HBM unsigned long long*)err)[2], (unsigned long long)(wall_clock64() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    mj_team_sync<64>();
+}
+
+__global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
+    __shared__ SpCtx X;
+    __shared__ int s_row;
+    __shared__ union SpTeams {
+        TableOne st;                                 // the decision's table record: read during the row set-up only
+        SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
+        float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
+        SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
+    } s_tm;
+    SpWork* W = P.work + blockIdx.x;
+    const int tid = threadIdx.x;
+
+    // the hash tags start empty: zeroed once when the work area is allocated, and every row clears the tags it set
+
+    const long long t_wg0 = P.prof ? wall_clock64() : 0;  // MJ_SP_PROF: workgroup lifetime / queue + reset time (err[19..22])
+    long long t_pop = 0, t_reset = 0;
+    // the queue is ordered by cost class (mj_k_order_*): the rows of class 7 (no state graph at all) form its tail
+    const int n_heavy = P.n_rows - P.queue[1 + 7];
+    bool wave_mode = false;
+    for (;;) {
+        const long long t_a = P.prof ? wall_clock64() : 0;
+        if (tid == 0) s_row = atomicAdd(P.queue, 1);
+        __syncthreads();
+        if (s_row >= P.n_rows) break;
+        if (s_row >= n_heavy) { wave_mode = true; break; }
+        const int row = (int)P.order[s_row];
+        if (P.prof) t_pop += wall_clock64() - t_a;
+        long long t_0 = wall_clock64(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0;
+        float* out = P.obs + (size_t)row * (1012 * 34);
+        const SpRowInfo R = sp_row_front<false, SP_THREADS>(P.rows, P.snap, W, X, &s_tm.st, tid, row, out, P.prof);
+        if (!R.ok) continue;
+        const int cur_shanten = R.cur_shanten, n_cand = R.n_cand, T = R.T;
+        const bool with_probs = R.with_probs, can_discard = R.can_discard;
+        const SpState root = R.root;
         // fewer draws left than the shanten number: tenpai / win / EV are exactly zero for every candidate (reaching tenpai
         // takes cur_shanten draws), so the state graph need not be built at all
-        const bool with_probs = cur_shanten <= 3 && X.T >= cur_shanten;
         t_1 = wall_clock64();
         t_2 = t_3 = t_4 = t_1;
         if (with_probs) {
@@ -1398,129 +1624,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             t_4 = wall_clock64();
         }
 
-        // ---- sort (calc.rs:181-188 / 196-199) + encode (obs_repr.rs:564-692)
-        if (tid < n_cand) {  // one lane per candidate fetches its turn-0 values (side by side, not a chain of dependent loads)
-            const int c = tid;
-            X.order[c] = c;
-            const int slot = X.cand_slot[c];
-            if (with_probs && slot >= 0) {  // Candidate::from clamps (candidate.rs:46-70); shanten 0 => tenpai = 1
-                const SpNode& nd = W->node[slot];
-                const float tp = cur_shanten == 0 ? 1.f : nd.val[0][0];
-                X.cand_tp0[c] = fminf(fmaxf(tp, 0.f), 1.f);
-                X.cand_wp0[c] = fminf(fmaxf(nd.val[0][1], 0.f), 1.f);
-                X.cand_ev0[c] = fmaxf(nd.val[0][2], 0.f);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            auto cmp = [&](int l, int r, int by) -> int {  // candidate.rs:73-106, by: 0 EV, 3 NotShantenDown
-                if (X.cand_tile[l] == X.cand_tile[r]) return 0;
-                int o;
-                if (by <= 0 && (o = f32_total_cmp(X.cand_ev0[l], X.cand_ev0[r])) != 0) return o;
-                if (by <= 1 && (o = f32_total_cmp(X.cand_wp0[l], X.cand_wp0[r])) != 0) return o;
-                if (by <= 2 && (o = f32_total_cmp(X.cand_tp0[l], X.cand_tp0[r])) != 0) return o;
-                if (!X.cand_down[l] && X.cand_down[r]) return 1;
-                if (X.cand_down[l] && !X.cand_down[r]) return -1;
-                if (X.cand_nreq[l] != X.cand_nreq[r]) return X.cand_nreq[l] < X.cand_nreq[r] ? -1 : 1;
-                return cmp_discard_priority(X.cand_tile[l], X.cand_tile[r]);
-            };
-            const int by = with_probs ? 0 : 3;
-            for (int i = 1; i < n_cand; i++) {  // stable insertion sort, descending: before(l, r) = cmp(r, l) < 0
-                int v = X.order[i], j = i - 1;
-                while (j >= 0 && cmp(X.order[j], v, by) < 0) {
-                    X.order[j + 1] = X.order[j];
-                    j--;
-                }
-                X.order[j + 1] = v;
-            }
-            // the candidate with the most required tiles: Iterator::max_by keeps the LAST maximum (obs_repr.rs:589-596)
-            int best = -1;
-            for (int k = 0; k < n_cand; k++) {
-                int c = X.order[k];
-                if (best < 0 || cmp(c, best, 3) >= 0) best = c;
-            }
-            X.lvl_begin[4] = best;
-        }
-        __syncthreads();
-        {
-            const int first = n_cand > 0 ? X.order[0] : -1;
-            const float max_ev = (with_probs && first >= 0 && T > 0) ? X.cand_ev0[first] : 0.f;
-            if (tid < 34) {
-                out[(O_SP + 0) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 100000.f) / 100000.f;
-                out[(O_SP + 1) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 30000.f) / 30000.f;
-            }
-            // required tiles
-            if (can_discard0 && !after_riichi) {
-                for (int c = tid / 34; c < n_cand; c += SP_THREADS / 34) {
-                    int t = tid % 34;
-                    if (tid >= (SP_THREADS / 34) * 34) break;
-                    if ((X.cand_req[c] >> t) & 1) {
-                        int dtid = deaka(X.cand_tile[c]);
-                        out[(O_SP + 2 + (X.cand_down[c] ? 34 : 0) + dtid) * 34 + t] = 1.f;
-                    }
-                }
-                if (tid == 0 && X.lvl_begin[4] >= 0) out[(O_SP + 70) * 34 + deaka(X.cand_tile[X.lvl_begin[4]])] = 1.f;
-            } else if (can_discard0) {
-                // discard after riichi: `cans.can_discard` is still true in the encoder (obs_repr.rs:580), the single
-                // candidate's tile was patched to the drawn tile (agent_helper.rs:588-590)
-                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 2 + deaka(last_tsumo)) * 34 + tid] = 1.f;
-                if (tid == 0) out[(O_SP + 70) * 34 + deaka(last_tsumo)] = 1.f;
-            } else {
-                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 71) * 34 + tid] = 1.f;
-            }
-            // sp table (obs_repr.rs:644-692)
-            const float ev_scale = max_ev < 1.f ? 0.f : 1.f / max_ev;
-            bool table_ok = with_probs && first >= 0 && X.cand_tp0[first] > 0.f;
-            if (table_ok) {  // uniform over the workgroup
-                // one load per (candidate, turn): the clamped values go to the LDS (the evaluation scratch is free now), and
-                // take_while(p > 0) on the tenpai probs becomes an AND over the lower turns' flags (instead of a chain of up to
-                // 17 dependent loads per thread)
-                float* tv = s_tm.ev;  // [candidate slot * SP_T + turn][4]: tenpai, win, ev, alive
-                static_assert(SP_EVAL_LDS_FLOATS >= SP_MAX_CAND * SP_T * 4, "table staging fits the evaluation scratch");
-                const int n_src = can_discard0 ? n_cand : 1;
-                for (int q = tid; q < n_src * SP_T; q += SP_THREADS) {
-                    const int c = q / SP_T, turn = q % SP_T;
-                    {
-                        float tpv = 0.f, wpv = 0.f, evv = 0.f;
-                        if (turn < T) {
-                            const SpNode& nd = W->node[X.cand_slot[can_discard0 ? c : first]];
-                            tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[turn][0], 0.f), 1.f);
-                            wpv = fminf(fmaxf(nd.val[turn][1], 0.f), 1.f);
-                            evv = fmaxf(nd.val[turn][2], 0.f);
-                        }
-                        float* dst = tv + (c * SP_T + turn) * 4;
-                        dst[0] = tpv; dst[1] = wpv; dst[2] = fminf(evv * ev_scale, 1.f); dst[3] = tpv > 0.f ? 1.f : 0.f;
-                    }
-                }
-                __syncthreads();
-                auto alive_upto = [&](int c, int turn) {
-                    bool alive = true;
-                    for (int q = 0; q <= turn; q++) alive = alive && tv[(c * SP_T + q) * 4 + 3] != 0.f;
-                    return alive;
-                };
-                if (can_discard0) {
-                    for (int q = tid; q < n_cand * SP_T; q += SP_THREADS) {
-                        const int c = q / SP_T, turn = q % SP_T;
-                        if (turn < T && alive_upto(c, turn)) {
-                            const int col = after_riichi ? deaka(last_tsumo) : deaka(X.cand_tile[c]);
-                            const float* src = tv + (c * SP_T + turn) * 4;
-                            out[(O_SP + 72 + turn) * 34 + col] = src[0];
-                            out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
-                            out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
-                        }
-                    }
-                } else {
-                    for (int w = tid; w < SP_T * 34; w += SP_THREADS) {
-                        const int turn = w / 34, col = w % 34;
-                        if (turn >= T || !alive_upto(0, turn)) continue;
-                        const float* src = tv + turn * 4;
-                        out[(O_SP + 72 + turn) * 34 + col] = src[0];
-                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
-                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
-                    }
-                }
-            }
-        }
+        sp_row_write<false, SP_THREADS>(W, X, R, tid, out, s_tm.ev);
         __syncthreads();
         if (tid == 0) {
             long long t_5 = wall_clock64();
@@ -1558,5 +1662,19 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
         atomicMax(&P.err[20], life);
         atomicAdd(&P.err[21], (unsigned long long)t_pop);
         atomicAdd(&P.err[22], (unsigned long long)t_reset);
+    }
+    // ---- the tail of the queue: every wavefront takes its own rows (set-up + encoder only, no workgroup barrier any more)
+    if (wave_mode) {
+        const int wv = tid >> 6, lane = tid & 63;
+        int q = s_row;  // the index this workgroup popped last goes to its first wavefront
+        if (wv != 0) {
+            if (lane == 0) q = atomicAdd(P.queue, 1);
+            q = __shfl(q, 0);
+        }
+        while (q < P.n_rows) {
+            sp_light_row(P.rows, P.snap, P.obs, P.err, W, &s_tm.wave[wv], (int)P.order[q]);
+            if (lane == 0) q = atomicAdd(P.queue, 1);
+            q = __shfl(q, 0);
+        }
     }
 }
