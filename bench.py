@@ -394,7 +394,8 @@ def main():
             if "write_bytes_per_decision" in pmc and "fetch_bytes_per_decision" in pmc:
                 per = pmc["write_bytes_per_decision"] + pmc["fetch_bytes_per_decision"]
                 traffic = per * rows_timed / enc_launches
-                traffic_src = f"profiles/pmc_encode.json ({per:.0f} B/decision, PMC passes at {pmc['tables']} tables)"
+                traffic_src = (f"profiles/pmc_encode.json ({per:.0f} B/decision; static file from separate rocprofv3 --pmc passes at "
+                               f"{pmc.get('measured_at_tables', pmc['tables'])} tables, {pmc.get('measured_utc', 'round 2')})")
         line = {
             "metric": "env steps/sec (65536 parallel tables per GPU)",
             "value": steps / dt,
@@ -461,30 +462,56 @@ def main():
         dist.destroy_process_group()
 
 
-VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md: v_fma_f32)
+# What this kernel's instruction mix can issue at best: tools/ubench_valu.hip (profiles/r03_ubench_valu.jsonl, MI355X, 4 waves
+# per SIMD) measures 4.2-4.4 cycles per wave-instruction per SIMD for v_bfe / v_lshrrev_b64 / v_mul_lo / v_mad_u32_u24 / v_bcnt /
+# v_min3 / v_perm / v_lshl_add / v_cmp / DPP moves / v_pk_fma_f32, 3.45 for v_fma_f32 and 2.4-2.6 only for v_add_u32 / v_and_b32 /
+# v_mul_f32 / v_add_f32 - the integer / bit-field work of mj_k_sp is priced at 4.3.
+VALU_PEAK_WAVE_INSTS_INT_MIX = 256 * 4 * 2.4e9 / 4.3
+SP_PMC_FILE = os.path.join(ROOT, "profiles", "r03_sp_pmc.json")
+
+
+def sp_source_sha16():
+    """Identity of the SP kernel's sources: the PMC summary is stamped with it, and a bench line refuses to quote instruction
+    counts measured on different code (stale static profiles must not look measured)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("mj_sp.hip", "mj_sptab.h", "mj_algo.h", "mj_rules.h", "mj_state.h"):
+        with open(os.path.join(ROOT, "mortal_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _roofline_sp(r, sp_ms, sp_launches):
-    """The cycle's dominant kernel is not HBM- or MFMA-bound: it is integer / f32 VALU work (shanten probes, hashing, IEEE
-    divisions in the reference's summation order).  Model: VALU wave-instructions per state graph node (from the separate
-    rocprofv3 --pmc pass, profiles/r02_sp_pmc.json) x nodes visited in the timed region (counted by the kernel) / kernel time
-    (HIP events on the launch stream), against the chip's VALU issue peak; the PMC pass also gives the VALU-busy share, the
-    lane utilisation and the HBM-side traffic of the kernel."""
-    out = {"kernel": "mj_k_sp", "bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_WAVE_INSTS / 1e9,
+    """The cycle's dominant kernel is neither HBM- nor MFMA-bound: integer / bit-field VALU work (table-id shanten sets, hashing,
+    child lists) and exact f32 sums in the reference's order, much of it waiting for dependent gathers.  Model: VALU
+    wave-instructions per state-graph node (separate rocprofv3 --pmc pass, profiles/r03_sp_pmc.json - a STATIC file, stamped with
+    the hash of the kernel sources; if it does not match the sources of this run the fraction is null and `stale` is set)
+    x nodes visited in the timed region (counted by the kernel) / kernel time (HIP events on the launch stream), against the
+    issue rate the instruction mix can reach (tools/ubench_valu.hip) and, for reference, the f32 FMA rate."""
+    out = {"kernel": "mj_k_sp", "bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_WAVE_INSTS_INT_MIX / 1e9,
+           "peak_basis": "measured issue interval of the kernel's integer / bit-field instruction classes: 4.3 cycles per wave-instruction "
+                         "per SIMD (profiles/r03_ubench_valu.jsonl); the guide's v_fma_f32 rate (2 cycles) is `peak_f32_fma`",
+           "peak_f32_fma": VALU_PEAK_WAVE_INSTS / 1e9,
            "avg_launch_ms": sp_ms / max(sp_launches, 1), "launches": sp_launches,
-           "states_per_launch": r["sp_phases"]["states_per_step"]}
-    f = os.path.join(ROOT, "profiles", "r02_sp_pmc.json")
-    if os.path.exists(f) and sp_ms > 0:
-        pmc = json.load(open(f))
+           "states_per_launch": r["sp_phases"]["states_per_step"], "from_static_profile": True}
+    if os.path.exists(SP_PMC_FILE) and sp_ms > 0:
+        pmc = json.load(open(SP_PMC_FILE))
+        stale = pmc.get("source_sha16") != sp_source_sha16()
+        out["stale"] = stale
+        out["static_profile"] = {"file": "profiles/r03_sp_pmc.json", "measured_utc": pmc.get("measured_utc"),
+                                 "measured_at_tables": pmc.get("measured_at_tables"), "source_sha16": pmc.get("source_sha16")}
         insts = pmc["valu_insts_per_state"] * r["sp_phases"]["states_per_step"] * r["n_cycles"]
-        out["achieved"] = insts / (sp_ms * 1e-3) / 1e9
-        out["frac"] = out["achieved"] / out["peak"]
         out["valu_insts_per_state"] = pmc["valu_insts_per_state"]
+        out["achieved"] = None if stale else insts / (sp_ms * 1e-3) / 1e9
+        out["frac"] = None if stale else out["achieved"] / out["peak"]
+        out["frac_of_f32_fma_rate"] = None if stale else out["achieved"] / out["peak_f32_fma"]
         for k in ("valu_busy", "lane_utilisation", "wave_wait_share", "hbm_fetch_bytes_per_state", "hbm_write_bytes_per_state",
-                  "l2_hit_rate", "source"):
+                  "l2_hit_rate", "salu_insts_per_state", "lds_insts_per_state", "vmem_rd_insts_per_state", "source"):
             if k in pmc:
                 out[k] = pmc[k]
-        if "hbm_fetch_bytes_per_state" in pmc:
+        if "hbm_fetch_bytes_per_state" in pmc and not stale:
             by = (pmc["hbm_fetch_bytes_per_state"] + pmc["hbm_write_bytes_per_state"]) * r["sp_phases"]["states_per_step"] * r["n_cycles"]
             out["hbm_gbs"] = by / (sp_ms * 1e-3) / 1e9
             out["hbm_frac_of_peak"] = out["hbm_gbs"] / HBM_PEAK_GBS

@@ -37,13 +37,17 @@ def pmc_rows(d, name):
 
 def main():
     src, rnd = sys.argv[1], sys.argv[2]
+    tables = int(sys.argv[3]) if len(sys.argv) > 3 else 65536  # table count of the PMC passes (tools/r03_full.sh: the bench's own)
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
     for v in (3, 4):
         f = first(os.path.join(src, f"v{v}_stats", "**", "*kernel_stats.csv"))
         if f:
             shutil.copy(f, os.path.join(prof, f"{rnd}_bench_v{v}_kernel_stats.csv"))
-    out = {"source": f"tools/profile_round.sh -> {src}", "tables": 16384, "obs_version": 4}
+    import time
+
+    out = {"source": f"{src} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes over mj_k_encode)", "tables": tables, "measured_at_tables": tables,
+           "obs_version": 4, "measured_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "round": rnd}
     for key, cname, scale in (("write", "WRITE_SIZE", 1.0), ("fetch", "FETCH_SIZE", 2.0)):
         f, rows = pmc_rows(os.path.join(src, f"pmc_{key}"), cname)
         if not rows:

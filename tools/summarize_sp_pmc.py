@@ -14,6 +14,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main():
@@ -39,8 +40,13 @@ def main():
     n_simd = 256 * 4
     wave_qc = c["SQ_WAVE_CYCLES"]
     waves = c["SQ_WAVES"]
+    import time
+
+    from bench import sp_source_sha16
+
     out = {
         "source": f"tools/pmc_sp.sh -> {src} (bench.py --steps 4 --warmup 2 under rocprofv3 --pmc, mj_k_sp launches only)",
+        "source_sha16": sp_source_sha16(), "measured_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "measured_at_tables": 65536,
         "states_per_launch": states, "rows_per_launch": rows, "kernel_ms_under_profiler": ms,
         "valu_insts_per_launch": c["SQ_INSTS_VALU"], "valu_insts_per_state": c["SQ_INSTS_VALU"] / states,
         "salu_insts_per_state": c.get("SQ_INSTS_SALU", 0) / states, "lds_insts_per_state": c.get("SQ_INSTS_LDS", 0) / states,

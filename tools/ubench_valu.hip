@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_bench(int iters, uint32_t seed, unsigne
             REP8(CHAINS(OP))
 #undef OP
         } else if constexpr (KIND == K_CNDMASK) {
-#define OP(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(k) : "vcc");
+#define OP(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(k), "s"(t1));  // the mask in an SGPR pair
             REP8(CHAINS(OP))
 #undef OP
         } else if constexpr (KIND == K_LSHR64) {
