@@ -1,0 +1,199 @@
+"""A second, independently shaped reading of the single-player calculator (algo/sp/calc.rs:447-637) for the oracle's sp.cc: the
+draw / discard recursion written directly as probabilities over the turns, in EXACT rationals — no probability tables, no f32, no
+memo keyed by levels — and compared with oracle/sp.cc's f32 results (relative 2e-5).
+
+What it re-derives, from the calculator's own model (one tile leaves the unseen pool per turn; only draws that lower the shanten
+number are kept; the discard after such a draw is the one with the larger integer EV, ties by discard priority):
+  * prob(i, j) = P(no useful tile on turns i .. j-1) * count / (left - j)  instead of  tsumo_prob[count][j] * not_tsumo[j] / not_tsumo[i]
+    (calc.rs:135-167, 486-503), including the table's cut-off once every remaining tile is a useful one;
+  * the turn bounds: a draw on the last turn cannot be followed by another one (calc.rs:533), tenpai at 1-shanten counts the
+    draw itself (calc.rs:529-531);
+  * ippatsu / haitei / double-riichi han bonuses per (i, j) (calc.rs:505-521) — exercised with a closed hand that does not
+    prefer riichi (menzen tsumo only) and with haitei on, so the score vector is the plain point table;
+  * the per-turn choice of the discard by the truncated EV (calc.rs:606-629) and the red-five draw entries (state.rs:150-165).
+The shanten numbers, agari (fu / han) and points come from the oracle functions that the reference's KATs pin
+(tests/test_oracle_kats.py).  CPU only."""
+from fractions import Fraction
+from functools import lru_cache
+
+import numpy as np
+import pytest
+
+DISCARD_PRIO = [6, 5, 4, 3, 2, 3, 4, 5, 6] * 3 + [7] * 7 + [1, 1, 1, 0]  # tile.rs:21-28
+
+
+def _tsumo_total(o, is_oya, fu, han):
+    out = np.zeros(3, dtype=np.int32)
+    assert o.lib().mjo_point(int(is_oya), fu, han, o.ptr(out)) == 0
+    return int(out[1]) * 3 if is_oya else int(out[1]) * 2 + int(out[2])
+
+
+class ExactSP:
+    """Closed hand (len_div3 = 4), no riichi preference: additional han = 1 (menzen tsumo), han bonus only from haitei."""
+
+    def __init__(self, o, wall, akas_wall, T, bakaze, jikaze, dora_ind, calc_haitei):
+        self.o, self.T, self.bakaze, self.jikaze, self.dora_ind, self.haitei = o, T, bakaze, jikaze, dora_ind, calc_haitei
+        self.n_left = int(sum(wall))
+        self.root_wall, self.root_akas_wall = tuple(wall), tuple(akas_wall)
+
+    def shanten(self, hand):
+        return self.o.calc_shanten(np.array(hand, dtype=np.uint8), 4)
+
+    def entries(self, hand, wall, akas_wall, L):
+        """(tile37, count) of the draws that lower the shanten number, reference order (state.rs:128-173)."""
+        out = []
+        for t in range(34):
+            c = wall[t]
+            if c == 0:
+                continue
+            h = list(hand)
+            h[t] += 1
+            if self.shanten(h) != L - 1:
+                continue
+            k = {4: 0, 13: 1, 22: 2}.get(t)
+            if k is not None and akas_wall[k]:
+                if c >= 2:
+                    out.append((t, c - 1))
+                out.append((34 + k, 1))
+            else:
+                out.append((t, c))
+        return out
+
+    def score(self, hand14, akas_hand, win_tile, han_plus):
+        """get_score (calc.rs:640-758) without riichi: tsumo points of fu / han + 1 (menzen tsumo) + doras + han_plus."""
+        t = win_tile if win_tile < 34 else (4, 13, 22)[win_tile - 34]
+        doras = sum(hand14[self.o.lib().mjo_tile_next(d)] for d in self.dora_ind) + sum(akas_hand)
+        r = self.o.agari(np.array(hand14, dtype=np.uint8), t, False, mode=0, additional_hans=1, doras=doras, bakaze=self.bakaze,
+                         jikaze=self.jikaze)
+        if r is None:
+            return None
+        is_oya = self.jikaze == 27
+        if r[0] == "yakuman":
+            return 16000 * r[1] * 3 if is_oya else 8000 * r[1] * 2 + 16000 * r[1]
+        return _tsumo_total(self.o, is_oya, r[1], r[2] + han_plus)
+
+    @lru_cache(maxsize=None)
+    def draw(self, hand, akas_hand, wall, akas_wall, L):
+        """values[i] = (tenpai, win, ev) of a 13-tile state at shanten L when turn i is next (draw_without_tegawari)."""
+        T, n = self.T, self.n_left
+        ent = self.entries(hand, wall, akas_wall, L)
+        R = sum(c for _, c in ent)
+        ten, win, ev = [Fraction(0)] * T, [Fraction(0)] * T, [Fraction(0)] * T
+        for tile, c in ent:
+            t = tile if tile < 34 else (4, 13, 22)[tile - 34]
+            h = list(hand); h[t] += 1
+            w = list(wall); w[t] -= 1
+            ah, aw = list(akas_hand), list(akas_wall)
+            if tile >= 34:
+                ah[tile - 34], aw[tile - 34] = 1, 0
+            if L > 0:
+                nxt = self.discard(tuple(h), tuple(ah), tuple(w), tuple(aw), L - 1)
+                scores = None
+            else:
+                scores = [self.score(h, ah, tile, hp) for hp in (0, 1)]
+                if scores[0] is None:
+                    continue  # no yaku with this tile
+            for i in range(T):
+                no = Fraction(1)  # P(no useful tile on turns i .. j-1 | none before i)
+                for j in range(i, T):
+                    left = n - j
+                    if left <= 0 or no == 0:
+                        break
+                    p = no * Fraction(c, left)
+                    if L == 0:
+                        win[i] += p
+                        ev[i] += p * scores[int(self.haitei and j == T - 1)]
+                    else:
+                        if L == 1:
+                            ten[i] += p
+                        if j < T - 1:
+                            if L > 1:
+                                ten[i] += p * nxt[0][j + 1]
+                            win[i] += p * nxt[1][j + 1]
+                            ev[i] += p * nxt[2][j + 1]
+                    no *= Fraction(max(left - R, 0), left)
+        return tuple(ten), tuple(win), tuple(ev)
+
+    @lru_cache(maxsize=None)
+    def discard(self, hand, akas_hand, wall, akas_wall, L):
+        """Per turn the discard with the larger truncated EV, ties by priority (discard_slow, calc.rs:563-637)."""
+        T = self.T
+        best = [None] * T
+        vals = [None] * T
+        for d in range(34):
+            if hand[d] == 0:
+                continue
+            h = list(hand); h[d] -= 1
+            if self.shanten(h) != L:
+                continue
+            ah = list(akas_hand)
+            tile = d
+            k = {4: 0, 13: 1, 22: 2}.get(d)
+            if k is not None and akas_hand[k] and hand[d] == 1:  # the red five goes last (state.rs:116-121)
+                tile, ah[k] = 34 + k, 0
+            v = self.draw(tuple(h), tuple(ah), wall, akas_wall, L)
+            for i in range(T):
+                key = (int(v[2][i]), DISCARD_PRIO[tile], -tile)  # value, then cmp_discard_priority (tile.rs:169-177)
+                if best[i] is None or key > best[i]:
+                    best[i], vals[i] = key, (v[0][i], v[1][i], v[2][i])
+        return tuple(x[0] for x in vals), tuple(x[1] for x in vals), tuple(x[2] for x in vals)
+
+
+def _cases():
+    """13-tile hands near completion: four random sets + a pair, one tile removed, then up to two tiles swapped for random ones."""
+    rng = np.random.default_rng(20260924)
+    out = []
+    while len(out) < 24:
+        cnt = np.zeros(34, dtype=np.int64)
+        for _ in range(4):
+            if rng.random() < 0.65:
+                s_, p_ = int(rng.integers(0, 3)), int(rng.integers(0, 7))
+                cnt[9 * s_ + p_:9 * s_ + p_ + 3] += 1
+            else:
+                cnt[int(rng.integers(0, 34))] += 3
+        cnt[int(rng.integers(0, 34))] += 2
+        if cnt.max() > 4:
+            continue
+        cnt[int(rng.choice(np.flatnonzero(cnt)))] -= 1
+        for _ in range(int(rng.integers(0, 3))):
+            cnt[int(rng.choice(np.flatnonzero(cnt)))] -= 1
+            t = int(rng.integers(0, 34))
+            while cnt[t] >= 4:
+                t = int(rng.integers(0, 34))
+            cnt[t] += 1
+        rest = np.repeat(np.arange(34), 4 - cnt)
+        rng.shuffle(rest)
+        seen_extra = np.bincount(rest[:int(rng.integers(15, 75))], minlength=34)
+        out.append((cnt, seen_extra, int(rng.integers(2, 8)), 27 + int(rng.integers(0, 2)), 27 + int(rng.integers(0, 4)),
+                    int(rng.integers(0, 34)), bool(rng.integers(0, 2)), tuple(int(x) for x in rng.integers(0, 2, 3))))
+    return out
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_oracle_sp_against_exact_rational_recursion(oracle, case):
+    hand, seen_extra, T, bakaze, jikaze, dora, haitei, akas_seen_bits = _cases()[case]
+    L = oracle.calc_shanten(hand.astype(np.uint8), 4)
+    if not (0 <= L <= 2) or T < L:
+        pytest.skip("outside the recursion's range for this test")
+    seen = hand + seen_extra  # seen_extra is drawn from the tiles the hand does not hold: never more than four of a kind
+    if seen[dora] == hand[dora] and seen[dora] < 4:
+        seen[dora] += 1  # the indicator itself is a seen tile
+    wall = [4 - int(x) for x in seen]
+    # red fives: in the hand if the hand holds the five and the bit says so; otherwise seen elsewhere or still in the wall
+    akas_hand = tuple(int(akas_seen_bits[k] and hand[t] > 0) for k, t in enumerate((4, 13, 22)))
+    akas_seen = tuple(int(akas_hand[k] or (akas_seen_bits[k] and seen[t] > hand[t]) or wall[t] == 0) for k, t in enumerate((4, 13, 22)))
+    akas_wall = tuple(1 - a for a in akas_seen)
+    got = oracle.sp_calc(hand.astype(np.uint8), seen.astype(np.uint8), jikaze=jikaze, bakaze=bakaze, tsumos_left=T, cur_shanten=L,
+                         can_discard=False, prefer_riichi=False, calc_haitei=haitei, dora_indicators=[dora], akas_in_hand=akas_hand,
+                         akas_seen=akas_seen, sort_result=False)
+    assert len(got) == 1
+    X = ExactSP(oracle, wall, akas_wall, T, bakaze, jikaze, [dora], haitei)
+    ten, win, ev = X.draw(tuple(int(x) for x in hand), akas_hand, tuple(wall), akas_wall, L)
+    c = got[0]
+    n = len(c["win_probs"])
+    assert n == T
+    for i in range(T):
+        want_t = 1.0 if L == 0 else float(ten[i])
+        assert abs(float(c["win_probs"][i]) - float(win[i])) <= 2e-5 * max(1.0, float(win[i])), (i, c["win_probs"][i], float(win[i]))
+        assert abs(float(c["exp_values"][i]) - float(ev[i])) <= 2e-5 * max(1.0, float(ev[i])), (i, c["exp_values"][i], float(ev[i]))
+        assert abs(min(max(float(c["tenpai_probs"][i]), 0.0), 1.0) - min(want_t, 1.0)) <= 2e-5, (i, c["tenpai_probs"][i], want_t)
