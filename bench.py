@@ -163,6 +163,11 @@ def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmu
     pool = pool_cls(N, version=version, deal_algo=deal_algo, device=str(dev), max_rows=2 * N)
     pool.reset(seeds, game_ids=np.arange(N), n_games_total=N)
     pool.set_refill(world * N // 4)  # a finished table restarts on a seed no other table/rank uses
+    if preroll > 0:
+        # table t enters play at cycle hash(t) % preroll: after the pre-roll the pool is spread over EVERY phase of a hanchan (a
+        # hanchan lasts ~3,100 cycles under the random policy).  Started all at once, the tables march in step for many
+        # generations and a timed window only ever sees one phase (round 2: late south round, before the first wave of restarts)
+        pool.set_start_stagger(preroll)
     C = pool.C
     obs_v = obs[: 2 * N * C * 34].view(2 * N, C, 34)
     obs_3 = obs[: 2 * N * 934 * 34].view(2 * N, 934, 34)

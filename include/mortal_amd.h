@@ -63,6 +63,11 @@ int mj_log_read(MjPool* pool, int table0, int n, uint64_t* words_out /* [n][word
 
 /* Steady-state mode for throughput runs: finished tables restart with nonce += stride. 0 disables. */
 int mj_pool_set_refill(MjPool* pool, uint64_t nonce_stride);
+/* Steady-state throughput mode only (after mj_pool_reset + mj_pool_set_refill, before the first mj_step): instead of all tables
+ * starting their hanchan on the same cycle, table t enters play at cycle hash(t) % cycles (it is parked as finished until then
+ * and started by the refill path), so a pool is spread over every phase of a hanchan from the start — what a long-running
+ * self-play server looks like.  No reference counterpart (BatchGame::run starts all games at once and never restarts one). */
+int mj_pool_set_start_stagger(MjPool* pool, uint32_t cycles, void* stream);
 
 /* One arena cycle.  actions_dev[a] = int32 device array with one action id (0..45) per row of agent a's previous
  * batch (NULL on the first cycle or when that agent had no rows). */

@@ -158,6 +158,7 @@ struct MjPool {
     int enable_quick_eval[2] = {1, 1};
     int enable_agari_guard[2] = {0, 0};
     uint64_t refill_stride = 0;
+    uint32_t start_stagger = 0;
     uint64_t cycles = 0;
     int last_rows[2] = {0, 0};
     bool rows_valid = false;
@@ -374,6 +375,7 @@ int mj_pool_reset(MjPool* P, const uint64_t* nonces, const uint64_t* keys, const
     if (P->log_len) HIP_OK(hipMemset(P->log_len, 0, (size_t)P->n_tables * sizeof(uint32_t)));
     P->rp_active = false;
     P->cycles = 0;
+    P->start_stagger = 0;
     P->rows_valid = false;
     return 0;
 }
@@ -419,6 +421,16 @@ int mj_pool_set_refill(MjPool* P, uint64_t stride) {
     return 0;
 }
 
+int mj_pool_set_start_stagger(MjPool* P, uint32_t cycles, void* stream) {
+    if (!P) return fail("null pool");
+    if (P->cycles != 0) return fail("mj_pool_set_start_stagger: call it right after mj_pool_reset, before the first mj_step");
+    if (cycles && !P->refill_stride) return fail("mj_pool_set_start_stagger needs the refill mode (mj_pool_set_refill)");
+    P->start_stagger = cycles;
+    if (cycles) hipLaunchKernelGGL(mj_k_park, dim3(P->n_blocks), dim3(64), 0, (hipStream_t)stream, P->blocks, P->n_tables);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 static int launch_rows(MjPool* P, hipStream_t s);
 int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
     return mj_step_q(P, a0, a1, nullptr, nullptr, stream);
@@ -454,6 +466,7 @@ int mj_step_ev(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0,
     sp.game_length = 8;
     sp.refill = P->refill_stride != 0;
     sp.refill_stride = P->refill_stride;
+    sp.start_stagger = P->start_stagger;
     sp.counters = P->counters;
     sp.final_scores = P->final_scores;
     sp.final_done = P->final_done;

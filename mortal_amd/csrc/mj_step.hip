@@ -37,6 +37,7 @@ struct StepParams {
     int game_length;           // 8 = hanchan
     int refill;                // steady-state mode: restart finished tables with fresh seeds
     uint64_t refill_stride;    // nonce increment on refill
+    uint32_t start_stagger;    // steady-state mode: table t plays its first game from cycle hash(t) % start_stagger on (0 = all at once)
     unsigned long long* counters;  // [0] env steps, [1] games finished, [2] error count, [3] decisions, [4] quick-evals
     int* final_scores;         // [n_games_total][4] written when a game finishes
     uint8_t* final_done;       // [n_games_total]
@@ -816,12 +817,22 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
     SPROF_CNT(8);
 }
 
+// Park every table as finished (before the first cycle of a staggered steady-state run): mj_k_refill starts each at its own cycle.
+__global__ __launch_bounds__(64) void mj_k_park(TableBlock* blocks, int n_tables) {
+    const int table = blockIdx.x * 64 + threadIdx.x;
+    Lane L = {MJ_POOL_PTR(blocks + blockIdx.x), (int)threadIdx.x, &c_mj_tables};
+    if (table < n_tables && !(F(flags) & TF_INACTIVE)) F(flags) |= TF_DONE;
+}
+
 // Restart finished tables with fresh seeds (steady-state throughput mode; not used in parity runs).
 __global__ __launch_bounds__(64) void mj_k_refill(StepParams P) {
     const int table = blockIdx.x * 64 + threadIdx.x;
     Lane L = {MJ_POOL_PTR(P.blocks + blockIdx.x), (int)threadIdx.x, &c_mj_tables};
     u32 fl = F(flags);
     if (table >= P.n_tables || (fl & TF_INACTIVE) || !(fl & TF_DONE)) return;
+    // staggered first start (mj_pool_set_start_stagger): every table was parked as finished; it enters play at its own cycle,
+    // so that a pool is spread over all phases of a hanchan from the beginning instead of marching in step
+    if (P.start_stagger && P.cycle < (((uint32_t)table * 2654435761u) >> 8) % P.start_stagger) return;
     F(seed_nonce) += P.refill_stride;
     F(game_id) += (u32)P.n_tables;
     if (P.log_len) P.log_len[table] = 0;

@@ -151,6 +151,10 @@ class TablePool:
     def set_refill(self, nonce_stride):
         check(self._L.mj_pool_set_refill(self.h, nonce_stride))
 
+    def set_start_stagger(self, cycles):
+        """Steady-state runs: table t starts its first hanchan at cycle hash(t) % cycles (after reset + set_refill)."""
+        check(self._L.mj_pool_set_start_stagger(self.h, int(cycles), self._stream()))
+
     def step(self, actions0=None, actions1=None, q0=None, q1=None, ev0=None, ev1=None):
         """One arena cycle; actionsN = int32 cuda tensor with one action per row of agent N's last batch; qN = that
         batch's q-values (f32 cuda [n, 46]), needed only by an agent configured with the rule-based agari guard."""

@@ -163,3 +163,33 @@ def test_emu_reference_kats_and_generated_hands(oracle, emu):
     assert K.check_point_sweep(lib) > 250
     st = K.check_generated_hands(oracle, 4000, 7, lib)
     assert st["open"] > 1000 and st["kans"] > 500 and st["yakuman"] > 30 and st["none"] > 30, st
+
+
+def test_emu_staggered_start(oracle, emu):
+    """mj_pool_set_start_stagger (the benchmark's steady-state mode): every table is parked, enters play at its own cycle
+    hash(t) % S through the refill path, and from then on behaves like any refilled table (no errors, games finish)."""
+    import numpy as np
+    import torch
+
+    n, S = 24, 40
+    pool = emu(n, version=3, max_rows=4 * n)
+    pool.reset(parity_util.default_seeds(n), game_ids=np.arange(n), n_games_total=n)
+    pool.set_refill(n)
+    pool.set_start_stagger(S)
+    masks = torch.zeros((4 * n, 46), dtype=torch.bool)
+    obs = torch.zeros((4 * n, 934, 34), dtype=torch.float32)
+    act = torch.zeros(4 * n, dtype=torch.int32)
+    starts = [((t * 2654435761) % (1 << 32) >> 8) % S for t in range(n)]
+    live_prev, a_prev = 0, None
+    for c in range(S + 400):
+        k, _ = pool.step(a_prev, None)
+        steps = pool.counters()["steps"]
+        live = steps - live_prev
+        live_prev = steps
+        assert live == sum(1 for s in starts if s <= c), (c, live)  # the refill of cycle s runs ahead of that cycle's step: in play from cycle s on
+        pool.encode(0, obs, masks)
+        pool.random_policy(0, masks, 7, c, act)
+        a_prev = act[:k]
+        if c > S:
+            assert k > 0
+    assert pool.first_error()[0] == 0
