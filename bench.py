@@ -46,6 +46,7 @@ def _write_ceiling_gbs(buf, nbytes):
     return best
 
 STATE_READ_BYTES = 1500  # per-decision state read
+STAGGER = [True]  # --no-start-stagger: all tables start at once, like rounds 1-2 measured (the timed window then sees ONE phase)
 
 
 def _cpu_worker(version, budget_s, n_tables, wid):
@@ -163,7 +164,7 @@ def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmu
     pool = pool_cls(N, version=version, deal_algo=deal_algo, device=str(dev), max_rows=2 * N)
     pool.reset(seeds, game_ids=np.arange(N), n_games_total=N)
     pool.set_refill(world * N // 4)  # a finished table restarts on a seed no other table/rank uses
-    if preroll > 0:
+    if preroll > 0 and STAGGER[0]:
         # table t enters play at cycle hash(t) % preroll: after the pre-roll the pool is spread over EVERY phase of a hanchan (a
         # hanchan lasts ~3,100 cycles under the random policy).  Started all at once, the tables march in step for many
         # generations and a timed window only ever sees one phase (round 2: late south round, before the first wave of restarts)
@@ -273,6 +274,9 @@ def main():
                          "the reference's Brain/DQN architecture (192 ch x 40 blocks, bf16 autocast), consuming the encoded "
                          "batch in place (BASELINE configs[2])")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for --gpus N > 1 (nccl = RCCL over xGMI)")
+    ap.add_argument("--no-start-stagger", action="store_true",
+                    help="start every table on cycle 0 (the protocol of rounds 1-2) instead of spreading the first starts over the "
+                         "pre-roll (mj_pool_set_start_stagger): the timed window then shows a single phase of the hanchan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true", help="skip the extra workloads (obs v3, no pre-roll, greedy policy)")
     ap.add_argument("--launch-check", action="store_true",
@@ -282,6 +286,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-tables", type=int, default=16, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    STAGGER[0] = not args.no_start_stagger
     if args.cpu_worker >= 0:
         print(json.dumps(_cpu_worker(args.version, args.cpu_budget, args.cpu_tables, args.cpu_worker)))
         return
@@ -426,8 +431,11 @@ def main():
                             + f", env-step + obs(v{args.version})"
                             f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals "
                             f"(wall shuffle of rand {'0.9.1' if default_deal_algo() else '0.8'}); "
-                            f"{args.preroll} untimed pre-roll cycles spread the tables over all game phases",
+                            f"{args.preroll} untimed pre-roll cycles"
+                            + (", first starts staggered over them: every phase of a hanchan is present" if STAGGER[0] and args.preroll > 0
+                               else ", all tables started together: one phase of the hanchan"),
                 "preroll_cycles": args.preroll,
+                "start_stagger": bool(STAGGER[0] and args.preroll > 0),
                 "policy": args.policy,
                 "tables_per_gpu": N,
                 "obs_version": args.version,
