@@ -812,7 +812,10 @@ struct SpEvalFetch {  // what is prefetched per state
     float m;              // not_tsumo_probs[turn of this lane] of the state's required-tile sum (a row of the HBM table)
 };
 template <int TN, int LK>
-__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int first, int end, int stride, int ln) {
+__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int first, int end, int stride, int lane_in_team, int off) {
+    // lane -> turn: a state `off` levels below the row's roots is reached after at least `off` draws, so nobody ever reads its
+    // values of the turns before that (a parent's lane of turn i reads val[j + 1], j >= i): the team is T - off lanes wide
+    const int ln = lane_in_team + off;  // this lane's turn
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(TM);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
@@ -878,12 +881,12 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
         const float my_m = lane_on ? m_raw : 1.f;
         const float my_r = sp_rcp_refined(my_m);
         const int eff_ln = lane_on ? ln : 127;  // `eff_ln <= j` == this lane has a term at turn j
-        mj_team_sync_n(T);  // the team's previous state is done with A[] / nx[]
+        mj_team_sync_n(T - off);  // the team's previous state is done with A[] / nx[]
         Ab[ln] = tp0 * m_raw;
         Ab[T + ln] = tp1 * m_raw;
         Ab[2 * T + ln] = tp2 * m_raw;
         Ab[3 * T + ln] = tp3 * m_raw;
-        mj_team_sync_n(T);
+        mj_team_sync_n(T - off);
         float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
 
         // one draw entry: scores (level 0) or the folded child values in nx[buf] (level > 0)
@@ -892,7 +895,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
             const float* nx = nxb + buf * 4 * (T + 1);
             sp_static_for<0, TN>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                if (j >= T) return;  // uniform (T is a constant of the row)
+                if (j >= T || j < off) return;  // uniform (T and off are constants of the level): no lane of the team has a term before turn `off`
                 float prob = sp_div_domain(Ac[j], my_m, my_r);
                 prob = eff_ln <= j ? prob : 0.f;
                 if constexpr (LK == 0) {
@@ -966,7 +969,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
                     if (e & SP_ENT_LAST) {  // last child of this draw entry (uniform in the team)
                         float* dst = nxb + (buf * (T + 1) + ln) * 4;
                         dst[0] = nx_t; dst[1] = nx_w; dst[2] = nx_e; dst[3] = 0.f;
-                        mj_team_sync_n(T);
+                        mj_team_sync_n(T - off);
                         accumulate(min(max((int)SP_ENT_COUNT(e), 1), 4), buf, 0.f, 0.f, 0.f, 0.f);
                         buf ^= 1;
                         nx_t = nx_w = nx_e = -3.40282347e+38f;
@@ -1597,23 +1600,26 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                 sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
                 {
                     // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
-                    const int wl = tid & 63, tpw = 64 / T, tw = wl / T, ln = wl - tw * T;
+                    // ... of the turns that can be reached at this level: the first `off` turns are dead (see sp_eval_team)
+                    const int off = min(cur_shanten - lv, T - 1), TW = T - off;
+                    const int wl = tid & 63, tpw = min(64 / TW, (SP_EVAL_LDS_FLOATS / (SP_THREADS / 64)) / sp_eval_lds_stride(T));  // lanes, LDS scratch
+                    const int tw = wl / TW, ln = wl - tw * TW;
                     const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
                     float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
                     const long long t_ev0 = P.prof ? wall_clock64() : 0;
                     if (tw < tpw && b + team < e) {
                         if (T <= 8) {
-                            if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln);
-                            else if (lv == 1) sp_eval_team<8, 1>(W, &X, lds, b + team, e, n_teams, ln);
-                            else sp_eval_team<8, 2>(W, &X, lds, b + team, e, n_teams, ln);
+                            if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else if (lv == 1) sp_eval_team<8, 1>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else sp_eval_team<8, 2>(W, &X, lds, b + team, e, n_teams, ln, off);
                         } else if (T <= 16) {
-                            if (lv == 0) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln);
-                            else if (lv == 1) sp_eval_team<16, 1>(W, &X, lds, b + team, e, n_teams, ln);
-                            else sp_eval_team<16, 2>(W, &X, lds, b + team, e, n_teams, ln);
+                            if (lv == 0) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else if (lv == 1) sp_eval_team<16, 1>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else sp_eval_team<16, 2>(W, &X, lds, b + team, e, n_teams, ln, off);
                         } else {
-                            if (lv == 0) sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln);
-                            else if (lv == 1) sp_eval_team<17, 1>(W, &X, lds, b + team, e, n_teams, ln);
-                            else sp_eval_team<17, 2>(W, &X, lds, b + team, e, n_teams, ln);
+                            if (lv == 0) sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else if (lv == 1) sp_eval_team<17, 1>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else sp_eval_team<17, 2>(W, &X, lds, b + team, e, n_teams, ln, off);
                         }
                     }
                     if (P.prof && (tid & 63) == 0) atomicAdd(&P.err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
