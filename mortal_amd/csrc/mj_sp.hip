@@ -40,6 +40,9 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #ifndef SP_NS
 #define SP_NS 16               // states per expansion chunk (one chunk per wavefront)
 #endif
+#ifndef SP_SORT_MIN
+#define SP_SORT_MIN 8            // levels up to this size are evaluated in list order (no cost sort)
+#endif
 #ifndef SP_ITEM_CAP
 #define SP_ITEM_CAP 64         // draw items (state, required tile) per sub-batch of a chunk: one lane each
 #endif
@@ -863,12 +866,25 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
                 for (int k = 0; k < 4; k++) v[q][k] = ok ? src[k] : 0.f;
             }
         } else {
+            // a tenpai state has 1.3 draw entries on average: only those are fetched (the count sits in the header already)
 #pragma unroll
             for (int q = 0; q < SP_CH; q++) {
-                cnt0[q] = node.l0cnt[q];
+                cnt0[q] = 1;
 #pragma unroll
-                for (int k = 0; k < 4; k++) v[q][k] = node.sc[q][k];
+                for (int k = 0; k < 4; k++) v[q][k] = 0.f;
+                if (q < n_ch) {
+                    cnt0[q] = node.l0cnt[q];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[q][k] = node.sc[q][k];
+                }
             }
+        }
+        // a state with more than SP_CH children: the second batch of its child list is requested now, next to the first batch's
+        // values, instead of after them (one dependent round trip less in the middle of the fold)
+        u32 ent2[SP_CH];
+        if constexpr (LK > 0) {
+#pragma unroll
+            for (int q = 0; q < SP_CH; q++) ent2[q] = n_ch > SP_CH ? Wg->pool[min((int)child_off + SP_CH + q, SP_POOL - 1)] : 0u;
         }
         // in flight behind them: the next state's child list and the header of the state after it
         SpEvalFetch nn;
@@ -938,9 +954,9 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
             float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
             int max_value = INT_MIN, max_key = sp_discard_key(T_UNK), buf = 0;
             for (int c0 = 0; c0 < n_ch; c0 += SP_CH) {
-                if (c0 > 0) {  // more than SP_CH children: fetch the next batch now (two dependent round trips)
+                if (c0 > 0) {  // more than SP_CH children: the second batch of entries is here already, later ones are fetched now
 #pragma unroll
-                    for (int q = 0; q < SP_CH; q++) cur.ent[q] = Wg->pool[min((int)child_off + c0 + q, SP_POOL - 1)];
+                    for (int q = 0; q < SP_CH; q++) cur.ent[q] = c0 == SP_CH ? ent2[q] : Wg->pool[min((int)child_off + c0 + q, SP_POOL - 1)];
 #pragma unroll
                     for (int q = 0; q < SP_CH; q++) {
                         const SP_HBM float* src = Wg->node[SP_ENT_SLOT(cur.ent[q])].val[ln];
@@ -992,8 +1008,8 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
 __device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] */, int b, int e) {
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int tid = threadIdx.x;
-    if (e - b <= 8) {  // a handful of states (the root level): one round of teams whatever the order
-        if (b + tid < e) Wg->elist[b + tid] = Wg->list[b + tid];
+    if (e - b <= SP_SORT_MIN) {  // a handful of states (the root level): one round of teams whatever the order
+        for (int i = b + tid; i < e; i += SP_THREADS) Wg->elist[i] = Wg->list[i];
         __syncthreads();
         return;
     }
