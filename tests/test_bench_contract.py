@@ -1,4 +1,4 @@
-"""The driver's bench.py contract, checked on the committed line of the last GPU run (profiles/r02_bench_v4.json) and on
+"""The driver's bench.py contract, checked on the committed line of the last GPU run (profiles/r03_bench_v4.json) and on
 bench.py's argument defaults — no GPU needed.  Guards against drift between the JSON the driver parses, BASELINE.json's
 metric, and the numbers quoted in DESIGN.md §7."""
 import json
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_v4.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_v4.json")) as f:
         return json.load(f)
 
 
@@ -33,14 +33,18 @@ def test_committed_bench_line_has_the_contract_keys_and_consistent_arithmetic():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2  # no wasted re-reads / rewrites
     s = d["roofline_sp"]
-    assert s["bound"] == "valu" and abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-6
+    assert s["bound"] == "valu" and s["from_static_profile"] is True and s["stale"] is False  # the PMC summary matches the kernel sources
+    assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-6 and s["peak"] < s["peak_f32_fma"]
     assert abs(s["achieved"] - s["valu_insts_per_state"] * s["states_per_launch"] / (s["avg_launch_ms"] * 1e-3) / 1e9) / s["achieved"] < 1e-3
+    assert s["static_profile"]["measured_at_tables"] == 65536 and "65536 tables" in r["traffic_source"]
     k = d["kernel_ms_per_step"]
     assert abs(sum(k.values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.02  # the per-kernel split covers the cycle
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
-    for w in ("obs_v3_random", "obs_v4_random_no_preroll", "obs_v4_greedy"):
+    for w in ("obs_v3_random", "obs_v4_random_no_preroll", "obs_v4_greedy", "brain_v4"):
         assert d["workloads"][w]["value"] > 0
+    assert d["workloads"]["brain_v4"]["env_share_of_cycle"] < 0.05  # BASELINE configs[2]: the net, not the environment, is the cycle
+    assert d["steps"] >= 100 and d["config"]["start_stagger"] is True
 
 
 def test_design_quotes_the_committed_numbers():
