@@ -17,6 +17,6 @@ cd /root/repo; python tools/summarize_profiles.py $OUT r03 65536 > $OUT/summariz
 cp profiles/r03_* profiles/pmc_encode.json $OUT/profiles/ 2>/dev/null
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
 cp $OUT/bench.json $OUT/profiles/r03_bench_v4.json
-timeout 300 python bench.py --gpus 2 --dist-backend gloo --tables 8192 --steps 10 --warmup 3 --preroll 256 --no-cpu-baseline --no-matrix > $OUT/profiles/r03_bench_gloo_2ranks_1gpu.json 2> $OUT/gloo.err; echo "gloo 2-rank rc=$?"; cut -c1-300 $OUT/profiles/r03_bench_gloo_2ranks_1gpu.json
+timeout 300 python bench.py --gpus 2 --dist-backend gloo --tables 8192 --steps 10 --warmup 3 --preroll 256 --no-cpu-baseline --no-matrix 2> $OUT/gloo.err | grep '^{' > $OUT/profiles/r03_bench_gloo_2ranks_1gpu.json; echo "gloo 2-rank rc=$?"; cut -c1-300 $OUT/profiles/r03_bench_gloo_2ranks_1gpu.json
 timeout 1500 python -m pytest tests -m gpu -q --durations=10 > $OUT/gputest.log 2>&1; echo "gputest rc=$?"; tail -4 $OUT/gputest.log
 rm -rf $OUT/pmc_write $OUT/pmc_fetch $OUT/v4_stats $OUT/v3_stats; du -sh $OUT
