@@ -473,8 +473,7 @@ int mj_step_ev(MjPool* P, const int32_t* a0, const int32_t* a1, const float* q0,
     sp.n_games_total = P->n_games_total;
     sp.block_rows = P->block_rows;
     if (sp.refill) hipLaunchKernelGGL(mj_k_refill, dim3(P->n_blocks), dim3(64), 0, s, sp);
-    if (STEP_SPLIT > 1) HIP_OK(hipMemsetAsync(P->block_rows, 0, (size_t)P->n_blocks * 2 * sizeof(int), s));
-    hipLaunchKernelGGL(mj_k_step, dim3(P->n_blocks * STEP_SPLIT), dim3(STEP_LANES), 0, s, sp);
+    hipLaunchKernelGGL(mj_k_step, dim3(P->n_blocks), dim3(MJ_LANES), 0, s, sp);
     return launch_rows(P, s);
 }
 static int launch_rows(MjPool* P, hipStream_t s) {

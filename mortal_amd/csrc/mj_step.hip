@@ -652,18 +652,15 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
     }
 }
 
-// One wavefront serves 64 / STEP_SPLIT tables of a pool block.  A wavefront executes the union of its lanes' paths (deal, draw,
-// call, win, ...); narrower wavefronts were measured (-DSTEP_SPLIT=2 / 4: 2.604 / 2.735 ms per v3 cycle against 2.596): a
-// wavefront of 32 or 16 tables still walks nearly every path, so the split only multiplies the instructions issued.
-#ifndef STEP_SPLIT
-#define STEP_SPLIT 1
-#endif
-#define STEP_LANES (MJ_LANES / STEP_SPLIT)
+// One wavefront serves the 64 tables of a pool block.  A wavefront executes the union of its lanes' paths (deal, draw, call,
+// win, ...); narrower wavefronts were measured in round 2 (32 / 16 tables per wavefront: 2.604 / 2.735 ms per v3 cycle against
+// 2.596 — a wavefront of 16 tables still walks nearly every path, the split only multiplies the instructions issued) and the
+// knob was removed.
 __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
     __shared__ DealScratch s_deal;
-    const int blk = blockIdx.x / STEP_SPLIT, lane0 = (blockIdx.x % STEP_SPLIT) * STEP_LANES;
-    const int table = blk * 64 + lane0 + threadIdx.x;
-    Lane L = {MJ_POOL_PTR(P.blocks + blk), lane0 + (int)threadIdx.x, &c_mj_tables};
+    const int blk = blockIdx.x;
+    const int table = blk * 64 + threadIdx.x;
+    Lane L = {MJ_POOL_PTR(P.blocks + blk), (int)threadIdx.x, &c_mj_tables};
     L.deal = &s_deal;
     if (P.log && table < P.n_tables) {
         L.log = P.log + (size_t)table * P.log_cap;
@@ -795,20 +792,15 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
     unsigned long long live_mask = __ballot(live_after);
     int dec_sum = n_dec, quick_sum = n_quick;
     int rows0 = F1(n_rows, 0), rows1 = F1(n_rows, 1);
-    for (int off = STEP_LANES / 2; off > 0; off >>= 1) {
+    for (int off = MJ_LANES / 2; off > 0; off >>= 1) {
         dec_sum += __shfl_down(dec_sum, off);
         quick_sum += __shfl_down(quick_sum, off);
         rows0 += __shfl_down(rows0, off);
         rows1 += __shfl_down(rows1, off);
     }
     if (threadIdx.x == 0) {
-        if (STEP_SPLIT == 1) {
-            P.block_rows[2 * blk] = rows0;
-            P.block_rows[2 * blk + 1] = rows1;
-        } else {  // the block's sums come from STEP_SPLIT wavefronts (block_rows is zeroed before the launch)
-            if (rows0) atomicAdd(&P.block_rows[2 * blk], rows0);
-            if (rows1) atomicAdd(&P.block_rows[2 * blk + 1], rows1);
-        }
+        P.block_rows[2 * blk] = rows0;
+        P.block_rows[2 * blk + 1] = rows1;
         if (live_mask) atomicAdd(&P.counters[0], (unsigned long long)__popcll(live_mask));
         if (dec_sum) atomicAdd(&P.counters[3], (unsigned long long)dec_sum);
         if (quick_sum) atomicAdd(&P.counters[4], (unsigned long long)quick_sum);
