@@ -720,47 +720,101 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         mj_team_sync<SP_NT>();
         if (prof) tp3 = wall_clock64();
         // P4: children, one lane per CHILD ENTRY (draw variant x kept discard): it inserts its child state into the hash set and
-        // leaves its child-list entry at its place of the reference's order (t, variant, d ascending).
-        for (int e0 = 0; e0 < n_entries; e0 += SP_NT) {
-            const int e = e0 + tid;
-            if (e < n_entries) {
-                int lo = 0, hi = n_items;  // largest item with eoff[item] <= e
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if ((int)C->eoff[mid] <= e) lo = mid; else hi = mid;
-                }
-                const int it = lo, local = e - (int)C->eoff[it];
-                const u64 bits = C->kept[it];
-                const int nk = __popcll(bits), vidx = local >= nk ? 1 : 0, rank = local - vidx * nk;
-                u64 mrest = bits;
-                for (int r = rank; r > 0; r--) mrest &= mrest - 1;
-                const int d = __ffsll((long long)mrest) - 1;
-                const int s = C->item[it] & (SP_NS - 1), t = C->item[it] >> SP_SB;
-                const SpState Sx = sp_chunk_state(C, s);
-                const int cnt = Sx.w.get(t);
-                const bool aka = sp_aka_in_wall(Sx, t);
-                // the tile's draw entries: plain (all copies but the red one) if any, then the red five
-                const bool red = aka && (vidx == 1 || cnt < 2);
-                const int count = !aka ? cnt : red ? 1 : cnt - 1;
-                const int tile = red ? akaize(t) : t;
-                const u32 akas1 = red ? (Sx.akas | (1u << (tile - T_5MR))) : Sx.akas;  // akas_in_hand after the draw
-                const int c = Sx.h.get(d);  // d != t: the draw does not change its count
-                int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
-                if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
-                else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
-                else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
-                bool fresh;
-                const int cs = sp_insert(Wg, X, sp_dk_add(C->dk[s], tile, dt), Sx, tile, dt, fresh);
-                if (fresh && cs >= 0) {
-                    const int idx = atomicAdd(&X->n_list, 1);
-                    if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
-                    else X->overflow = 1;
-                }
-                const int pos = C->child_base[s] + (int)C->coff[it] + local;
-                const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(dt) << 14) | (rank == nk - 1 ? SP_ENT_LAST : 0u) |
-                                ((u32)count << 24);
-                if (pos < SP_POOL) Wg->pool[pos] = ent;
+        // leaves its child-list entry at its place of the reference's order (t, variant, d ascending).  A lane takes TWO entries
+        // per round and claims both hash slots before it looks at either answer: an insert is one L2 atomic round trip of
+        // latency and little else, so two in flight per lane halve the rounds.
+        struct Ent {  // one child entry, decoded
+            bool on;
+            int s, it, local, rank, nk, tile, dt, count;
+            u64 dk;
+            u32 pos;
+        };
+        auto decode = [&](int e) -> Ent {
+            Ent E;
+            E.on = e < n_entries;
+            const int ee = E.on ? e : 0;
+            int lo = 0, hi = n_items;  // largest item with eoff[item] <= e
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((int)C->eoff[mid] <= ee) lo = mid; else hi = mid;
             }
+            E.it = lo;
+            E.local = ee - (int)C->eoff[lo];
+            const u64 bits = C->kept[lo];
+            E.nk = __popcll(bits);
+            const int vidx = E.local >= E.nk ? 1 : 0;
+            E.rank = E.local - vidx * E.nk;
+            u64 mrest = bits;
+            for (int r = E.rank; r > 0; r--) mrest &= mrest - 1;
+            const int d = __ffsll((long long)mrest) - 1;
+            E.s = C->item[lo] & (SP_NS - 1);
+            const int t = C->item[lo] >> SP_SB;
+            const SpState Sx = sp_chunk_state(C, E.s);
+            const int cnt = Sx.w.get(t);
+            const bool aka = sp_aka_in_wall(Sx, t);
+            // the tile's draw entries: plain (all copies but the red one) if any, then the red five
+            const bool red = aka && (vidx == 1 || cnt < 2);
+            E.count = !aka ? cnt : red ? 1 : cnt - 1;
+            E.tile = red ? akaize(t) : t;
+            const u32 akas1 = red ? (Sx.akas | (1u << (E.tile - T_5MR))) : Sx.akas;  // akas_in_hand after the draw
+            const int c = Sx.h.get(d & 63);  // d != t: the draw does not change its count
+            int dt = d;  // aka variant rule (state.rs:116-121): the red five goes last
+            if (d == T_5M && (akas1 & 1) && c == 1) dt = T_5MR;
+            else if (d == T_5P && (akas1 & 2) && c == 1) dt = T_5PR;
+            else if (d == T_5S && (akas1 & 4) && c == 1) dt = T_5SR;
+            E.dt = dt;
+            E.dk = sp_dk_add(C->dk[E.s], E.tile, dt);
+            E.pos = sp_dk_pos(E.dk);
+            return E;
+        };
+        auto finish = [&](const Ent& E, u64 first_old) {  // the rest of sp_insert after the first claim, the list and the child entry
+            const u64 tag = SP_TAG(E.dk);
+            const SpState Sx = sp_chunk_state(C, E.s);
+            u32 pos = E.pos;
+            u64 old = first_old;
+            int cs = -1;
+            bool fresh = false;
+            for (int probe = 0; probe < SP_CAP; probe++) {
+                if (old == 0ull) {
+                    u64 k[4];
+                    sp_key(sp_apply(Sx, E.tile, E.dt), k);
+                    auto& nd = Wg->node[pos];
+                    nd.k0 = k[0]; nd.k1 = k[1]; nd.k2 = k[2]; nd.k3 = k[3];
+                    fresh = true;
+                    cs = (int)pos;
+                    break;
+                }
+                if (old == tag) {
+#ifdef MJ_EMU  // the emulator never pre-empts between the claim and the key write: check the bijection on every hit
+                    u64 k[4];
+                    sp_key(sp_apply(Sx, E.tile, E.dt), k);
+                    auto& nd = Wg->node[pos];
+                    if (nd.k0 != k[0] || nd.k1 != k[1] || nd.k2 != k[2] || nd.k3 != k[3]) X->overflow = 1;
+#endif
+                    cs = (int)pos;
+                    break;
+                }
+                pos = (pos + 1) & (SP_CAP - 1);
+                old = sp_claim_tag(&Wg->tag[pos], tag);
+            }
+            if (cs < 0) X->overflow = 1;
+            if (fresh) {
+                const int idx = atomicAdd(&X->n_list, 1);
+                if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
+                else X->overflow = 1;
+            }
+            const int pos_out = C->child_base[E.s] + (int)C->coff[E.it] + E.local;
+            const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(E.dt) << 14) | (E.rank == E.nk - 1 ? SP_ENT_LAST : 0u) |
+                            ((u32)E.count << 24);
+            if (pos_out < SP_POOL) Wg->pool[pos_out] = ent;
+        };
+        for (int e0 = 0; e0 < n_entries; e0 += 2 * SP_NT) {
+            const Ent A = decode(e0 + tid), B = decode(e0 + SP_NT + tid);
+            u64 oa = 1ull, ob = 1ull;
+            if (A.on) oa = sp_claim_tag(&Wg->tag[A.pos], SP_TAG(A.dk));
+            if (B.on) ob = sp_claim_tag(&Wg->tag[B.pos], SP_TAG(B.dk));
+            if (A.on) finish(A, oa);
+            if (B.on) finish(B, ob);
         }
         mj_team_sync<SP_NT>();
         if (prof) {
