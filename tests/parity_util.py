@@ -1,5 +1,8 @@
 """Lock-step comparison of the HIP table pool with the oracle arena on identical seeds and action streams."""
 import numpy as np
+import torch
+
+from mortal_amd.pool import OBS_ROWS
 
 KEY = 0xD5DFAA4CEF265CD7
 
@@ -155,7 +158,12 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         n = len(rows_o)
         if n == 0 and arena.n_live == 0:
             break
-        obs_g, masks_g = pool.encode(0)
+        # buffers poisoned before the encode: every cell of the observation has to be WRITTEN by a kernel (the encoder owns rows
+        # 0..888 of obs v4 and mj_k_sp the rest), nothing may rely on what the allocator handed out
+        n_g = pool.n_rows[0]
+        obs_g = torch.full((n_g, OBS_ROWS[pool.versions[0]], 34), float("nan"), dtype=torch.float32, device=pool.device)
+        masks_g = torch.ones((n_g, 46), dtype=torch.bool, device=pool.device)
+        obs_g, masks_g = pool.encode(0, obs_g, masks_g)
         want_obs = compare_obs and ((cycle in obs_cycles) if obs_cycles is not None else (cycle % obs_every == 0))
         obs_o, masks_o = arena.encode(0, n, want_obs=want_obs, threads=threads)
         mg = masks_g.cpu().numpy().astype(np.uint8)
