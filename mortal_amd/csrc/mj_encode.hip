@@ -344,6 +344,34 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         }
     }
 
+    // ---- 2d. RBF rows of the integer features (obs v2 / v3, obs_repr.rs:79-90): their LUT values do not depend on the pass
+    // either — fetched once here instead of as a chain of dependent loads inside every pass (lanes 34..37: nine per score)
+    float rbf_v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (V == 2 || V == 3) {
+        const float* src = nullptr;
+        int cnt = 0;
+        if (tid >= 34 && tid < 38) {
+            const unsigned long long q = (unsigned long long)(long long)F1(scores, (p + tid - 34) & 3) / 100ull;  // `score as usize / 100`
+            src = P.rbf_score + (size_t)(q > 4095ull ? 4095u : (u32)q) * 9;
+            cnt = 9;
+        } else if (tid >= 40 && tid < 44) {
+            src = P.rbf_12 + (size_t)D->owned[tid - 40] * 2;
+            cnt = 2;
+        } else if (tid == 44) {
+            src = P.rbf_23 + (size_t)((F(n_dora_ind) * 4 + 3 - D->doras_seen) & 0xFF) * 3;
+            cnt = 3;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            if (k < cnt) rbf_v[k] = src[k];
+        if (tid == 38) {
+            rbf_v[0] = P.rbf_6[F(honba) * 2];
+            rbf_v[1] = P.rbf_6[F(honba) * 2 + 1];
+            rbf_v[2] = P.rbf_6[F(kyotaku) * 2];
+            rbf_v[3] = P.rbf_6[F(kyotaku) * 2 + 1];
+        }
+    }
+
     // ---- 3. passes
     float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)row * (C * 34));
     for (int pass = 0; pass < ENC_PASSES; pass++) {
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
             if (r >= r0 && r < r1) D->rowfill[r - r0] = v;
         };
         // obs_repr.rs:59-107 for one integer feature at row base `b`
-        auto int_encode = [&](int b, u32 n_in, int cap, bool rescale, int rbf, const float* lut) {
+        auto int_encode = [&](int b, u32 n_in, int cap, bool rescale, int rbf, int v0) {  // RBF values: rbf_v[v0 ..] (section 2d)
             int n = (int)min(n_in, (u32)cap);
             if (V == 1) {
                 for (int k = 0; k < n; k++) fillr(b + k, 1.f);
@@ -379,8 +407,11 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                 fillr(b, (float)n / (float)cap);
                 b += 1;
             }
-            if (V != 4 && rbf)
-                for (int i = 1; i < rbf; i++) fillr(b + i - 1, lut[i - 1]);
+            if (V != 4 && rbf) {
+#pragma unroll
+                for (int i = 1; i < 10; i++)
+                    if (i < rbf) fillr(b + i - 1, rbf_v[v0 + i - 1]);
+            }
         };
 
         if (tid < 34) {
@@ -407,7 +438,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
             if (V == 2 || V == 3) {
                 unsigned long long q = (unsigned long long)(long long)s / 100ull;  // `score as usize / 100`
                 u32 n = q > 4095ull ? 4095u : (u32)q;
-                int_encode(b + 1, n, 500, false, 10, P.rbf_score + (size_t)n * 9);
+                int_encode(b + 1, n, 500, false, 10, 0);
             } else if (V == 4) {
                 fillr(b + 1, (float)min(max(s, 0), 30000) / 30000.f);
             }
@@ -423,12 +454,12 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                 fillr(O::kyoku + kw, 1.f);
             }
             const int cap = (V == 1 || V == 4) ? 10 : 6;
-            int_encode(O::honba, F(honba), cap, V == 4, 3, P.rbf_6 + (size_t)F(honba) * 2);
-            int_encode(O::kyotaku, F(kyotaku), cap, V == 4, 3, P.rbf_6 + (size_t)F(kyotaku) * 2);
+            int_encode(O::honba, F(honba), cap, V == 4, 3, 0);
+            int_encode(O::kyotaku, F(kyotaku), cap, V == 4, 3, 2);
             const int bakaze = table_bakaze(L);
             put(O::kaze, bakaze, 1.f);
             put(O::kaze + 1, seat_jikaze(L, p), 1.f);
-            if (V >= 2) int_encode(O::kig, min(bakaze - T_E, 1) * 4 + kw, 7, true, 0, nullptr);
+            if (V >= 2) int_encode(O::kig, min(bakaze - T_E, 1) * 4 + kw, 7, true, 0, 0);
         } else if (tid == 39) {
             // dora indicators tile set (obs_repr.rs:694-712) + tiles_left
             const int n = F(n_dora_ind);
@@ -442,10 +473,10 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         } else if (tid < 44) {
             const int r = tid - 40;
             const int ow = D->owned[r];
-            int_encode(O::doras_owned + r * O::owned_stride, (u32)ow, 12, true, 3, P.rbf_12 + (size_t)ow * 2);
+            int_encode(O::doras_owned + r * O::owned_stride, (u32)ow, 12, true, 3, 0);
         } else if (tid == 44) {
             const u32 unseen = (u32)((F(n_dora_ind) * 4 + 3 - D->doras_seen) & 0xFF);
-            int_encode(O::doras_unseen, unseen, 23, true, 4, P.rbf_23 + (size_t)unseen * 3);
+            int_encode(O::doras_unseen, unseen, 23, true, 4, 0);
         } else if (tid == 45) {
             for (int r = 1; r < 4; r++) {
                 if (declared(L, (p + r) & 3)) fillr(O::riichi_flags + r - 1, 1.f);
