@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 GPU call: PMC passes (mj_k_sp instruction counts, mj_k_encode HBM bytes at the bench's own 65,536 tables) -> their
 # summaries under profiles/ of the box's copy, THEN the whole -m gpu suite, the default bench line (which reads those summaries),
-# rocprofv3 kernel stats of the v4 / v3 bench, the issue-rate microbenchmark and the 2-rank gloo smoke run of bench.py --gpus 2.
+# rocprofv3 kernel stats of the v4 / v3 bench, the issue-rate microbenchmark, the 2-rank gloo smoke run of bench.py --gpus 2 and __graft_entry__.smoke().
 # Output: gpurun_out/$1/ (profiles/ sub-directory = the files to commit).
 TAG=${1:-r03}; OUT=/root/repo/gpurun_out/$TAG; mkdir -p $OUT/profiles; cd /root/repo
 /root/repo/tools/bin/ubench_valu > $OUT/profiles/r03_ubench_valu.jsonl 2> $OUT/ubench.err; echo "ubench rc=$?"
@@ -18,5 +18,6 @@ cp profiles/r03_* profiles/pmc_encode.json $OUT/profiles/ 2>/dev/null
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
 cp $OUT/bench.json $OUT/profiles/r03_bench_v4.json
 timeout 300 python bench.py --gpus 2 --dist-backend gloo --tables 8192 --steps 10 --warmup 3 --preroll 256 --no-cpu-baseline --no-matrix 2> $OUT/gloo.err | grep '^{' > $OUT/profiles/r03_bench_gloo_2ranks_1gpu.json; echo "gloo 2-rank rc=$?"; cut -c1-300 $OUT/profiles/r03_bench_gloo_2ranks_1gpu.json
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q --durations=10 > $OUT/gputest.log 2>&1; echo "gputest rc=$?"; tail -4 $OUT/gputest.log
 rm -rf $OUT/pmc_write $OUT/pmc_fetch $OUT/v4_stats $OUT/v3_stats; du -sh $OUT
