@@ -252,6 +252,12 @@ int mj_tables_upload(const void* payload, size_t size) {
         if (upload(H.id, &d_id) || upload(H.mrg, &d_m) || upload(H.opt, &d_o) || upload(H.wk, &d_wk)) return -1;
         SpTabDev st{d_id, d_m, d_o, d_wk, ns, nj, H.zero_id};
         HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_sp_tab), &st, sizeof(SpTabDev)));
+        std::vector<float> nt((size_t)SP_NT_ROWS * SP_NT_ROWS * SP_NT_STRIDE);  // not_tsumo rows of every wall size (mj_sp.hip)
+        sp_not_tsumo_build(nt.data());
+        float* d_nt;
+        if (upload(nt, &d_nt)) return -1;
+        const float* d_ntc = d_nt;
+        HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_sp_nt), &d_ntc, sizeof d_ntc));
     }
     auto g = build_gather();
     g_tables.n_gather = (int)g.size();

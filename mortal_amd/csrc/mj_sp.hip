@@ -80,8 +80,31 @@ struct SpWork {                // per-workgroup scratch in HBM (persistent workg
     u32 elist[SP_CAP];         // the same ranges ordered by child-list length for the evaluation (sp_sort_level)
     u32 pool[SP_POOL];         // child lists
     u32 items[SP_ITEMS];       // level 0: (state, winning tile, variant) work items of the dense scoring pass
-    float not_tsumo[124][SP_T + 3];  // MAX_TILES_LEFT + 1 = 123 rows (calc.rs:14,148-167); row = sum of required tiles (80-byte rows)
 };
+
+// build_not_tsumo_prob_table (calc.rs:148-167) for EVERY wall size, built once on the host and shared by all workgroups:
+// row [n_left][q] = P(no tile out of q useful ones on turns 0 .. j-1 | n_left tiles unseen), the running product
+// cur * (n_left - q - j) / (n_left - j) in f32 exactly as the reference rounds it (x86 mulss / divss == the device's IEEE
+// multiply / divide).  The reference's per-decision table only adds a cut-off at its number of draws T, and nobody reads a
+// row past turn T - 1.  Round 3 built the 124 rows per decision into the workgroup's HBM area: 11.6 us per row of the queue.
+#define SP_NT_ROWS 124           // MAX_TILES_LEFT + 1 = 123 rows (calc.rs:14) + one all-zero row for sums past that
+#define SP_NT_STRIDE (SP_T + 3)  // 80-byte rows
+__constant__ const float* c_sp_nt;  // [SP_NT_ROWS wall sizes][SP_NT_ROWS][SP_NT_STRIDE]
+static inline void sp_not_tsumo_build(float* out /* [SP_NT_ROWS * SP_NT_ROWS * SP_NT_STRIDE] */) {
+    for (int n_left = 0; n_left < SP_NT_ROWS; n_left++)
+        for (int q = 0; q < SP_NT_ROWS; q++) {
+            float* r = out + ((size_t)n_left * SP_NT_ROWS + q) * SP_NT_STRIDE;
+            const bool row_on = q <= 122 && q < n_left + 1;
+            const int lim = n_left - q;
+            float cur = row_on ? 1.f : 0.f;
+            for (int j = 0; j < SP_NT_STRIDE; j++) r[j] = 0.f;
+            r[0] = cur;
+            for (int j = 0; j < SP_T - 1; j++) {
+                cur = (row_on && j < lim) ? cur * (float)(n_left - q - j) / (float)(n_left - j) : 0.f;
+                r[j + 1] = cur;
+            }
+        }
+}
 
 struct SpParams {
     const TableOne* snap;
@@ -166,6 +189,7 @@ struct SpCtx {  // per-decision constants (LDS)
     int n_cand;
     int cand_tile[SP_MAX_CAND], cand_slot[SP_MAX_CAND], cand_down[SP_MAX_CAND], cand_nreq[SP_MAX_CAND];
     u64 cand_req[SP_MAX_CAND];
+    u64 spec_req[2][34];  // row set-up: required draws of root - d for every held kind d, [1] = one shanten number up (4+ shanten roots)
     int order[SP_MAX_CAND];
     float cand_tp0[SP_MAX_CAND], cand_wp0[SP_MAX_CAND], cand_ev0[SP_MAX_CAND];
 };
@@ -866,7 +890,7 @@ struct SpEvalFetch {  // what is prefetched per state
     u32 slot;
     u64 hdr;              // child_off | n_ch << 32 | sumreq << 48
     u32 ent[SP_CH];       // level > 0: first SP_CH child-list entries
-    float m;              // not_tsumo_probs[turn of this lane] of the state's required-tile sum (a row of the HBM table)
+    float m;              // not_tsumo_probs[turn of this lane] of the state's required-tile sum (a row of the shared table c_sp_nt)
 };
 template <int TN, int LK>
 __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int first, int end, int stride, int lane_in_team, int off) {
@@ -884,6 +908,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
     const bool haitei = X->calc_haitei != 0;
     const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
 
+    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)min(X->n_left, SP_NT_ROWS - 1) * (SP_NT_ROWS * SP_NT_STRIDE);  // this wall size
     auto fetch_slot = [&](int i) -> u32 { return Wg->elist[min(i, end - 1)]; };
     auto fetch_hdr = [&](u32 slot) -> u64 {
         // one 8-byte load (level 0: past the L1 — the yaku bits were set by L2 atomics of the scoring pass)
@@ -891,7 +916,7 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
         return LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto fetch_ent = [&](SpEvalFetch& f) {  // what the header addresses: the child list and the not_tsumo row
-        f.m = Wg->not_tsumo[min((int)((f.hdr >> 48) & 0xFF), 123)][ln];
+        f.m = nt_rows[min((int)((f.hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln];
         if constexpr (LK > 0) {
 #pragma unroll
             for (int q = 0; q < SP_CH; q++) f.ent[q] = Wg->pool[min((int)(u32)f.hdr + q, SP_POOL - 1)];
@@ -1282,18 +1307,30 @@ __device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork
             if (is_aka(last_tsumo)) akas_hand &= ~(1 << (last_tsumo - T_5MR));
             can_discard = false;
         }
+        int n_left_all = 0;
         {
             Hand w = {0, 0};
             for (int t = 0; t < 34; t++) {
                 int seen = F1(pub_seen, t) + h0.get(t);  // tiles_seen = public + own hand (incl. the tile just drawn)
                 int left = (4 - seen) & 7;
                 for (int k = 0; k < left; k++) w.inc(t);
+                n_left_all += left;
             }
             root.w = w;
             int akas_seen = (F(pub_aka_seen) | F1(akas_in_hand, p)) & 7;
             root.akas = (u32)akas_hand | ((u32)(~akas_seen & 7) << 3);
         }
-        if (tid == 0) {
+        const int T = tsumos_left, n_left = n_left_all & 0xFF;
+        // fewer draws left than the shanten number: tenpai / win / EV are exactly zero for every candidate (reaching tenpai
+        // takes cur_shanten draws), so neither the probability table nor the state graph are needed at all
+        const bool with_probs = cur_shanten <= 3 && T >= cur_shanten;
+        // Three independent chains of dependent table walks / LDS reads run SIDE BY SIDE on three wavefronts of the workgroup
+        // (one after the other they were 6 + 10 + 10 us of a row's set-up, with 255 threads waiting at the barriers in between):
+        //   lane CTX   : the calculator's constants;
+        //   lane 0     : the discards that keep the shanten number -> the candidate list;
+        //   lanes SPEC : the required draws of root - d for EVERY held kind d, before it is known which d are candidates.
+        constexpr int CTX = (!WAVE && NT > 128) ? 128 : 0, SPEC = (!WAVE && NT > 64) ? 64 : 0;
+        if (tid == CTX) {
             X.melds = load_melds(L, p);
             X.len_div3 = ld3;
             X.bakaze = table_bakaze(L);
@@ -1320,49 +1357,39 @@ __device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork
             X.prefer_riichi = F1(scores, p) >= 1000;
             X.calc_double_riichi = can_discard0 && (F1(pflags, p) & PF_CAN_W_RIICHI) != 0;
             X.calc_haitei = calc_haitei;
-            X.T = tsumos_left;
-            int n_left = 0;
-            for (int t = 0; t < 34; t++) n_left += root.w.get(t);
-            X.n_left = n_left & 0xFF;
+            X.T = T;
+            X.n_left = n_left;
             X.n_list = 0;
             X.n_pool = 0;
             X.overflow = 0;
             X.prof = prof;
             for (int k = 0; k < 8; k++) X.pt[k] = 0;
-            X.n_cand = 0;
             for (int l = 0; l < 5; l++) X.lvl_begin[l] = X.lvl_end[l] = 0;
         }
-        sp_sync<WAVE>();
-        const int T = X.T, n_left = X.n_left;
-        // fewer draws left than the shanten number: tenpai / win / EV are exactly zero for every candidate (reaching tenpai
-        // takes cur_shanten draws), so neither the probability tables nor the state graph are needed at all
-        const bool with_probs = cur_shanten <= 3 && T >= cur_shanten;
-        if (with_probs) {
-            // build_tsumo_prob_table / build_not_tsumo_prob_table (calc.rs:135-167)
+        if (with_probs) {  // build_tsumo_prob_table (calc.rs:135-146); the not_tsumo rows come from the shared table c_sp_nt
             for (int q = tid; q < 4 * SP_T; q += NT) {
                 int i = q / SP_T, j = q % SP_T;
                 X.tsumo_prob[i][j] = j < T ? (float)(i + 1) / (float)(n_left - j) : 0.f;
             }
-            // the not_tsumo rows live in the wavefront's HBM work area (read once per evaluated state); only rows up to the wall size
-            // can be addressed by a required-tile sum
-            for (int q = tid; q < 124; q += NT) {
-                SP_HBM float* r = ((SP_HBM SpWork*)W)->not_tsumo[q];
-                const bool row_on = q <= 122 && q < n_left + 1;
-                const int lim = min(T - 1, n_left - q);
-                float cur = row_on ? 1.f : 0.f;
-                r[0] = cur;
-                for (int j = 0; j < SP_T - 1; j++) {
-                    cur = (row_on && j < lim) ? cur * (float)(n_left - q - j) / (float)(n_left - j) : 0.f;
-                    r[j + 1] = cur;
-                }
-            }
-            sp_sync<WAVE>();
         }
 
         // ---- candidates: analyze_discard / analyze_draw (+ *_simple for shanten > 3)  (calc.rs:205-312), from the table-id
-        // sets of mj_sptab.h: the discards of the root hand that keep its shanten number, then one lane per candidate for the
-        // draws that lower the shanten number of root - d.
+        // sets of mj_sptab.h: the discards of the root hand that keep its shanten number, and the draws that lower the shanten
+        // number of root - d (state.rs:176-200)
         const SpTabG TG = sp_tab_g(c_sp_tab);
+        if (tid >= SPEC && tid < SPEC + 34) {
+            const int d = tid - SPEC;
+            if (can_discard) {
+                if (root.h.get(d)) {
+                    Hand hc = root.h;
+                    hc.dec(d);
+                    X.spec_req[0][d] = sp_req_of_hand(TG, c_mj_tables, hc, ld3, cur_shanten);  // d keeps the shanten number
+                    if (cur_shanten > 3) X.spec_req[1][d] = sp_req_of_hand(TG, c_mj_tables, hc, ld3, cur_shanten + 1);  // d gives one up
+                }
+            } else if (d == 0) {
+                X.spec_req[0][0] = sp_req_of_hand(TG, c_mj_tables, root.h, ld3, calc_all(c_mj_tables, root.h, ld3));
+            }
+        }
         if (tid == 0) {
             int n = 0;
             if (can_discard) {
@@ -1389,17 +1416,9 @@ __device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork
         }
         sp_sync<WAVE>();
         const int n_cand = X.n_cand;
-        // required tiles of every candidate (state.rs:176-200): draws t that lower the shanten number of root - d (+ t)
         if (tid < n_cand) {
-            Hand hc = root.h;
-            int base;
-            if (can_discard) {
-                hc.dec(deaka(X.cand_tile[tid]));
-                base = cur_shanten + X.cand_down[tid];
-            } else {
-                base = calc_all(c_mj_tables, root.h, ld3);
-            }
-            const u64 req = sp_req_of_hand(TG, c_mj_tables, hc, ld3, base) & root.w.nonzero_mask();  // the discard does not change the wall
+            const u64 spec = can_discard ? X.spec_req[X.cand_down[tid]][deaka(X.cand_tile[tid])] : X.spec_req[0][0];
+            const u64 req = spec & root.w.nonzero_mask();  // the discard does not change the wall
             int nreq = 0;
             for (u64 rest = req; rest; rest &= rest - 1) nreq += root.w.get(__ffsll((long long)rest) - 1);
             X.cand_req[tid] = req;
