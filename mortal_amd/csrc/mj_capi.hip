@@ -3,6 +3,7 @@
 // Host float math below builds bit-exact LUTs: compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -666,6 +667,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         if (!P->sp_work) {
             P->sp_grid = 256 * SP_WGS;  // persistent workgroups: SP_WGS per CU, one decision row each at a time
             if (P->sp_grid > P->max_rows) P->sp_grid = P->max_rows;  // never more rows than that in a launch (small pools: small work area)
+            if (const char* g = getenv("MJ_SP_GRID")) P->sp_grid = std::max(1, std::min(P->sp_grid, atoi(g)));  // tests: few workgroups, many rows each (the row-to-row paths)
             HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
             for (int g = 0; g < P->sp_grid; g++) HIP_OK(hipMemsetAsync(P->sp_work[g].tag, 0, sizeof(P->sp_work[g].tag), s));  // empty hash sets
             HIP_OK(hipMalloc(&P->sp_queue, 17 * sizeof(int)));

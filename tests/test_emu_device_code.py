@@ -42,6 +42,16 @@ def test_emu_lockstep_v4_sp_rows_greedy(oracle, emu):
     assert st["obs_checked"] > 300 and st["counters"]["sp_overflow"] == 0
 
 
+def test_emu_lockstep_v4_one_workgroup_takes_every_row(oracle, emu, monkeypatch):
+    """MJ_SP_GRID=1: a single persistent workgroup pops the whole row queue, so every row but the first starts from the state
+    the previous one left behind (hash tags cleared, level bookkeeping, the queue tail handed to the wavefronts) — with the
+    default grid the small test pools give each workgroup exactly one row and never exercise that."""
+    monkeypatch.setenv("MJ_SP_GRID", "1")
+    st = parity_util.run_lockstep(oracle, 4, version=4, max_cycles=60, obs_every=1, pool_cls=emu, sp_rows_checked=True,
+                                  policy="greedy", verbose=False)
+    assert st["obs_checked"] > 200 and st["counters"]["sp_overflow"] == 0
+
+
 def test_emu_lockstep_older_obs_versions_and_guard(oracle, emu):
     for version in (1, 2):
         st = parity_util.run_lockstep(oracle, 2, version=version, max_cycles=150, obs_every=1, pool_cls=emu, policy="greedy",
