@@ -339,6 +339,21 @@ def test_oracle_sp_riichi_open_hands_and_roots_against_exact_recursion(oracle, c
             want[tile] = X.draw(tuple(h), tuple(ah), tuple(wall), akas_wall, L)
         assert sorted(x["tile"] for x in got) == sorted(want)
         pairs = [(x, want[x["tile"]]) for x in got]
+        # the sorted form (calc.rs:181-188, Candidate::cmp candidate.rs:73-106): same candidates, turn-0 EV descending, then win
+        # probability, then tenpai probability — checked wherever the exact values are clearly apart
+        srt = oracle.sp_calc(hand.astype(np.uint8), seen.astype(np.uint8), len_div3=ld3, is_menzen=is_menzen, jikaze=c["jikaze"],
+                             bakaze=c["bakaze"], tsumos_left=T, cur_shanten=L, can_discard=True, prefer_riichi=riichi,
+                             calc_double_riichi=c["double_riichi"] and riichi, calc_haitei=c["haitei"], dora_indicators=c["inds"],
+                             akas_in_hand=akas_hand, akas_seen=akas_seen, num_doras_in_fuuro=c["fuuro_doras"], sort_result=True,
+                             **c["melds"])
+        assert sorted(x["tile"] for x in srt) == sorted(want)
+        key = lambda t: (float(want[t][2][0]), float(want[t][1][0]), 1.0 if L == 0 else float(want[t][0][0]))
+        for a_, b_ in zip(srt, srt[1:]):
+            ka, kb = key(a_["tile"]), key(b_["tile"])
+            for x, y in zip(ka, kb):
+                if abs(x - y) > 1e-4 * max(1.0, abs(x)):
+                    assert x > y, (a_["tile"], b_["tile"], ka, kb)
+                    break
     else:
         assert len(got) == 1
         pairs = [(got[0], X.draw(h0, akas_hand, tuple(wall), akas_wall, L))]
