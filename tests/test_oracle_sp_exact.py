@@ -364,3 +364,51 @@ def test_oracle_sp_riichi_open_hands_and_roots_against_exact_recursion(oracle, c
             assert abs(float(cand["win_probs"][i]) - float(win[i])) <= 2e-5 * max(1.0, float(win[i])), (i, cand["win_probs"][i], float(win[i]))
             assert abs(float(cand["exp_values"][i]) - float(ev[i])) <= 3e-5 * max(1.0, float(ev[i])), (i, cand["exp_values"][i], float(ev[i]))
             assert abs(min(max(float(cand["tenpai_probs"][i]), 0.0), 1.0) - min(want_t, 1.0)) <= 2e-5, (i, cand["tenpai_probs"][i], want_t)
+
+
+def _cases_deep():
+    """Closed 13-tile hands at exactly 3 shanten (the deepest graphs the encoder builds), 3-5 draws left."""
+    rng = np.random.default_rng(31337)
+    out = []
+    while len(out) < 60:
+        cnt = _hand_near_completion(rng, 4)
+        for _ in range(3):
+            cnt[int(rng.choice(np.flatnonzero(cnt)))] -= 1
+            t = int(rng.integers(0, 34))
+            while cnt[t] >= 4:
+                t = int(rng.integers(0, 34))
+            cnt[t] += 1
+        cnt[int(rng.choice(np.flatnonzero(cnt)))] -= 1
+        if cnt.max() > 4:
+            continue
+        out.append((cnt, int(rng.integers(3, 6)), 27 + int(rng.integers(0, 2)), 27 + int(rng.integers(0, 4)), int(rng.integers(0, 34)),
+                    int(rng.integers(20, 60)), int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_oracle_sp_three_shanten_against_exact_recursion(oracle, case):
+    deep = [c for c in _cases_deep() if oracle.calc_shanten(c[0].astype(np.uint8), 4) == 3]
+    assert len(deep) >= 6
+    hand, T, bakaze, jikaze, dora, n_seen, sub = deep[case]
+    rng = np.random.default_rng(sub)
+    vis = hand.copy()
+    if vis[dora] < 4:
+        vis[dora] += 1
+    rest = np.repeat(np.arange(34), 4 - vis)
+    rng.shuffle(rest)
+    seen = vis + np.bincount(rest[:n_seen], minlength=34)
+    wall = [4 - int(x) for x in seen]
+    akas_seen = tuple(int(wall[t] == 0) for t in (4, 13, 22))
+    akas_wall = tuple(1 - a for a in akas_seen)
+    got = oracle.sp_calc(hand.astype(np.uint8), seen.astype(np.uint8), jikaze=jikaze, bakaze=bakaze, tsumos_left=T, cur_shanten=3,
+                         can_discard=False, prefer_riichi=True, calc_haitei=True, dora_indicators=[dora], akas_in_hand=(0, 0, 0),
+                         akas_seen=akas_seen, sort_result=False)
+    assert len(got) == 1
+    X = ExactSP(oracle, wall, akas_wall, T, bakaze, jikaze, [dora], True, prefer_riichi=True)
+    ten, win, ev = X.draw(tuple(int(x) for x in hand), (0, 0, 0), tuple(wall), akas_wall, 3)
+    c = got[0]
+    for i in range(T):
+        assert abs(float(c["win_probs"][i]) - float(win[i])) <= 3e-5 * max(1.0, float(win[i])) + 1e-9, (i, c["win_probs"][i], float(win[i]))
+        assert abs(float(c["exp_values"][i]) - float(ev[i])) <= 3e-5 * max(1.0, float(ev[i])), (i, c["exp_values"][i], float(ev[i]))
+        assert abs(float(c["tenpai_probs"][i]) - float(ten[i])) <= 3e-5, (i, c["tenpai_probs"][i], float(ten[i]))
