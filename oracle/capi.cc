@@ -409,6 +409,18 @@ int mjo_arena_restart(void* h, int game, u64 nonce) {
     });
 }
 
+// Staggered first start of the benchmark's steady-state mode (the device's mj_pool_set_start_stagger / mj_k_park): every slot is
+// marked finished before the first cycle without having played; the harness then restarts slot t at its own cycle.
+int mjo_arena_park(void* h) {
+    return guard([&] {
+        Arena* a = (Arena*)h;
+        if (a->cycles != 0) throw std::runtime_error("park after the first cycle");
+        for (size_t g = 0; g < a->done.size(); g++) a->done[g] = 1;
+        a->live.clear();
+        return 0;
+    });
+}
+
 // Poll phase (game.rs:287-289).  Returns the number of policy rows, -1 on error.
 int mjo_arena_poll(void* h) {
     return guard([&] {

@@ -59,6 +59,7 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p]
     L.mjo_arena_rows.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_arena_restart.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    L.mjo_arena_park.argtypes = [C.c_void_p]
     L.mjo_arena_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.mjo_arena_commit.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_arena_encode_oracle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -426,6 +427,10 @@ class Arena:
     def restart(self, g, nonce):
         """Finished slot g starts a fresh hanchan on (nonce, same key) — the oracle side of the pool's refill mode."""
         _check(lib().mjo_arena_restart(self.h, int(g), int(nonce)))
+
+    def park(self):
+        """Every slot finished before the first cycle (staggered first start): `restart` then brings slot t into play at its cycle."""
+        _check(lib().mjo_arena_park(self.h))
 
     def poll(self):
         n = _check(lib().mjo_arena_poll(self.h))

@@ -103,11 +103,14 @@ def fake_q_values(masks, rows, cycle, seed):
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
                  policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
                  policy="random", guard=False, oracle_obs=False, compare_logs=False, deal_algo=0, refill=0, min_games=2,
-                 threads=0, obs_cycles=None, pool_cls=None):
+                 threads=0, obs_cycles=None, pool_cls=None, stagger=0):
     """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch.
 
     refill = nonce stride: finished slots restart on (nonce + stride, key) on both sides (the pool's steady-state mode,
     mj_pool_set_refill / mj_k_refill — what bench.py times) until every slot has finished `min_games` hanchan.
+    stagger = S (needs refill): the protocol bench.py times — every slot is parked before the first cycle and slot t enters play
+    at cycle ((t * 2654435761 mod 2^32) >> 8) % S through the refill path (mj_pool_set_start_stagger, mj_step.hip: mj_k_park /
+    mj_k_refill), i.e. on (nonce + stride, key) as game id t + n_tables; the oracle slot idles until that cycle the same way.
     obs_cycles: explicit set of cycles whose obs are compared (overrides obs_every); threads: oracle encode threads."""
     import torch
 
@@ -125,6 +128,12 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         pool.set_refill(refill)
     gen = [0] * n_tables
     nonce = [int(s[0]) for s in seeds]
+    starts = None
+    if stagger:
+        assert refill, "the staggered start goes through the refill path"
+        pool.set_start_stagger(stagger)
+        arena.park()
+        starts = [(((t * 2654435761) & 0xFFFFFFFF) >> 8) % stagger for t in range(n_tables)]
     gen_scores = {}
     pool.configure(0, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
     pool.configure(1, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
@@ -134,6 +143,12 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     actions = q_dev = None
     stats = dict(cycles=0, rows=0, obs_checked=0)
     for cycle in range(max_cycles):
+        if starts is not None:
+            for g in range(n_tables):
+                if starts[g] == cycle:  # the device's refill kernel runs ahead of this cycle's step: in play from this cycle on
+                    gen[g] = 1
+                    nonce[g] += refill
+                    arena.restart(g, nonce[g])
         n0, n1 = pool.step(actions, None, q_dev, None)
         assert n1 == 0
         rows_o = arena.poll()
@@ -156,7 +171,7 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
             msg.append(f"gpu first error: code {code} table {t}")
             raise AssertionError("\n".join(msg))
         n = len(rows_o)
-        if n == 0 and arena.n_live == 0:
+        if n == 0 and arena.n_live == 0 and not (starts is not None and cycle < stagger):
             break
         # buffers poisoned before the encode: every cell of the observation has to be WRITTEN by a kernel (the encoder owns rows
         # 0..888 of obs v4 and mj_k_sp the rest), nothing may rely on what the allocator handed out
@@ -249,12 +264,12 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         if refill:
             for g in range(n_tables):
                 sc, dn = arena.result(g)
-                if dn:
+                if dn and (starts is None or starts[g] <= cycle):  # a parked slot is "finished" without having played
                     gen_scores[(g, gen[g])] = sc.copy()
                     gen[g] += 1
                     nonce[g] += refill
                     arena.restart(g, nonce[g])
-            if min(gen) >= min_games:
+            if min(gen) >= min_games + (1 if stagger else 0):
                 break
     code, t = pool.first_error()
     assert code == 0, f"gpu table {t} in error {code}"

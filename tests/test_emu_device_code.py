@@ -69,6 +69,17 @@ def test_emu_lockstep_refill(oracle, emu):
     assert st["generations"][0] >= 2 and st["games_checked"] >= 4
 
 
+def test_emu_lockstep_staggered_start(oracle, emu):
+    """The benchmark's protocol (set_refill + set_start_stagger) in lock-step with the oracle: slots idle until their own cycle,
+    start on nonce + stride, then restart like refilled tables; obs v4 with the SP rows on the first, v3 + greedy on the second."""
+    st = parity_util.run_lockstep(oracle, 3, version=4, max_cycles=20000, obs_every=40, sp_rows_checked=True, pool_cls=emu, refill=8,
+                                  stagger=90, min_games=1, deal_algo=1, verbose=False)
+    assert st["generations"][0] >= 2 and st["games_checked"] >= 3 and st["counters"]["sp_overflow"] == 0
+    st = parity_util.run_lockstep(oracle, 4, version=3, max_cycles=20000, obs_every=9, pool_cls=emu, refill=8, stagger=300,
+                                  min_games=2, policy="greedy", verbose=False)
+    assert st["generations"][0] >= 3 and st["games_checked"] >= 8
+
+
 def test_emu_invisible_obs(oracle, emu):
     st = parity_util.run_lockstep(oracle, 2, version=3, max_cycles=200, obs_every=2, compare_obs=False, pool_cls=emu,
                                   policy="greedy", oracle_obs=True, verbose=False)

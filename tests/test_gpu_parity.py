@@ -58,6 +58,18 @@ def test_lockstep_refill_matches_benchmark_mode(oracle):
     assert st["generations"][0] >= 3 and st["games_checked"] >= 768
 
 
+def test_lockstep_staggered_start_matches_benchmark_protocol(oracle):
+    """The protocol the headline is TIMED under (bench.py: set_refill + set_start_stagger): every table parked, table t entering
+    play at cycle hash(t) % S through the refill path, then restarting like any refilled table.  The oracle slots idle and start
+    the same way; rows, masks, obs v4 incl. the SP rows, the step counter and the scores of >= 2 played hanchan per slot."""
+    st = parity_util.run_lockstep(oracle, 48, version=4, max_cycles=20000, obs_every=6, sp_rows_checked=True, refill=12,
+                                  stagger=700, min_games=2, deal_algo=1, threads=8)
+    assert st["generations"][0] >= 3 and st["games_checked"] >= 96 and st["counters"]["sp_overflow"] == 0
+    st = parity_util.run_lockstep(oracle, 256, version=3, max_cycles=20000, obs_every=11, refill=64, stagger=1500, min_games=2,
+                                  policy="greedy", threads=8)
+    assert st["generations"][0] >= 3 and st["games_checked"] >= 512
+
+
 def test_lockstep_quick_eval_disabled(oracle):
     """enable_quick_eval = False (mortal.rs:210-250): single-candidate discards get a row, every ankan/kakan decision
     gets a kan-select row."""
