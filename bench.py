@@ -120,9 +120,7 @@ def cpu_baseline(version, budget_s=12.0, n_tables=16):
     import shutil
 
     toolchain = {"cargo": shutil.which("cargo"), "rustc": shutil.which("rustc")}  # probed on the measurement host
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "arena_bench")  # built by __graft_entry__.build() when a Rust toolchain exists
     return dict(value=value, unit="env steps/s", cores=len(res), kind="port", reference_toolchain=toolchain,
-                reference_binary=ref_bin if os.path.exists(ref_bin) else None,
                 sample=f"{len(res)} processes (1 per core) x arenas of {n_tables} tables for {budget_s:.0f}s each: "
                        f"{tot['arenas']} arenas, {tot['cycles']} cycles, {tot['steps']} env steps, {tot['rows']} decisions "
                        f"encoded (obs v{version}), random-legal policy, oracle/libmjoracle.so; the Rust reference is "

@@ -105,7 +105,10 @@ int mj_replay_meta(MjPool* pool, int32_t* meta_dev, void* stream);
  * apply one event (LG_* words, "?" tiles = 37 allowed for hidden hands), make (table, seat) the only policy row so that
  * mj_rows_count + mj_encode return its obs/mask (state/obs_repr.rs:776-791 encode_obs), and a few queries:
  * what = 0 agari_points(args: is_ron, n_ura, ura[5]) -> ok, ron, tsumo_ko, tsumo_oya | 1 rule_based_agari |
- *        2 real_time_shanten | 3 doras_owned[4] | 4 add_dora_indicator(args[0]) | 5 set scores(args[0..3]). */
+ *        2 real_time_shanten | 3 doras_owned[4] | 4 add_dora_indicator(args[0]) | 5 set scores(args[0..3]) |
+ *        6 set_scene (agent/mortal.rs:200-250) | 7 action id -> event word (agent/mortal.rs:338-573) |
+ *        8 the step kernel's check of an explicit reaction word (args: word lo, hi; state/action.rs:91-228 plus the seat
+ *          the call is made on) -> error code (0 = accepted), reaction type; the table is left untouched. */
 int mj_table_apply_event(MjPool* pool, int table, const uint64_t* words_host, int n_words, void* stream);
 int mj_table_mark_row(MjPool* pool, int table, int seat, int at_kan_select, void* stream);
 int mj_table_query(MjPool* pool, int table, int seat, int what, const int32_t* args8_host, int32_t* out8_host, void* stream);

@@ -199,7 +199,7 @@ class BatchRunner:
         if n > done:
             buf = np.empty((1, self.pool.log_cap), dtype=np.uint64)
             check(self.pool._L.mj_log_read(self.pool.h, int(g), 1, buf.ctypes.data, self.pool._stream()))
-            events = events + mjai_log.decode_events(buf[0, done:n])
+            events.extend(mjai_log.decode_events(buf[0, done:n]))  # in place: callers only read the list
             self._log_cache[g] = (n, events)
         return events
 

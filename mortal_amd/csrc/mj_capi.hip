@@ -180,18 +180,20 @@ int mj_algo_query(const MjAlgoQuery* queries_host, int n, MjAlgoResult* results_
     if (!g_tables.ready) return fail("mj_tables_upload has not been called");
     if (n <= 0) return 0;
     if (!queries_host || !results_host) return fail("null query / result buffer");
-    MjAlgoQuery* dq = nullptr;
-    MjAlgoResult* dr = nullptr;
+    struct DevBuf {  // freed on every return path
+        void* p = nullptr;
+        ~DevBuf() { if (p) hipFree(p); }
+    } bq, br;
     hipStream_t s = (hipStream_t)stream;
-    HIP_OK(hipMalloc(&dq, (size_t)n * sizeof(MjAlgoQuery)));
-    HIP_OK(hipMalloc(&dr, (size_t)n * sizeof(MjAlgoResult)));
+    HIP_OK(hipMalloc(&bq.p, (size_t)n * sizeof(MjAlgoQuery)));
+    HIP_OK(hipMalloc(&br.p, (size_t)n * sizeof(MjAlgoResult)));
+    MjAlgoQuery* dq = (MjAlgoQuery*)bq.p;
+    MjAlgoResult* dr = (MjAlgoResult*)br.p;
     HIP_OK(hipMemcpyAsync(dq, queries_host, (size_t)n * sizeof(MjAlgoQuery), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(mj_k_algo_query, dim3((n + 63) / 64), dim3(64), 0, s, dq, n, dr);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(results_host, dr, (size_t)n * sizeof(MjAlgoResult), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    hipFree(dq);
-    hipFree(dr);
     return 0;
 }
 // "name:elem_size:count:offset;..." of struct TableOne, so a host tool can decode mj_debug_table() generically
@@ -432,6 +434,7 @@ int mj_pool_set_start_stagger(MjPool* P, uint32_t cycles, void* stream) {
     if (!P) return fail("null pool");
     if (P->cycles != 0) return fail("mj_pool_set_start_stagger: call it right after mj_pool_reset, before the first mj_step");
     if (cycles && !P->refill_stride) return fail("mj_pool_set_start_stagger needs the refill mode (mj_pool_set_refill)");
+    if (!cycles && P->start_stagger) return fail("mj_pool_set_start_stagger(0) after the tables were parked: reset the pool instead");
     P->start_stagger = cycles;
     if (cycles) hipLaunchKernelGGL(mj_k_park, dim3(P->n_blocks), dim3(64), 0, (hipStream_t)stream, P->blocks, P->n_tables);
     HIP_OK(hipGetLastError());

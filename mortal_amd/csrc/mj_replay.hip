@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void mj_k_mark_row(TableBlock* blocks, int n_ta
 }
 // queries / pokes: out int32[8]
 enum { MJ_Q_AGARI_POINTS = 0, MJ_Q_RULE_BASED_AGARI = 1, MJ_Q_REAL_TIME_SHANTEN = 2, MJ_Q_DORAS_OWNED = 3,
-       MJ_Q_ADD_DORA = 4, MJ_Q_SET_SCORES = 5, MJ_Q_SCENE = 6, MJ_Q_DECODE_ACTION = 7 };
+       MJ_Q_ADD_DORA = 4, MJ_Q_SET_SCORES = 5, MJ_Q_SCENE = 6, MJ_Q_DECODE_ACTION = 7, MJ_Q_VALIDATE_REACTION = 8 };
 __global__ void mj_k_query(TableBlock* blocks, int table, int seat, int what, const int32_t* args, int32_t* out) {
     Lane L = {MJ_POOL_PTR(blocks + (table >> 6)), table & 63, &c_mj_tables};
     const int p = seat;
@@ -433,6 +433,16 @@ __global__ void mj_k_query(TableBlock* blocks, int table, int seat, int what, co
             out[1] = (int32_t)(uint32_t)(w >> 32);
             out[2] = F(err);
             F(err) = MJ_OK;  // an illegal action is reported to the caller, the table stays usable
+            break;
+        }
+        case MJ_Q_VALIDATE_REACTION: {  // the step kernel's own check of an explicit reaction word (mj_step_ev): args = word lo, hi -> error code
+            const unsigned long long w = (unsigned long long)(uint32_t)args[0] | ((unsigned long long)(uint32_t)args[1] << 32);
+            const u8 before = F(err);
+            F(err) = MJ_OK;
+            const Reaction r = reaction_from_word(L, p, w);
+            out[0] = F(err);
+            out[1] = r.type;
+            F(err) = before;
             break;
         }
     }

@@ -90,7 +90,10 @@ template <class LN> MJD bool hand_holds(const LN& L, int s, int a, int b, int c 
 // An explicit reaction of seat s (mjai-log engines): the LG_* header word of the event.  The Python host runs
 // PlayerState::validate_reaction on it first (state/action.rs:91-228, as BoardState::step does, board.rs:524-533), but a C-ABI
 // caller may not: the word is checked here against the seat's candidates AND its tiles (legal discard set, consumed tiles
-// held with their red flags, the called tile, the shape of a chi / pon / kan) before anything touches the packed hand.
+// held with their red flags, the called tile, the shape of a chi / pon / kan, the chi type's own candidate flag — kuikae —, the
+// seat the call is made on, tsumogiri only of the tile just drawn) before anything touches the packed hand.  A call or ron
+// must name the seat that discarded (cans_target): stricter than validate_reaction's `(target + 1) % 4 == actor` /
+// `target != actor`, which would let the wrong seat's river take the call mark.
 template <class LN> MJDN Reaction reaction_from_word(const LN& L, int s, uint64_t w) {
     Reaction r = {RX_NONE, (u8)s, 0, MJ_NONE, MJ_NONE, MJ_NONE, MJ_NONE, 0, 0ull};
     const int t = (int)(w & 15);
@@ -106,26 +109,34 @@ template <class LN> MJDN Reaction reaction_from_word(const LN& L, int s, uint64_
         case LG_DAHAI:
             r.type = RX_DAHAI; r.pai = (u8)pai; r.tsumogiri = (u8)((w >> 38) & 1);
             ok = ok && (cans & CAN_DISCARD) && pai < 37 && ((discard_candidates_aka(L, s) >> pai) & 1);
+            ok = ok && (!r.tsumogiri || F1(last_self_tsumo, s) == pai);  // action.rs:124-130
             break;
         case LG_REACH: r.type = RX_REACH; ok = ok && (cans & CAN_RIICHI); break;
         case LG_CHI: {
             r.type = RX_CHI; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1;
             ok = ok && (cans & (CAN_CHI_LOW | CAN_CHI_MID | CAN_CHI_HIGH)) && called && c0 < 37 && c1 < 37 && hand_holds(L, s, c0, c1, MJ_NONE);
+            ok = ok && r.target == F1(cans_target, s) && ((r.target + 1) & 3) == s;  // action.rs:144 + the seat that discarded
             if (ok) {  // three consecutive tiles of one number suit
                 const int x = deaka(pai), y = deaka(c0), z = deaka(c1);
                 const int lo = min(x, min(y, z)), hi = max(x, max(y, z)), mid = x + y + z - lo - hi;
                 ok = hi < 27 && lo / 9 == hi / 9 && mid == lo + 1 && hi == lo + 2;
+                // ChiType::new (chi_type.rs:12-25): the called tile below / between / above the consumed pair picks the flag; a
+                // legal shape whose own flag is off is a forbidden swap call (kuikae, update.rs:826-868)
+                const u32 need = x == lo ? CAN_CHI_LOW : x == mid ? CAN_CHI_MID : CAN_CHI_HIGH;
+                ok = ok && (cans & need);
             }
             break;
         }
         case LG_PON:
             r.type = RX_PON; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1;
             ok = ok && (cans & CAN_PON) && called && c0 < 37 && c1 < 37 && deaka(c0) == deaka(pai) && deaka(c1) == deaka(pai) && hand_holds(L, s, c0, c1, MJ_NONE);
+            ok = ok && r.target == F1(cans_target, s) && r.target != s;  // action.rs:164
             break;
         case LG_DAIMINKAN:
             r.type = RX_DAIMINKAN; r.pai = (u8)pai; r.c0 = (u8)c0; r.c1 = (u8)c1; r.c2 = (u8)c2;
             ok = ok && (cans & CAN_DAIMINKAN) && called && c0 < 37 && c1 < 37 && c2 < 37 && deaka(c0) == deaka(pai) && deaka(c1) == deaka(pai) &&
                  deaka(c2) == deaka(pai) && hand_holds(L, s, c0, c1, c2);
+            ok = ok && r.target == F1(cans_target, s) && r.target != s;  // action.rs:179
             break;
         case LG_KAKAN:
             r.type = RX_KAKAN; r.pai = (u8)pai;
@@ -135,7 +146,10 @@ template <class LN> MJDN Reaction reaction_from_word(const LN& L, int s, uint64_
             r.type = RX_ANKAN; r.pai = (u8)deaka(c0);
             ok = ok && (cans & CAN_ANKAN) && c0 < 37 && ((F1(ankan_cand, s) >> deaka(c0)) & 1) && load_hand(L, s).get(deaka(c0)) == 4;
             break;
-        case LG_HORA: r.type = RX_HORA; ok = ok && (r.target == s ? (cans & CAN_TSUMO_AGARI) : (cans & CAN_RON_AGARI)); break;
+        case LG_HORA:
+            r.type = RX_HORA;
+            ok = ok && (r.target == s ? (cans & CAN_TSUMO_AGARI) : ((cans & CAN_RON_AGARI) && r.target == F1(cans_target, s)));
+            break;
         case LG_RYUKYOKU: r.type = RX_RYUKYOKU; ok = ok && (cans & CAN_RYUKYOKU); break;
         default: ok = false; break;
     }

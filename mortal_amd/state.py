@@ -18,6 +18,7 @@ from .pool import TablePool, _stream
 _CAN_BITS = ["can_discard", "can_chi_low", "can_chi_mid", "can_chi_high", "can_pon", "can_daiminkan", "can_kakan",
              "can_ankan", "can_riichi", "can_tsumo_agari", "can_ron_agari", "can_ryukyoku"]
 Q_AGARI_POINTS, Q_RULE_BASED_AGARI, Q_REAL_TIME_SHANTEN, Q_DORAS_OWNED, Q_ADD_DORA, Q_SET_SCORES = range(6)
+Q_VALIDATE_REACTION = 8
 
 
 class ActionCandidate:
@@ -90,6 +91,17 @@ class PlayerState:
         if code:
             raise MortalAmdError(f"rule violation while applying {ev} (error code {code})")
         return self.last_cans
+
+    def reaction_accepted_by_device(self, mjai_json):
+        """The step kernel's own verdict on an explicit reaction (what a raw `mj_step_ev` caller gets): True = it would be applied,
+        False = the table would go into MJ_ERR_ILLEGAL_ACTION.  validate_reaction's checks plus: a call / ron must name the seat
+        that discarded (`last_cans.target_actor`)."""
+        from .arena import pack_reaction
+
+        ev = json.loads(mjai_json) if isinstance(mjai_json, str) else mjai_json
+        w = pack_reaction(ev)
+        out = self._query(Q_VALIDATE_REACTION, [int(np.int32(np.uint32(w & 0xFFFFFFFF))), int(np.int32(np.uint32(w >> 32)))])
+        return int(out[0]) == 0
 
     # ---- validate_reaction (state/action.rs:91-228)
     def validate_reaction(self, mjai_json):

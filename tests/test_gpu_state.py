@@ -9,6 +9,8 @@ import test_oracle_state as T
 
 pytestmark = pytest.mark.gpu
 
+TILE_NAMES34 = [f"{n}{s}" for s in "mps" for n in range(1, 10)] + ["E", "S", "W", "N", "P", "F", "C"]
+
 # scenarios that only poke private fields of the Rust struct (no event stream) have no counterpart on the public surface
 EVENT_DRIVEN = sorted(n for n in T.SCEN if n not in ("waits", "can_chi"))
 
@@ -87,8 +89,17 @@ def test_device_player_state_obs_matches_oracle(oracle):
     (hidden hands as "?"), all four obs versions."""
     from libriichi.state import PlayerState
 
-    sc = T.SCEN["discard_candidates_with_unconditional_tenpai"]
-    evs = [s["ev"] for s in sc["steps"] if "ev" in s]
+    agree = rejected = dev_rejected = wrong_seat = 0
+    for scen in ("discard_candidates_with_unconditional_tenpai", "chi_at_0_shanten", "kakan_from_hand", "dora_count_after_kan", "double_chankan_ron"):
+        a_, r_, d_, w_ = _validate_scenario(oracle, PlayerState, scen)
+        agree, rejected, dev_rejected, wrong_seat = agree + a_, rejected + r_, dev_rejected + d_, wrong_seat + w_
+    print('validate_reaction', agree, rejected, dev_rejected, wrong_seat)
+    assert agree > 500 and 0 < rejected < agree and dev_rejected >= rejected + wrong_seat and wrong_seat >= 5
+
+
+def _validate_scenario(oracle, PlayerState, scen):
+    sc = T.SCEN[scen]
+    evs = [s["ev"] for s in sc["steps"] if "ev" in s and s["on"] == "ps"]
     pid = next(s["new"] for s in sc["steps"] if "new" in s)
     dev, ora = PlayerState(pid), oracle.PlayerState(pid)
     checked = 0
@@ -106,27 +117,49 @@ def test_device_player_state_obs_matches_oracle(oracle):
 
 
 def test_device_player_state_validate_reaction(oracle):
-    """validate_reaction (state/action.rs:91-228) agrees with the oracle's on every logged reaction of a kyoku and on a
-    set of illegal ones."""
+    """validate_reaction (state/action.rs:91-228) agrees with the oracle's on every logged reaction of five of the reference's
+    scenario kyoku and on a set of illegal ones; the step kernel's OWN check of the same reactions as explicit event words (what
+    a raw mj_step_ev caller gets: mj_table_query 8 -> reaction_from_word) accepts exactly those the reference accepts, except
+    that a call / ron on a seat other than the one that discarded is refused too (wrong-seat calls, tsumogiri of a
+    tile that was not drawn)."""
     from libriichi.state import PlayerState
 
-    sc = T.SCEN["discard_candidates_with_unconditional_tenpai"]
-    evs = [s["ev"] for s in sc["steps"] if "ev" in s]
+    agree = rejected = dev_rejected = wrong_seat = 0
+    for scen in ("discard_candidates_with_unconditional_tenpai", "chi_at_0_shanten", "kakan_from_hand", "dora_count_after_kan",
+                 "double_chankan_ron"):
+        a_, r_, d_, w_ = _validate_scenario(oracle, PlayerState, scen)
+        agree, rejected, dev_rejected, wrong_seat = agree + a_, rejected + r_, dev_rejected + d_, wrong_seat + w_
+    print("validate_reaction", agree, rejected, dev_rejected, wrong_seat)
+    assert agree > 500 and 0 < rejected < agree and dev_rejected == rejected + wrong_seat and wrong_seat >= 5
+
+
+def _validate_scenario(oracle, PlayerState, scen):
+    sc = T.SCEN[scen]
+    evs = [s["ev"] for s in sc["steps"] if "ev" in s and s["on"] == "ps"]
     pid = next(s["new"] for s in sc["steps"] if "new" in s)
+    if scen.startswith("discard_candidates"):  # two kyoku in one scenario: the first one
+        evs = evs[: next(i for i, e in enumerate(evs) if i > 0 and e["type"] == "start_kyoku")]
     dev, ora = PlayerState(pid), oracle.PlayerState(pid)
     probes = [{"type": "dahai", "actor": pid, "pai": "1m", "tsumogiri": False}, {"type": "dahai", "actor": pid, "pai": "C", "tsumogiri": True},
-              {"type": "reach", "actor": pid}, {"type": "hora", "actor": pid, "target": pid}, {"type": "hora", "actor": pid, "target": (pid + 1) % 4},
-              {"type": "pon", "actor": pid, "target": (pid + 2) % 4, "pai": "E", "consumed": ["E", "E"]},
-              {"type": "chi", "actor": pid, "target": (pid + 3) % 4, "pai": "3s", "consumed": ["4s", "5s"]},
-              {"type": "ankan", "actor": pid, "consumed": ["9m", "9m", "9m", "9m"]}, {"type": "ryukyoku"},
+              {"type": "reach", "actor": pid}, {"type": "ankan", "actor": pid, "consumed": ["9m", "9m", "9m", "9m"]}, {"type": "ryukyoku"},
               {"type": "dahai", "actor": (pid + 1) % 4, "pai": "1m", "tsumogiri": False}]
-    agree = rejected = 0
+    for t in range(4):  # every seat as the target of a call / ron
+        probes += [{"type": "pon", "actor": pid, "target": t, "pai": "E", "consumed": ["E", "E"]},
+                   {"type": "hora", "actor": pid, "target": t},
+                   {"type": "chi", "actor": pid, "target": t, "pai": "3s", "consumed": ["4s", "5s"]},
+                   {"type": "daiminkan", "actor": pid, "target": t, "pai": "9m", "consumed": ["9m", "9m", "9m"]}]
+    agree = rejected = dev_rejected = wrong_seat = 0
     for k, ev in enumerate(evs):
         dev.update(ev)
         ora.update(ev)
         cand = list(probes)
         if k + 1 < len(evs) and evs[k + 1].get("actor") == pid and evs[k + 1]["type"] in ("dahai", "chi", "pon", "reach"):
             cand.append(evs[k + 1])
+            if evs[k + 1]["type"] in ("chi", "pon"):  # the logged call, aimed at every other seat
+                cand += [dict(evs[k + 1], target=t) for t in range(4) if t != evs[k + 1]["target"]]
+        snap = ora.snapshot()
+        if snap["cans"]["can_discard"]:  # every hand tile as a claimed tsumogiri
+            cand += [{"type": "dahai", "actor": pid, "pai": name, "tsumogiri": True} for t, name in enumerate(TILE_NAMES34) if snap["tehai"][t] > 0]
         for a in cand:
             ok_dev = ok_ora = True
             try:
@@ -140,7 +173,13 @@ def test_device_player_state_validate_reaction(oracle):
             assert ok_dev == ok_ora, (ev, a)
             agree += 1
             rejected += not ok_dev
-    assert agree > 500 and 0 < rejected < agree
+            # the device's own verdict on the packed event word
+            wrong = a["type"] in ("chi", "pon", "daiminkan", "hora") and a["target"] != pid and a["target"] != snap["cans"]["target_actor"]
+            ok_word = dev.reaction_accepted_by_device(a)
+            assert ok_word == (ok_ora and not wrong), (ev, a, ok_word, ok_ora, wrong)
+            dev_rejected += not ok_word
+            wrong_seat += ok_ora and wrong
+    return agree, rejected, dev_rejected, wrong_seat
 
 
 def test_bot_replays_a_game_like_the_oracle_agent(oracle):
