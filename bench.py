@@ -233,7 +233,7 @@ def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmu
     return res
 
 
-def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs):
+def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs, other_ms=None):
     """BASELINE configs[2] as a driver-timed workload: the policy/value net is PyTorch's (out of this path's scope), so what the
     entry shows is the end-to-end rate and how small the environment's share of that cycle is."""
     import torch
@@ -247,9 +247,13 @@ def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs):
     except Exception as e:  # noqa: BLE001 - an extra workload must never cost the headline line
         return {"error": repr(e)[:300]}
     out = _brief(r)
-    env_ms = out["kernel_ms_per_step"]["mj_k_encode"] + out["kernel_ms_per_step"]["mj_k_sp"] + 0.6  # + step / snapshot / bookkeeping
+    # step / snapshot / row bookkeeping: what the headline's own cycle spends outside the two event-timed kernels (measured in this
+    # run: ms_per_step - encode - SP of the random-policy headline, whose policy kernel is a few microseconds)
+    env_ms = out["kernel_ms_per_step"]["mj_k_encode"] + out["kernel_ms_per_step"]["mj_k_sp"] + (other_ms if other_ms is not None else 0.6)
     out["env_share_of_cycle"] = env_ms / out["ms_per_step"]
-    out["net"] = "random-init Brain + DQN, 192 ch x 40 blocks, bf16 autocast, greedy"
+    out["env_ms_per_step"] = env_ms
+    out["net"] = ("random-init Brain + DQN, 192 ch x 40 blocks, torch.autocast default dtype of the backend (fp16 on ROCm, exactly "
+                  "like mortal/engine.py:46), greedy")
     return out
 
 
@@ -274,12 +278,15 @@ def main():
     ap.add_argument("--policy", choices=["random", "greedy", "brain"], default="random",
                     help="random = uniform-random legal action on device (BASELINE configs[1]); greedy = tenpai-seeking policy on "
                          "device (hands at 0..3 shanten: realistic SP load); brain = greedy argmax of a random-init network of "
-                         "the reference's Brain/DQN architecture (192 ch x 40 blocks, bf16 autocast), consuming the encoded "
+                         "the reference's Brain/DQN architecture (192 ch x 40 blocks, fp16 autocast), consuming the encoded "
                          "batch in place (BASELINE configs[2])")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for --gpus N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--no-start-stagger", action="store_true",
                     help="start every table on cycle 0 (the protocol of rounds 1-2) instead of spreading the first starts over the "
                          "pre-roll (mj_pool_set_start_stagger): the timed window then shows a single phase of the hanchan")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, what the driver's N = 1, 2, 4, 8 runs measure): --tables per GPU, total work grows with N; "
+                         "strong: --tables is the TOTAL over all ranks (BASELINE.md C4's '65,536 total' point), each rank owns tables / N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true", help="skip the extra workloads (obs v3, no pre-roll, greedy policy)")
     ap.add_argument("--launch-check", action="store_true",
@@ -342,6 +349,10 @@ def main():
     from mortal_amd.pool import TablePool, default_deal_algo
 
     N = args.tables
+    if args.scaling == "strong":
+        if N % (4 * world):
+            raise SystemExit(f"bench.py --scaling strong: {N} tables do not split into {world} ranks of whole duplicate-deal sets (x4)")
+        N //= world
     g0 = rank * N  # tables shard by contiguous game-index ranges, multiples of 4: each duplicate-deal set stays on one GPU
     bufs = (torch.empty(2 * N * 1012 * 34, dtype=torch.float32, device=dev), torch.empty((2 * N, 46), dtype=torch.bool, device=dev),
             torch.empty(2 * N, dtype=torch.int32, device=dev))
@@ -374,8 +385,10 @@ def main():
         ret = torch.from_numpy(sc).to(red_dev)
         out = [torch.empty_like(ret) for _ in range(world)] if rank == 0 else None
         dist.gather(ret, out, dst=0)
+        collective_ranks = dist.get_world_size()  # the ranks the gather really spanned (RCCL when --dist-backend nccl)
     else:
         rows_all = rows_timed
+        collective_ranks = 1
 
     # the other driver-timed workloads (N = 1 only, a few seconds each): where the headline sits between them
     matrix = None
@@ -385,9 +398,10 @@ def main():
             "obs_v3_random": _brief(_measure(TablePool, N, g0, world, dev, 3, args.preroll, "random", 10 * k, 10, bufs)),
             "obs_v4_random_no_preroll": _brief(_measure(TablePool, N, g0, world, dev, 4, 0, "random", k, 3, bufs)),
             "obs_v4_greedy": _brief(_measure(TablePool, N, g0, world, dev, 4, args.preroll, "greedy", k, 3, bufs)),
-            "brain_v4": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs),
+            "brain_v4": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs,
+                                        other_ms=(dt * 1e3 - enc_ms - sp_ms) / args.steps),
             "note": "brain_v4 = BASELINE configs[2]: full self-play cycle with a random-init net of the reference's Brain/DQN shape "
-                    "(192 channels x 40 blocks, bf16 autocast, greedy argmax) consuming the encoded batch in place on the same GPU; "
+                    "(192 channels x 40 blocks, fp16 autocast = torch.autocast's default on this backend like mortal/engine.py:46, greedy argmax) consuming the encoded batch in place on the same GPU; "
                     "2 timed cycles (the net takes seconds per 65 k-row batch); env_share = (step + encode + SP kernels) / cycle; "
                     "obs_v3_random = env-step + encode only (no SP block); obs_v4_random_no_preroll = every table in the first "
                     "turns of E1 (17 draws left: the heaviest SP phase); obs_v4_greedy = tenpai-seeking policy on device "
@@ -410,27 +424,30 @@ def main():
                 traffic_src = (f"profiles/pmc_encode.json ({per:.0f} B/decision; static file from separate rocprofv3 --pmc passes at "
                                f"{pmc.get('measured_at_tables', pmc['tables'])} tables, {pmc.get('measured_utc', 'round 2')})")
         line = {
-            "metric": "env steps/sec (65536 parallel tables per GPU)",
+            "metric": ("env steps/sec (65536 parallel tables per GPU)" if args.scaling == "weak"
+                       else f"env steps/sec ({args.tables} parallel tables in total)"),
             "value": steps / dt,
             "unit": "env steps/s",
             "n_gpus": world,
             "ranks": world,
             "dist_backend": (args.dist_backend if world > 1 else None),
+            "collective_ranks": collective_ranks,  # dist.get_world_size() after the gather of episode returns ("rccl_ranks" over nccl)
+            "rccl_ranks": (collective_ranks if world > 1 and args.dist_backend == "nccl" else None),
             "gpus_visible_per_rank": torch.cuda.device_count(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8/i32 state, f32 obs",
             "data": "synthetic",
             "games_per_sec": games / dt,
             "decisions_per_sec": rows_all / dt,
             "config": {
-                "workload": f"{N} tables per GPU, "
+                "workload": f"{N} tables per GPU" + (f" ({args.tables} in total, strong scaling)" if args.scaling == "strong" else "") + ", "
                             + {"random": "uniform-random legal policy on device", "greedy": "tenpai-seeking policy on device",
-                               "brain": "greedy policy of a random-init Brain/DQN-shaped net (192x40, bf16) on the same device"}[args.policy]
+                               "brain": "greedy policy of a random-init Brain/DQN-shaped net (192x40, fp16 autocast) on the same device"}[args.policy]
                             + f", env-step + obs(v{args.version})"
                             f"+mask encode of every decision, finished tables refilled; fixed-seed synthetic deals "
                             f"(wall shuffle of rand {'0.9.1' if default_deal_algo() else '0.8'}); "
@@ -484,7 +501,15 @@ VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU
 # v_min3 / v_perm / v_lshl_add / v_cmp / DPP moves / v_pk_fma_f32, 3.45 for v_fma_f32 and 2.4-2.6 only for v_add_u32 / v_and_b32 /
 # v_mul_f32 / v_add_f32 - the integer / bit-field work of mj_k_sp is priced at 4.3.
 VALU_PEAK_WAVE_INSTS_INT_MIX = 256 * 4 * 2.4e9 / 4.3
-SP_PMC_FILE = os.path.join(ROOT, "profiles", "r03_sp_pmc.json")
+def _latest_sp_pmc():
+    """profiles/rNN_sp_pmc.json of the latest round (tools/pmc_sp.sh + tools/summarize_sp_pmc.py write one per round)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_sp_pmc.json")))
+    return files[-1] if files else os.path.join(ROOT, "profiles", "r03_sp_pmc.json")
+
+
+SP_PMC_FILE = _latest_sp_pmc()
 
 
 def sp_source_sha16():
@@ -502,27 +527,33 @@ def sp_source_sha16():
 def _roofline_sp(r, sp_ms, sp_launches):
     """The cycle's dominant kernel is neither HBM- nor MFMA-bound: integer / bit-field VALU work (table-id shanten sets, hashing,
     child lists) and exact f32 sums in the reference's order, much of it waiting for dependent gathers.  Model: VALU
-    wave-instructions per state-graph node (separate rocprofv3 --pmc pass, profiles/r03_sp_pmc.json - a STATIC file, stamped with
+    wave-instructions per state-graph node (separate rocprofv3 --pmc pass, profiles/rNN_sp_pmc.json - a STATIC file, stamped with
     the hash of the kernel sources; if it does not match the sources of this run the fraction is null and `stale` is set)
     x nodes visited in the timed region (counted by the kernel) / kernel time (HIP events on the launch stream), against the
-    issue rate the instruction mix can reach (tools/ubench_valu.hip) and, for reference, the f32 FMA rate."""
-    out = {"kernel": "mj_k_sp", "bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_WAVE_INSTS_INT_MIX / 1e9,
-           "peak_basis": "measured issue interval of the kernel's integer / bit-field instruction classes: 4.3 cycles per wave-instruction "
-                         "per SIMD (profiles/r03_ubench_valu.jsonl); the guide's v_fma_f32 rate (2 cycles) is `peak_f32_fma`",
-           "peak_f32_fma": VALU_PEAK_WAVE_INSTS / 1e9,
+    guide's VALU issue peak (`peak` / `frac`: comparable across rounds) and, separately, against the issue rate the instruction mix
+    reached in the builder's micro-benchmark (`frac_of_measured_int_issue`).  `states_per_sec` is the work rate."""
+    states = r["sp_phases"]["states_per_step"] * r["n_cycles"]
+    out = {"kernel": "mj_k_sp", "bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_WAVE_INSTS / 1e9,
+           "peak_basis": "MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD x 1,024 SIMDs x 2.4 GHz (the same "
+                         "denominator as rounds 1-2; round 3's line priced against peak_measured_int_issue instead)",
+           "peak_measured_int_issue": VALU_PEAK_WAVE_INSTS_INT_MIX / 1e9,
+           "peak_measured_int_issue_basis": "tools/ubench_valu.hip, 4 waves per SIMD: 4.3 cycles per wave-instruction for the kernel's "
+                                            "integer / bit-field classes (profiles/r03_ubench_valu.jsonl; builder-run)",
+           # the work rate: the number that has to rise from round to round whatever the instruction count does
+           "states_per_sec": states / (sp_ms * 1e-3) if sp_ms > 0 else None,
            "avg_launch_ms": sp_ms / max(sp_launches, 1), "launches": sp_launches,
            "states_per_launch": r["sp_phases"]["states_per_step"], "from_static_profile": True}
     if os.path.exists(SP_PMC_FILE) and sp_ms > 0:
         pmc = json.load(open(SP_PMC_FILE))
         stale = pmc.get("source_sha16") != sp_source_sha16()
         out["stale"] = stale
-        out["static_profile"] = {"file": "profiles/r03_sp_pmc.json", "measured_utc": pmc.get("measured_utc"),
+        out["static_profile"] = {"file": os.path.relpath(SP_PMC_FILE, ROOT), "measured_utc": pmc.get("measured_utc"),
                                  "measured_at_tables": pmc.get("measured_at_tables"), "source_sha16": pmc.get("source_sha16")}
         insts = pmc["valu_insts_per_state"] * r["sp_phases"]["states_per_step"] * r["n_cycles"]
         out["valu_insts_per_state"] = pmc["valu_insts_per_state"]
         out["achieved"] = None if stale else insts / (sp_ms * 1e-3) / 1e9
         out["frac"] = None if stale else out["achieved"] / out["peak"]
-        out["frac_of_f32_fma_rate"] = None if stale else out["achieved"] / out["peak_f32_fma"]
+        out["frac_of_measured_int_issue"] = None if stale else out["achieved"] / out["peak_measured_int_issue"]
         for k in ("valu_busy", "lane_utilisation", "wave_wait_share", "hbm_fetch_bytes_per_state", "hbm_write_bytes_per_state",
                   "l2_hit_rate", "salu_insts_per_state", "lds_insts_per_state", "vmem_rd_insts_per_state", "source"):
             if k in pmc:

@@ -867,7 +867,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
 // per entry) and the numerators A[c][j] = tsumo_prob[c][j] * not_tsumo[j] of the state's probability table.  A team is
 // exactly T lanes wide (T = draws left, a constant of the row): floor(64 / T) teams per wavefront, so rows with 9 draws
 // left run 7 states per wavefront instead of 4.  Team scratch: nx[2][T + 1][4] then A[4][T] floats.
-#define SP_EVAL_LDS_FLOATS ((SP_THREADS / 64) * 1280)  /* per wavefront (64 / T) teams x (12 T + 8) floats, T >= 1 */
+#define SP_EVAL_LDS_FLOATS ((SP_THREADS / 64) * 1408)  /* per wavefront: level 0 (64 / T) teams x (12 T + 8) floats; levels > 0 SP_EVW_WAVE_FLOATS */
 MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
 #ifndef SP_CH
 #define SP_CH (SP_WPS > 4 ? 4 : 8)  // children (or level-0 draw entries) fetched per round trip
@@ -1078,6 +1078,178 @@ __device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int fi
         dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
         cur = nxt;
         nxt = nn;
+    }
+}
+
+// ---- Levels > 0, round 4: the WHOLE wavefront walks through the evaluation in lock-step (uniform control flow), its teams
+// side by side.  sp_eval_team above (still used for level 0) lets every team run the accumulate — T iterations of
+// {LDS read, division, 3 multiply-adds} — at ITS OWN draw-entry boundaries: with 3-4 teams per wavefront the boundaries
+// rarely coincide, so the wavefront executed the accumulate up to 3-4 times per entry position with a third of its lanes,
+// and every turn of the unrolled loop was its own basic block behind an exec-mask branch (three LDS reads, a wait, eight
+// VALU, three SALU).  Here a STEP = {fold SP_EV_ENT children per team (selects, no branches), park every completed draw
+// entry's folded row in the team's LDS buffer, issue the loads of the next step, accumulate ALL parked entries of ALL teams
+// together}: one b128 LDS read per turn (the row {nx_t, nx_w, nx_e, A}: the numerator A[j] = tsumo_prob[count][j] *
+// not_tsumo[j] rides in the spare word of row j + 1), turns in groups of four behind one scalar branch, rows past T are zero
+// (+0.0 terms, like the dead turns of sp_eval_team).  The loads of the next step (child values, next child-list entries,
+// the next states' headers) are issued before the accumulate and consumed after it.  Same f32 operation order per lane as
+// sp_eval_team: entries in list order, turns ascending.
+#define SP_EV_ENT 4                       // children folded per step = upper bound of the entries parked per step
+#define SP_EVW_WAVE_FLOATS 1408           // LDS per wavefront: teams x SP_EV_ENT x (T + 4) rows x 4 floats (T = 17: 4 teams)
+MJD int sp_evw_team_floats(int T) { return SP_EV_ENT * (T + 4) * 4; }
+struct alignas(16) SpF4 { float x, y, z, w; };
+template <int TN, int LK>
+__device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int first, int end, int stride, int lane_in_team, int off_,
+                                          int team_in_wave, bool team_on) {
+    static_assert(LK >= 1, "level 0 has no children: sp_eval_team<TN, 0>");
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(WL);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const int T = __builtin_amdgcn_readfirstlane(X->T), off = __builtin_amdgcn_readfirstlane(off_);
+    const int ln = min(lane_in_team + off, SP_T - 1);  // this lane's turn (lanes outside any team: clamped, never stored)
+    const int rows = T + 4;
+    float* const eb = WL + (team_on ? team_in_wave : 0) * (SP_EV_ENT * rows * 4);  // [SP_EV_ENT][rows][4]
+    if (team_on)
+        for (int r = lane_in_team; r < SP_EV_ENT * rows; r += T - off) *reinterpret_cast<SpF4*>(eb + 4 * r) = SpF4{0.f, 0.f, 0.f, 0.f};
+    const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
+    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)min(X->n_left, SP_NT_ROWS - 1) * (SP_NT_ROWS * SP_NT_STRIDE);
+    const int last = max(end - 1, 0);
+    auto ld_slot = [&](int i) -> u32 { return Wg->elist[min(i, last)] & (SP_CAP - 1); };
+    auto ld_hdr = [&](u32 slot) -> u64 { return *reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off); };
+    auto ld_m = [&](u64 hdr) -> float { return nt_rows[min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln]; };
+    auto ld_ent = [&](u32 at) -> u32 { return Wg->pool[min(at, (u32)(SP_POOL - 1))]; };
+    auto ld_val = [&](u32 ent) -> SpF4 {  // one 16-byte load (member-wise: SP_HBM is an address space)
+        const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(Wg->node[SP_ENT_SLOT(ent)].val[ln]);
+        SpF4 r;
+        r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
+        return r;
+    };
+    mj_team_sync<64>();
+
+    // the pipeline: state 0 = current, 1 = next (header, first entries and not_tsumo value loaded), 2 = header loaded, 3 = slot
+    int i = first;
+    bool has = team_on && i < end;
+    u32 s0 = ld_slot(i), s1 = ld_slot(i + stride), s2 = ld_slot(i + 2 * stride), s3 = ld_slot(i + 3 * stride);
+    u64 h0 = ld_hdr(s0), h1 = ld_hdr(s1), h2 = ld_hdr(s2);
+    float m_raw = ld_m(h0), m_nxt = ld_m(h1);
+    u32 ent[SP_EV_ENT], entn[SP_EV_ENT], nent[SP_EV_ENT];
+#pragma unroll
+    for (int q = 0; q < SP_EV_ENT; q++) {
+        ent[q] = ld_ent((u32)h0 + q);
+        entn[q] = ld_ent((u32)h0 + SP_EV_ENT + q);
+        nent[q] = ld_ent((u32)h1 + q);
+    }
+    SpF4 v[SP_EV_ENT];
+#pragma unroll
+    for (int q = 0; q < SP_EV_ENT; q++) v[q] = ld_val(ent[q]);
+
+    int c0 = 0;
+    float my_m = m_raw != 0.f ? m_raw : 1.f, my_r = sp_rcp_refined(my_m);
+    float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;
+    // discard_slow (calc.rs:570-637) fold state of the draw entry in progress
+    float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
+    int max_value = INT_MIN, max_key = sp_discard_key(T_UNK);
+
+    while (__ballot(has) != 0ull) {
+        const int n_ch = (int)((h0 >> 32) & 0xFFFF);
+        // ---- fold SP_EV_ENT children; a completed draw entry parks its row
+        int k = 0;
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) {
+            const u32 e = ent[q];
+            const bool valid = has && c0 + q < n_ch;
+            const bool bad = (e & SP_ENT_INVALID) != 0;
+            if (valid && bad) X->overflow = 1;
+            const int value = __float_as_int(v[q].w);  // `as i32` of the child's EV (maximize_win_prob = false)
+            const int key = (int)SP_ENT_KEY(e);        // cmp_discard_priority(dt, max_tile) > 0  <=>  key > max_key
+            const bool better = valid && !bad && (value > max_value || (value == max_value && key > max_key));
+            nx_t = better ? v[q].x : nx_t;
+            nx_w = better ? v[q].y : nx_w;
+            nx_e = better ? v[q].z : nx_e;
+            max_value = better ? value : max_value;
+            max_key = better ? key : max_key;
+            if (valid && (e & SP_ENT_LAST)) {  // last child of this draw entry (uniform in the team)
+                const int cnt = min(max((int)SP_ENT_COUNT(e), 1), 4);
+                const float tpc = cnt == 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
+                float* row = eb + (k * rows + ln) * 4;
+                row[0] = nx_t;
+                row[1] = nx_w;
+                row[2] = nx_e;
+                row[7] = tpc * m_raw;  // A[ln], read with row ln + 1
+                k++;
+                nx_t = nx_w = nx_e = -3.40282347e+38f;
+                max_value = INT_MIN;
+                max_key = sp_discard_key(T_UNK);
+            }
+        }
+        c0 += SP_EV_ENT;
+        const bool done = has && c0 >= n_ch;
+        // ---- the loads of the next step: its children's values, the entries after them, and (used only when a state ends)
+        // the pipeline's tail.  Issued by every lane whether or not its team advances: no divergent control flow.
+        u32 up[SP_EV_ENT], upn[SP_EV_ENT], nent2[SP_EV_ENT];
+        SpF4 vn[SP_EV_ENT];
+        const u32 up_off = done ? (u32)h1 + SP_EV_ENT : (u32)h0 + (u32)c0 + SP_EV_ENT;
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) up[q] = done ? nent[q] : entn[q];
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) vn[q] = ld_val(up[q]);
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) upn[q] = ld_ent(up_off + q);
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) nent2[q] = ld_ent((u32)h2 + q);
+        const float m_n2 = ld_m(h2);
+        const u64 h3 = ld_hdr(s3);
+        const u32 s4 = ld_slot(i + 4 * stride);
+
+        // ---- accumulate (calc.rs:486-548) the parked entries of every team, entry by entry, turns in groups of four
+        mj_team_sync<64>();
+        const int kmax = __ballot(k >= 4) ? 4 : __ballot(k >= 3) ? 3 : __ballot(k >= 2) ? 2 : __ballot(k >= 1) ? 1 : 0;
+        for (int en = 0; en < kmax; en++) {
+            if (en < k) {
+                const float* er = eb + en * rows * 4;
+                sp_static_for<0, (TN + 3) / 4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if (4 * g + 3 < off || 4 * g >= T) return;  // scalar: turns before `off` have no lane, rows past T are zero
+                    SpF4 r[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) r[jj] = *reinterpret_cast<const SpF4*>(er + (4 * g + jj + 1) * 4);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        constexpr int j0 = 4 * g;
+                        const int j = j0 + jj;
+                        float prob = sp_div_domain(r[jj].w, my_m, my_r);
+                        prob = ln <= j ? prob : 0.f;
+                        if constexpr (LK == 1) acc_t += prob;
+                        else acc_t += prob * r[jj].x;
+                        acc_w += prob * r[jj].y;
+                        acc_e += prob * r[jj].z;
+                    }
+                });
+            }
+        }
+        mj_team_sync<64>();  // the parked rows are consumed: the next step may overwrite them
+
+        // ---- end of a state: its values, then the pipeline moves up
+        if (done) {
+            SP_HBM SpF4* dst = reinterpret_cast<SP_HBM SpF4*>(Wg->node[s0].val[ln]);
+            dst->x = acc_t; dst->y = acc_w; dst->z = acc_e; dst->w = __int_as_float((int)acc_e);
+            s0 = s1; s1 = s2; s2 = s3; s3 = s4;
+            h0 = h1; h1 = h2; h2 = h3;
+            m_raw = m_nxt; m_nxt = m_n2;
+#pragma unroll
+            for (int q = 0; q < SP_EV_ENT; q++) nent[q] = nent2[q];
+            c0 = 0;
+            my_m = m_raw != 0.f ? m_raw : 1.f;
+            my_r = sp_rcp_refined(my_m);
+            acc_t = acc_w = acc_e = 0.f;
+            i += stride;
+            has = i < end;
+        }
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) {
+            ent[q] = up[q];
+            entn[q] = upn[q];
+            v[q] = vn[q];
+        }
     }
 }
 
@@ -1696,19 +1868,27 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                     const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
                     float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
                     const long long t_ev0 = P.prof ? wall_clock64() : 0;
-                    if (tw < tpw && b + team < e) {
+                    if (lv == 0) {
+                        if (tw < tpw && b + team < e) {
+                            if (T <= 8) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else if (T <= 16) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            else sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
+                        }
+                    } else {
+                        // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
+                        const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
+                        const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
+                        float* wl_lds = s_tm.ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
+                        const bool on = tw < tpw2;
                         if (T <= 8) {
-                            if (lv == 0) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else if (lv == 1) sp_eval_team<8, 1>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else sp_eval_team<8, 2>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<8, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
                         } else if (T <= 16) {
-                            if (lv == 0) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else if (lv == 1) sp_eval_team<16, 1>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else sp_eval_team<16, 2>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            if (lv == 1) sp_eval_wave<16, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<16, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
                         } else {
-                            if (lv == 0) sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else if (lv == 1) sp_eval_team<17, 1>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else sp_eval_team<17, 2>(W, &X, lds, b + team, e, n_teams, ln, off);
+                            if (lv == 1) sp_eval_wave<17, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<17, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
                         }
                     }
                     if (P.prof && (tid & 63) == 0) atomicAdd(&P.err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
