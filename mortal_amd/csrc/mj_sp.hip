@@ -171,7 +171,7 @@ MJD void sp_key(const SpState& s, u64 k[4]) {
     k[3] = s.w.sz | ((u64)((s.akas >> 3) & 7) << 48);
 }
 
-struct SpCtx {  // per-decision constants (LDS)
+struct alignas(16) SpCtx {  // per-decision constants (LDS; the per-phase pipeline of mj_sp2.hip keeps a copy per row in HBM)
     Melds melds;
     int len_div3, bakaze, jikaze, is_menzen, num_doras_in_fuuro, n_dora, calc_double_riichi, calc_haitei,
         prefer_riichi, T, n_left;
@@ -1615,10 +1615,10 @@ __device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork
 
 // Sorting of the candidates + the encoder block of obs v4 (rows 889..1011).
 template <bool WAVE, int NT, class OutP>
-__device__ __forceinline__ void sp_row_write(SpWork* W, SpCtx& X, const SpRowInfo& R, const int tid, OutP out, float* tv_area) {
+__device__ __forceinline__ void sp_row_write(const SpNode* nodes, SpCtx& X, const SpRowInfo& R, const int tid, OutP out, float* tv_area) {
     constexpr int O_SP = 889;  // Lay<4>::sp
     const int n_cand = R.n_cand, cur_shanten = R.cur_shanten, T = R.T, last_tsumo = R.last_tsumo;
-    const bool with_probs = WAVE ? false : R.with_probs;  // a row processed by one wavefront never has a state graph
+    const bool with_probs = R.with_probs && tv_area != nullptr;  // (the queue tail of mj_k_sp: rows without a state graph, no staging area)
     const bool can_discard0 = R.can_discard0, after_riichi = R.after_riichi;
         // ---- sort (calc.rs:181-188 / 196-199) + encode (obs_repr.rs:564-692)
         if (tid < n_cand) {  // one lane per candidate fetches its turn-0 values (side by side, not a chain of dependent loads)
@@ -1626,7 +1626,7 @@ __device__ __forceinline__ void sp_row_write(SpWork* W, SpCtx& X, const SpRowInf
             X.order[c] = c;
             const int slot = X.cand_slot[c];
             if (with_probs && slot >= 0) {  // Candidate::from clamps (candidate.rs:46-70); shanten 0 => tenpai = 1
-                const SpNode& nd = W->node[slot];
+                const SpNode& nd = nodes[slot];
                 const float tp = cur_shanten == 0 ? 1.f : nd.val[0][0];
                 X.cand_tp0[c] = fminf(fmaxf(tp, 0.f), 1.f);
                 X.cand_wp0[c] = fminf(fmaxf(nd.val[0][1], 0.f), 1.f);
@@ -1705,7 +1705,7 @@ __device__ __forceinline__ void sp_row_write(SpWork* W, SpCtx& X, const SpRowInf
                     {
                         float tpv = 0.f, wpv = 0.f, evv = 0.f;
                         if (turn < T) {
-                            const SpNode& nd = W->node[X.cand_slot[can_discard0 ? c : first]];
+                            const SpNode& nd = nodes[X.cand_slot[can_discard0 ? c : first]];
                             tpv = cur_shanten == 0 ? 1.f : fminf(fmaxf(nd.val[turn][0], 0.f), 1.f);
                             wpv = fminf(fmaxf(nd.val[turn][1], 0.f), 1.f);
                             evv = fmaxf(nd.val[turn][2], 0.f);
@@ -1758,7 +1758,7 @@ __device__ __noinline__ void sp_light_row(const uint32_t* rows, const TableOne* 
     const SpRowInfo R = sp_row_front<true, 64>((const SP_HBM uint32_t*)rows, (const SP_HBM TableOne*)snap, W, A->X, &A->st, lane, row, out, nullptr);
     if (R.ok) {
         if (R.with_probs) A->X.overflow = 1;  // cannot happen: the row order put a row WITH a graph into the tail of the queue
-        sp_row_write<true, 64>(W, A->X, R, lane, out, nullptr);
+        sp_row_write<true, 64>((const SpNode*)nullptr, A->X, R, lane, out, nullptr);
         if (A->X.overflow && lane == 0) __hip_atomic_fetch_add(&((SP_HBM unsigned long long*)err)[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0) {
@@ -1783,6 +1783,9 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     // the hash tags start empty: zeroed once when the work area is allocated, and every row clears the tags it set
 
     const long long t_wg0 = P.prof ? wall_clock64() : 0;  // MJ_SP_PROF: workgroup lifetime / queue + reset time (err[19..22])
+#ifndef MJ_EMU
+    const long long c_wg0 = P.prof ? clock64() : 0;       // the same lifetime in shader-clock cycles (s_memtime): err[24] / err[19] x 100 MHz = the clock the kernel ran at
+#endif
     long long t_pop = 0, t_reset = 0;
     // the queue is ordered by cost class (mj_k_order_*): the rows of class 7 (no state graph at all) form its tail
     const int n_heavy = P.n_rows - P.queue[1 + 7];
@@ -1899,7 +1902,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             t_4 = wall_clock64();
         }
 
-        sp_row_write<false, SP_THREADS>(W, X, R, tid, out, s_tm.ev);
+        sp_row_write<false, SP_THREADS>(W->node, X, R, tid, out, s_tm.ev);
         __syncthreads();
         if (tid == 0) {
             long long t_5 = wall_clock64();
@@ -1934,6 +1937,9 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     if (P.prof && tid == 0) {
         const unsigned long long life = (unsigned long long)(wall_clock64() - t_wg0);
         atomicAdd(&P.err[19], life);
+#ifndef MJ_EMU
+        atomicAdd(&P.err[24], (unsigned long long)(clock64() - c_wg0));
+#endif
         atomicMax(&P.err[20], life);
         atomicAdd(&P.err[21], (unsigned long long)t_pop);
         atomicAdd(&P.err[22], (unsigned long long)t_reset);

@@ -70,6 +70,18 @@ def test_lockstep_staggered_start_matches_benchmark_protocol(oracle):
     assert st["generations"][0] >= 3 and st["games_checked"] >= 512
 
 
+def test_lockstep_per_phase_pipeline(oracle, monkeypatch):
+    """MJ_SP_PIPELINE=phase: the per-phase SP pipeline (mj_sp2.hip; round 4's measured alternative to one row per workgroup, slower
+    for lack of locality but bit-identical) against the oracle: 256 tables at the start of E1 (the heaviest graphs, chunks and
+    evaluation blocks mixing rows) and the benchmark's refill mode."""
+    monkeypatch.setenv("MJ_SP_PIPELINE", "phase")
+    st = parity_util.run_lockstep(oracle, 256, version=4, max_cycles=40, obs_every=4, sp_rows_checked=True, policy="greedy", threads=8)
+    assert st["obs_checked"] > 1500 and st["counters"]["sp_overflow"] == 0
+    st = parity_util.run_lockstep(oracle, 48, version=4, max_cycles=20000, obs_every=6, sp_rows_checked=True, refill=12,
+                                  min_games=2, deal_algo=1, threads=8)
+    assert st["generations"][0] >= 2 and st["counters"]["sp_overflow"] == 0
+
+
 def test_lockstep_quick_eval_disabled(oracle):
     """enable_quick_eval = False (mortal.rs:210-250): single-candidate discards get a row, every ankan/kakan decision
     gets a kan-select row."""

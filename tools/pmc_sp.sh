@@ -2,6 +2,7 @@
 # PMC counters of mj_k_sp only (--kernel-include-regex), separate passes, default bench workload at a reduced table count.
 #   tools/pmc_sp.sh <outdir-tag> [tables] [extra bench flags]
 # Output: gpurun_out/<tag>/<pass>.txt with per-launch averages; tools/summarize_sp_pmc.py folds them into profiles/.
+# PMC_SP_PASSES="1 2" restricts the run to those passes (a quick instruction-count / activity check of a kernel variant).
 OUT=/root/repo/gpurun_out/${1:-pmc_sp}; TABLES=${2:-65536}; shift; shift
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 i=0
@@ -13,6 +14,7 @@ for set in \
   "FETCH_SIZE TCP_TOTAL_ACCESSES_sum" \
   "WRITE_SIZE TCP_TCC_READ_REQ_sum"; do
   i=$((i+1)); tag=p$i
+  if [ -n "$PMC_SP_PASSES" ] && ! echo " $PMC_SP_PASSES " | grep -q " $i "; then continue; fi
   timeout 240 rocprofv3 --pmc $set --kernel-include-regex mj_k_sp --output-format csv -d $OUT/$tag -- \
       python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-matrix --version 4 --tables $TABLES "$@" > $OUT/$tag.log 2>&1
   python3 - <<PY | tee $OUT/$tag.txt
