@@ -1146,39 +1146,46 @@ __device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     float my_m = m_raw != 0.f ? m_raw : 1.f, my_r = sp_rcp_refined(my_m);
     float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;
     // discard_slow (calc.rs:570-637) fold state of the draw entry in progress
+    // The fold's order (calc.rs:600-615: larger (int)EV first, then the discard priority) as ONE integer: (int)EV << 9 | order key.
+    // (int)EV is non-negative and below 2^19 (six-fold yakuman of the dealer: 288,000), the key is 9 bits wide; the initial
+    // value loses against every child (INT_MIN there, the unknown tile's key 63 - 37 here: any real key is larger).
     float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
-    int max_value = INT_MIN, max_key = sp_discard_key(T_UNK);
+    int max_pack = -1;
+    float* const row0 = eb + ln * 4;  // this lane's row of the first parked entry
 
     while (__ballot(has) != 0ull) {
         const int n_ch = (int)((h0 >> 32) & 0xFFFF);
         // ---- fold SP_EV_ENT children; a completed draw entry parks its row
-        int k = 0;
+        int k = 0, koff = 0;
 #pragma unroll
         for (int q = 0; q < SP_EV_ENT; q++) {
             const u32 e = ent[q];
             const bool valid = has && c0 + q < n_ch;
             const bool bad = (e & SP_ENT_INVALID) != 0;
             if (valid && bad) X->overflow = 1;
-            const int value = __float_as_int(v[q].w);  // `as i32` of the child's EV (maximize_win_prob = false)
-            const int key = (int)SP_ENT_KEY(e);        // cmp_discard_priority(dt, max_tile) > 0  <=>  key > max_key
-            const bool better = valid && !bad && (value > max_value || (value == max_value && key > max_key));
+            // `as i32` of the child's EV (maximize_win_prob = false) above the discard order key (cmp_discard_priority > 0 <=> larger key)
+            const int pack = (__float_as_int(v[q].w) << 9) | (int)SP_ENT_KEY(e);
+#ifdef MJ_EMU
+            // the packing's range (the team's first lane reads a turn its children never wrote — nobody reads what it folds)
+            if (valid && !bad && lane_in_team > 0 && ((unsigned)__float_as_int(v[q].w) >> 22)) X->overflow = 1;
+#endif
+            const bool better = valid && !bad && pack > max_pack;
             nx_t = better ? v[q].x : nx_t;
             nx_w = better ? v[q].y : nx_w;
             nx_e = better ? v[q].z : nx_e;
-            max_value = better ? value : max_value;
-            max_key = better ? key : max_key;
+            max_pack = better ? pack : max_pack;
             if (valid && (e & SP_ENT_LAST)) {  // last child of this draw entry (uniform in the team)
-                const int cnt = min(max((int)SP_ENT_COUNT(e), 1), 4);
-                const float tpc = cnt == 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
-                float* row = eb + (k * rows + ln) * 4;
+                const u32 cnt = SP_ENT_COUNT(e);  // 1..4 copies of the drawn tile
+                const float tpc = cnt <= 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
+                float* row = row0 + koff;
                 row[0] = nx_t;
                 row[1] = nx_w;
                 row[2] = nx_e;
                 row[7] = tpc * m_raw;  // A[ln], read with row ln + 1
                 k++;
+                koff += rows * 4;
                 nx_t = nx_w = nx_e = -3.40282347e+38f;
-                max_value = INT_MIN;
-                max_key = sp_discard_key(T_UNK);
+                max_pack = -1;
             }
         }
         c0 += SP_EV_ENT;
@@ -1194,11 +1201,19 @@ __device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
         for (int q = 0; q < SP_EV_ENT; q++) vn[q] = ld_val(up[q]);
 #pragma unroll
         for (int q = 0; q < SP_EV_ENT; q++) upn[q] = ld_ent(up_off + q);
+        // the pipeline's tail moves only when some team finishes its state in this step (a wavefront-uniform branch)
+        float m_n2 = 0.f;
+        u64 h3 = 0ull;
+        u32 s4 = 0u;
 #pragma unroll
-        for (int q = 0; q < SP_EV_ENT; q++) nent2[q] = ld_ent((u32)h2 + q);
-        const float m_n2 = ld_m(h2);
-        const u64 h3 = ld_hdr(s3);
-        const u32 s4 = ld_slot(i + 4 * stride);
+        for (int q = 0; q < SP_EV_ENT; q++) nent2[q] = 0u;
+        if (__ballot(done) != 0ull) {
+#pragma unroll
+            for (int q = 0; q < SP_EV_ENT; q++) nent2[q] = ld_ent((u32)h2 + q);
+            m_n2 = ld_m(h2);
+            h3 = ld_hdr(s3);
+            s4 = ld_slot(i + 4 * stride);
+        }
 
         // ---- accumulate (calc.rs:486-548) the parked entries of every team, entry by entry, turns in groups of four
         mj_team_sync<64>();
