@@ -103,7 +103,7 @@ def fake_q_values(masks, rows, cycle, seed):
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
                  policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
                  policy="random", guard=False, oracle_obs=False, compare_logs=False, deal_algo=0, refill=0, min_games=2,
-                 threads=0, obs_cycles=None, pool_cls=None, stagger=0):
+                 threads=0, obs_cycles=None, pool_cls=None, stagger=0, obs_slice=0):
     """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch.
 
     refill = nonce stride: finished slots restart on (nonce + stride, key) on both sides (the pool's steady-state mode,
@@ -111,7 +111,9 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     stagger = S (needs refill): the protocol bench.py times — every slot is parked before the first cycle and slot t enters play
     at cycle ((t * 2654435761 mod 2^32) >> 8) % S through the refill path (mj_pool_set_start_stagger, mj_step.hip: mj_k_park /
     mj_k_refill), i.e. on (nonce + stride, key) as game id t + n_tables; the oracle slot idles until that cycle the same way.
-    obs_cycles: explicit set of cycles whose obs are compared (overrides obs_every); threads: oracle encode threads."""
+    obs_cycles: explicit set of cycles whose obs are compared (overrides obs_every); threads: oracle encode threads;
+    obs_slice: compare the obs in slices of that many rows (the oracle encodes slice by slice: the 65,536-table pool's 8 GB
+    batch never exists twice on the host)."""
     import torch
 
     if pool_cls is None:
@@ -180,7 +182,8 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         masks_g = torch.ones((n_g, 46), dtype=torch.bool, device=pool.device)
         obs_g, masks_g = pool.encode(0, obs_g, masks_g)
         want_obs = compare_obs and ((cycle in obs_cycles) if obs_cycles is not None else (cycle % obs_every == 0))
-        obs_o, masks_o = arena.encode(0, n, want_obs=want_obs, threads=threads)
+        sliced = bool(want_obs and obs_slice and n > obs_slice)
+        obs_o, masks_o = arena.encode(0, n, want_obs=want_obs and not sliced, threads=threads)
         mg = masks_g.cpu().numpy().astype(np.uint8)
         if not (mg == masks_o).all():
             r = int(np.argwhere((mg != masks_o).any(axis=1))[0][0])
@@ -190,7 +193,22 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
                 f" state: {arena.player_state(int(rows_o[r][0]), int(rows_o[r][1])).snapshot()}")
         if n and not bool(masks_g.any(dim=1).all()):
             raise AssertionError(f"cycle {cycle}: a decision row without any legal action")
-        if want_obs and n:
+        if sliced:
+            for r0 in range(0, n, obs_slice):
+                r1 = min(n, r0 + obs_slice)
+                og = obs_g[r0:r1].cpu().numpy()
+                oo, _ = arena.encode(r0, r1, want_obs=True, threads=threads)
+                if not (np.isfinite(og).all() and og.min() >= 0.0 and og.max() <= 1.0):
+                    raise AssertionError(f"cycle {cycle}: obs value outside [0, 1] in rows {r0}..{r1}")
+                a = np.ascontiguousarray(og[:, :n_cmp]).view(np.uint32)
+                b = np.ascontiguousarray(oo[:, :n_cmp]).view(np.uint32)
+                if not (a == b).all():
+                    bad = np.argwhere(a != b)
+                    r = int(bad[0][0])
+                    raise AssertionError(f"cycle {cycle}: obs mismatch at row {r0 + r} {rows_o[r0 + r]}; differing obs rows "
+                                         f"{sorted(set(int(x[1]) for x in bad if x[0] == r))[:40]}")
+                stats["obs_checked"] += r1 - r0
+        elif want_obs and n:
             og = obs_g.cpu().numpy()
             # obs_repr.rs:626-628: every plane value lies in [0, 1] (the reference's debug assertion on the finished tensor)
             if not (np.isfinite(og).all() and og.min() >= 0.0 and og.max() <= 1.0):

@@ -152,6 +152,16 @@ def test_lockstep_obs_v1_v2(oracle, version):
     assert st["obs_checked"] > 40000
 
 
+def test_full_size_pool_against_the_oracle(oracle):
+    """The headline pool size against the ORACLE (the 65,536-table pool had only been compared with a smaller HIP
+    pool): 65,536 tables, obs v3, uniform-random legal policy, the first 48 cycles (~3.2 M decisions) — row lists and 46-wide
+    masks of every decision of every cycle, the whole obs tensor on sampled cycles, the step counter.  The oracle arena holds
+    all 65,536 games and encodes on 16 threads."""
+    st = parity_util.run_lockstep(oracle, 65536, version=3, max_cycles=48, obs_every=12, threads=16, obs_slice=8192, verbose=True)
+    assert st["rows"] > 3_000_000 and st["obs_checked"] > 250_000 and st["cycles"] == 48
+    assert st["counters"]["steps"] == st["oracle_steps"] == 48 * 65536
+
+
 @pytest.mark.parametrize("version,cycles", [(3, 48), (4, 14)])
 def test_full_size_pool_is_size_independent(version, cycles):
     """BASELINE's 65,536-table configuration: tables are independent, so the first 1,024 tables of the big pool must
