@@ -1268,218 +1268,6 @@ __device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     }
 }
 
-// ---- Levels > 0, second form (round 4): the BATCH STREAM.  sp_eval_wave above walks each team through "its" states with a
-// hand-built prefetch queue (slot -> header -> entries -> values, four states deep) and needs the level sorted by cost so that the
-// teams of a wavefront finish together.  Here a wavefront takes BLOCKS of up to 64 consecutive states of the level list, loads the 64
-// headers once (one lane per state, into LDS), and cuts the block's work — batches of SP_EV_ENT children — into `tpw` contiguous
-// pieces of equal length, one per team (a prefix sum over the lanes: a state's batches stay with one team).  The teams then run
-// their streams in lock-step: step j folds batch j while the child values of batch j + 1 and the child-list entries of batch j + 2
-// are in flight — one flat software pipeline over the stream index, whatever the state boundaries; a batch that opens a state
-// resets the sums, one that closes it stores the values.  No cost sort (the cut balances the teams exactly), no header queue, no
-// per-step select chains.  Same arithmetic and order per state as sp_eval_wave / sp_eval_team.
-#define SP_ST_CAP 512                     // batches of a block's stream (more: the block is cut short)
-struct SpStreamLds {                      // per wavefront
-    u64 hdr[64];                          // node headers of the block's states (child_off | n_ch << 32 | sumreq << 48 | n_ent << 56)
-    u32 slot[64];
-    unsigned short batch[SP_ST_CAP + 8];  // state | batch-of-that-state << 6
-    unsigned short tstart[66];            // first stream position of every team (+ end)
-};
-template <int TN, int LK>
-__device__ __noinline__ void sp_eval_stream(SpWork* W, SpCtx* X, float* WL, SpStreamLds* SL, int b, int e, int off_, int wave, int n_waves) {
-    static_assert(LK >= 1, "level 0 has no children: sp_eval_team<TN, 0>");
-    SP_ASSUME_LDS(X);
-    SP_ASSUME_LDS(WL);
-    SP_ASSUME_LDS(SL);
-    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const int lane = threadIdx.x & 63;
-    const int T = __builtin_amdgcn_readfirstlane(X->T), off = __builtin_amdgcn_readfirstlane(off_);
-    const int TW = T - off, rows = T + 4;
-    const int tpw = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
-    const int tw = lane / TW, lane_in_team = lane - tw * TW;
-    const bool team_on = tw < tpw;
-    const int ln = min(lane_in_team + off, SP_T - 1);  // this lane's turn (lanes outside any team: clamped, never stored)
-    float* const eb = WL + (team_on ? tw : 0) * (SP_EV_ENT * rows * 4);  // [SP_EV_ENT][rows][4]
-    float* const row0 = eb + ln * 4;
-    const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
-    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)min(X->n_left, SP_NT_ROWS - 1) * (SP_NT_ROWS * SP_NT_STRIDE);
-    auto ld_ent = [&](u32 at) -> u32 { return Wg->pool[min(at, (u32)(SP_POOL - 1))]; };
-    auto ld_val = [&](u32 ent) -> SpF4 {  // one 16-byte load
-        const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(Wg->node[SP_ENT_SLOT(ent)].val[ln]);
-        SpF4 r;
-        r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
-        return r;
-    };
-    if (team_on)
-        for (int r = lane_in_team; r < SP_EV_ENT * rows; r += TW) *reinterpret_cast<SpF4*>(eb + 4 * r) = SpF4{0.f, 0.f, 0.f, 0.f};
-
-    for (int blk0 = b + wave * 64; blk0 < e; blk0 += n_waves * 64)
-    for (int b0 = blk0, blk_end = min(blk0 + 64, e); b0 < blk_end;) {
-        int n = blk_end - b0;
-        // ---- the block's headers; batches per state; the stream cut into tpw pieces of equal length
-        mj_team_sync<64>();  // (the previous block's streams are done with SL)
-        u32 my_slot = 0;
-        u64 my_hdr = 0;
-        if (lane < n) {
-            my_slot = Wg->list[b0 + lane] & (SP_CAP - 1);
-            my_hdr = *reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[my_slot].child_off);
-        }
-        const int my_nch = (int)((my_hdr >> 32) & 0xFFFF);
-        int nb = lane < n ? max(1, (my_nch + SP_EV_ENT - 1) / SP_EV_ENT) : 0;
-        int incl = (int)sp_wave_scan_incl((u32)nb);
-        // a block whose stream would not fit is cut short (the rest is the wavefront's next block: b0 moves by what was taken)
-        const int fit = __popcll(__ballot(lane < n && incl <= SP_ST_CAP));
-        int taken = n;
-        if (fit < n) {
-            taken = max(fit, 1);
-            n = taken;
-            if (lane >= n) nb = 0;
-            incl = (int)sp_wave_scan_incl((u32)nb);
-        }
-        const int total = min(__shfl(incl, 63), SP_ST_CAP);
-        const int excl = incl - nb;
-        const int per = max(1, (total + tpw - 1) / tpw);  // stream positions per team
-        const int my_team = min(excl / per, tpw - 1);
-        if (lane < n) {
-            SL->hdr[lane] = my_hdr;
-            SL->slot[lane] = my_slot;
-            for (int k = 0; k < nb; k++)
-                if (excl + k < SP_ST_CAP) SL->batch[excl + k] = (unsigned short)(lane | (k << 6));
-        }
-        if (lane <= tpw) SL->tstart[lane] = (unsigned short)total;  // default: empty piece at the end
-        mj_team_sync<64>();
-        {   // the first state of every team marks the team's start (teams without a state keep `total`, fixed below)
-            const int prev_team = __shfl_up(my_team, 1);
-            if (lane < n && (lane == 0 || prev_team != my_team)) SL->tstart[my_team] = (unsigned short)excl;
-        }
-        mj_team_sync<64>();
-        // an empty team's start = the next non-empty team's start: a suffix minimum over <= 64 entries, lane = team
-        {
-            int st = lane <= tpw ? (int)SL->tstart[lane] : total;
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_down(st, d);
-                if (lane + d < 64) st = min(st, o);
-            }
-            mj_team_sync<64>();
-            if (lane <= tpw) SL->tstart[lane] = (unsigned short)st;
-        }
-        mj_team_sync<64>();
-        const int my_first = team_on ? (int)SL->tstart[tw] : total, my_end = team_on ? (int)SL->tstart[tw + 1] : total;
-        const int my_len = my_end - my_first;
-        int nsteps = my_len;
-        for (int d = 32; d > 0; d >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, d));
-
-        // ---- the pipeline over the stream index
-        auto batch_at = [&](int j) -> int {  // state | batch << 6 of this team's j-th batch (clamped: a finished team re-reads its last)
-            return (int)SL->batch[min(my_first + min(j, max(my_len - 1, 0)), SP_ST_CAP - 1)];
-        };
-        auto ents_of = [&](int bt, u32 out[SP_EV_ENT]) {
-            const u64 h = SL->hdr[bt & 63];
-            const u32 at = (u32)h + (u32)(bt >> 6) * SP_EV_ENT;
-#pragma unroll
-            for (int q = 0; q < SP_EV_ENT; q++) out[q] = ld_ent(at + q);
-        };
-        int bt0 = batch_at(0), bt1 = batch_at(1), bt2 = batch_at(2);
-        u32 e0[SP_EV_ENT], e1[SP_EV_ENT], e2[SP_EV_ENT];
-        ents_of(bt0, e0);
-        ents_of(bt1, e1);
-        SpF4 v[SP_EV_ENT];
-#pragma unroll
-        for (int q = 0; q < SP_EV_ENT; q++) v[q] = ld_val(e0[q]);
-        float m_raw = nt_rows[min((int)((SL->hdr[bt0 & 63] >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln];
-        float my_m = 1.f, my_r = 1.f;
-        float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;
-        float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
-        int max_pack = -1;
-        for (int j = 0; j < nsteps; j++) {
-            const bool has = j < my_len;
-            const u64 h0 = SL->hdr[bt0 & 63];
-            const int n_ch = (int)((h0 >> 32) & 0xFFFF), c0 = (bt0 >> 6) * SP_EV_ENT;
-            if (c0 == 0) {  // the batch opens its state
-                my_m = m_raw != 0.f ? m_raw : 1.f;
-                my_r = sp_rcp_refined(my_m);
-                acc_t = acc_w = acc_e = 0.f;
-            }
-            // ---- loads of the next steps: values of batch j + 1, entries of batch j + 2, the not_tsumo value of batch j + 1's state
-            SpF4 vn[SP_EV_ENT];
-#pragma unroll
-            for (int q = 0; q < SP_EV_ENT; q++) vn[q] = ld_val(e1[q]);
-            ents_of(bt2, e2);
-            const float m_nx = nt_rows[min((int)((SL->hdr[bt1 & 63] >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln];
-            const int bt3 = batch_at(j + 3);
-            // ---- fold SP_EV_ENT children; a completed draw entry parks its row
-            int k = 0, koff = 0;
-#pragma unroll
-            for (int q = 0; q < SP_EV_ENT; q++) {
-                const u32 en = e0[q];
-                const bool valid = has && c0 + q < n_ch;
-                const bool bad = (en & SP_ENT_INVALID) != 0;
-                if (valid && bad) X->overflow = 1;
-                const int pack = (__float_as_int(v[q].w) << 9) | (int)SP_ENT_KEY(en);  // (int)EV above the discard order key (sp_eval_wave)
-#ifdef MJ_EMU
-                if (valid && !bad && lane_in_team > 0 && ((unsigned)__float_as_int(v[q].w) >> 22)) X->overflow = 1;
-#endif
-                const bool better = valid && !bad && pack > max_pack;
-                nx_t = better ? v[q].x : nx_t;
-                nx_w = better ? v[q].y : nx_w;
-                nx_e = better ? v[q].z : nx_e;
-                max_pack = better ? pack : max_pack;
-                if (valid && (en & SP_ENT_LAST)) {  // last child of this draw entry (uniform in the team)
-                    const u32 cnt = SP_ENT_COUNT(en);
-                    const float tpc = cnt <= 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
-                    float* row = row0 + koff;
-                    row[0] = nx_t;
-                    row[1] = nx_w;
-                    row[2] = nx_e;
-                    row[7] = tpc * m_raw;  // A[ln], read with row ln + 1
-                    k++;
-                    koff += rows * 4;
-                    nx_t = nx_w = nx_e = -3.40282347e+38f;
-                    max_pack = -1;
-                }
-            }
-            // ---- accumulate (calc.rs:486-548) the parked entries of every team, entry by entry, turns in groups of four
-            mj_team_sync<64>();
-            const int kmax = __ballot(k >= 4) ? 4 : __ballot(k >= 3) ? 3 : __ballot(k >= 2) ? 2 : __ballot(k >= 1) ? 1 : 0;
-            for (int en = 0; en < kmax; en++) {
-                if (en < k) {
-                    const float* er = eb + en * rows * 4;
-                    sp_static_for<0, (TN + 3) / 4>([&](auto gc) {
-                        constexpr int g = decltype(gc)::value;
-                        if (4 * g + 3 < off || 4 * g >= T) return;  // scalar: turns before `off` have no lane, rows past T are zero
-                        SpF4 r[4];
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) r[jj] = *reinterpret_cast<const SpF4*>(er + (4 * g + jj + 1) * 4);
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) {
-                            const int jt = 4 * g + jj;
-                            float prob = sp_div_domain(r[jj].w, my_m, my_r);
-                            prob = ln <= jt ? prob : 0.f;
-                            if constexpr (LK == 1) acc_t += prob;
-                            else acc_t += prob * r[jj].x;
-                            acc_w += prob * r[jj].y;
-                            acc_e += prob * r[jj].z;
-                        }
-                    });
-                }
-            }
-            mj_team_sync<64>();  // the parked rows are consumed: the next step may overwrite them
-            if (has && c0 + SP_EV_ENT >= n_ch) {  // the batch closes its state
-                SP_HBM SpF4* dst = reinterpret_cast<SP_HBM SpF4*>(Wg->node[SL->slot[bt0 & 63]].val[ln]);
-                dst->x = acc_t; dst->y = acc_w; dst->z = acc_e; dst->w = __int_as_float((int)acc_e);
-            }
-            bt0 = bt1; bt1 = bt2; bt2 = bt3;
-            m_raw = m_nx;
-#pragma unroll
-            for (int q = 0; q < SP_EV_ENT; q++) {
-                e0[q] = e1[q];
-                e1[q] = e2[q];
-                v[q] = vn[q];
-            }
-        }
-        b0 += taken;  // (a block whose stream did not fit was cut short: its rest comes next)
-    }
-}
-
 // The teams of a wavefront evaluate consecutive states of a level, and the wavefront runs as long as its slowest team: order
 // the level by child-list length (counting sort over 64 buckets, workgroup-wide) so that neighbours cost about the same (key: children + 4 x draw entries).  The
 // order of states inside a level does not touch the results (each state is evaluated on its own).
@@ -2004,7 +1792,6 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
         float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
         SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
     } s_tm;
-    __shared__ SpStreamLds s_stream[SP_THREADS / 64];  // evaluation of the levels > 0: block headers and batch streams, per wavefront
     SpWork* W = P.work + blockIdx.x;
     const int tid = threadIdx.x;
 
@@ -2089,36 +1876,37 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                         atomicAdd(&P.err[18], (unsigned long long)(wall_clock64() - t_2a));
                     }
                 }
-                if (lv == 0) sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);  // (levels > 0: the batch stream balances its teams itself)
+                sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
                 {
                     // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
                     // ... of the turns that can be reached at this level: the first `off` turns are dead (see sp_eval_team)
                     const int off = min(cur_shanten - lv, T - 1), TW = T - off;
+                    const int wl = tid & 63, tpw = min(64 / TW, (SP_EVAL_LDS_FLOATS / (SP_THREADS / 64)) / sp_eval_lds_stride(T));  // lanes, LDS scratch
+                    const int tw = wl / TW, ln = wl - tw * TW;
+                    const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
+                    float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
                     const long long t_ev0 = P.prof ? wall_clock64() : 0;
                     if (lv == 0) {
-                        const int wl = tid & 63, tpw = min(64 / TW, (SP_EVAL_LDS_FLOATS / (SP_THREADS / 64)) / sp_eval_lds_stride(T));  // lanes, LDS scratch
-                        const int tw = wl / TW, ln = wl - tw * TW;
-                        const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
-                        float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
                         if (tw < tpw && b + team < e) {
                             if (T <= 8) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
                             else if (T <= 16) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
                             else sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
                         }
                     } else {
-                        // levels > 0: blocks of 64 states per wavefront, the batch stream (sp_eval_stream)
+                        // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
+                        const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
+                        const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
                         float* wl_lds = s_tm.ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
-                        SpStreamLds* sl = &s_stream[tid >> 6];
-                        const int wave = tid >> 6;
+                        const bool on = tw < tpw2;
                         if (T <= 8) {
-                            if (lv == 1) sp_eval_stream<8, 1>(W, &X, wl_lds, sl, b, e, off, wave, SP_THREADS / 64);
-                            else sp_eval_stream<8, 2>(W, &X, wl_lds, sl, b, e, off, wave, SP_THREADS / 64);
+                            if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<8, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
                         } else if (T <= 16) {
-                            if (lv == 1) sp_eval_stream<16, 1>(W, &X, wl_lds, sl, b, e, off, wave, SP_THREADS / 64);
-                            else sp_eval_stream<16, 2>(W, &X, wl_lds, sl, b, e, off, wave, SP_THREADS / 64);
+                            if (lv == 1) sp_eval_wave<16, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<16, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
                         } else {
-                            if (lv == 1) sp_eval_stream<17, 1>(W, &X, wl_lds, sl, b, e, off, wave, SP_THREADS / 64);
-                            else sp_eval_stream<17, 2>(W, &X, wl_lds, sl, b, e, off, wave, SP_THREADS / 64);
+                            if (lv == 1) sp_eval_wave<17, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<17, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
                         }
                     }
                     if (P.prof && (tid & 63) == 0) atomicAdd(&P.err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
