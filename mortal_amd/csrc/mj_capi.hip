@@ -152,6 +152,7 @@ struct MjPool {
     uint32_t* sp_order = nullptr;   // [max_rows] queue position -> row
     uint8_t* sp_cls = nullptr;      // [max_rows] cost class of a row
     unsigned long long* sp_err = nullptr;
+    int* enc_flag = nullptr;        // [1] an encoder op list overflowed (reported with the SP overflows)
     SpG spg = {};                   // the per-phase SP pipeline's work area (mj_sp2.hip), lazily allocated on the first v4 encode
     bool spg_ready = false;
     int sp_pipeline = -1;           // 0 = mj_k_sp (one row per workgroup), 1 = per-phase pipeline (MJ_SP_PIPELINE=phase), -1 = not decided yet
@@ -353,6 +354,7 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->sp_order);
     hipFree(P->sp_cls);
     hipFree(P->sp_err);
+    hipFree(P->enc_flag);
     if (P->spg_ready) {
         hipFree(P->spg.tag); hipFree(P->spg.node); hipFree(P->spg.pool); hipFree(P->spg.items); hipFree(P->spg.ctx); hipFree(P->spg.rinfo);
         hipFree(P->spg.ctl); hipFree(P->spg_cnt);
@@ -667,6 +669,11 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     ep.rbf_6 = g_tables.rbf_6;
     ep.rbf_12 = g_tables.rbf_12;
     ep.rbf_23 = g_tables.rbf_23;
+    if (!P->enc_flag) {
+        HIP_OK(hipMalloc(&P->enc_flag, sizeof(int)));
+        HIP_OK(hipMemset(P->enc_flag, 0, sizeof(int)));
+    }
+    ep.err_flag = P->enc_flag;
     size_t lds = enc_lds_bytes(ep.version);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -923,10 +930,15 @@ int mj_counters(MjPool* P, uint64_t out[8], void* stream) {
     HIP_OK(hipMemcpy(tmp, P->counters, sizeof tmp, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = tmp[i];
     out[5] = P->cycles;
+    if (P->enc_flag) {
+        int f = 0;
+        HIP_OK(hipMemcpy(&f, P->enc_flag, sizeof f, hipMemcpyDeviceToHost));
+        out[6] = (unsigned long long)f;  // (the SP block's overflows are added below)
+    }
     if (P->sp_err) {
         unsigned long long e2[32];
         HIP_OK(hipMemcpy(e2, P->sp_err, sizeof e2, hipMemcpyDeviceToHost));
-        out[6] = e2[0];
+        out[6] += e2[0];
         out[7] = e2[1];
         if (getenv("MJ_SP_PROF"))
             fprintf(stderr, "[sp prof] rows %llu setup %llu expand %llu evalL0 %llu evalL>0 %llu encode %llu states %llu (wall_clock64 ticks, 100 MHz) | "

@@ -6,11 +6,12 @@
 //                16-byte loads;
 //   2. derive  : unconditional-tenpai discards (agent_helper.rs:100-197: up to 14x34 shanten probes + yaku checks)
 //                spread over the workgroup; per-seat scalars (rank, dora counts, kawa lengths) by single lanes;
-//   3. PASSES x { zero a (C/PASSES)-row LDS tile; scatter; stream the tile out }.
+//   3. record  : the scatter tasks run ONCE and leave what they assign in an op list in LDS (cell, value) + (row, fill value).
 //      The scatter is THREAD-PER-TASK, not row-serial: lane t < 34 owns tile id t, one lane per kawa entry, per meld,
 //      per scalar block — each lane has a short dependency chain and only idempotent or provably unique stores, so
 //      the whole plane stack is decoded in a few hundred cycles of wall time instead of a 1000-load serial chain.
-//      Quarter-size tiles let 4 workgroups share a CU so one group's HBM stores overlap another's gather/scatter.
+//   4. PASSES x { zero a (C/PASSES)-row LDS tile; apply the ops that fall into it; stream the tile out }.
+//      Small tiles let 5 workgroups share a CU, so that one group's HBM stores overlap another's record phase.
 // The 46-byte mask is produced in the same pass.  The v4 SP block (rows 889..1011) is written by mj_sp.hip.
 //
 // Row offsets are compile-time per version (Appendix C of SURVEY.md; each total equals consts.rs:22-25).
@@ -35,14 +36,37 @@ struct EncParams {
     const float* rbf_6;       // [256][2]   cap 6, 3 intervals   (honba, kyotaku)
     const float* rbf_12;      // [256][2]   cap 12, 3 intervals  (doras owned)
     const float* rbf_23;      // [256][3]   cap 23, 4 intervals  (doras unseen)
+    int* err_flag;            // [1] set when a row's op list overflowed (mj_counters reports it with the SP overflows: must stay 0)
 };
 
 #define ENC_THREADS 256
 #ifndef ENC_PASSES
-#define ENC_PASSES 4
+#define ENC_PASSES 8   // output passes per decision row = LDS tile of C / 8 rows.  With the op list a pass is {zero, apply, stream}: more,
+                       // smaller tiles only cost barriers and buy resident workgroups (5 per CU at 8 passes).  Measured (round 4, one box,
+                       // mj_k_encode<3> / <4> per launch): rounds 1-3 code 1.873 / 1.888 ms -> op list with 4 passes 1.756 / 1.790 ->
+                       // 6 passes 1.571 / 1.776 -> 8 passes 1.573 / 1.709 ms (0.67 of the HBM spec peak for both versions)
 #endif
+#ifndef ENC_OPS
+#define ENC_OPS 1024   // cell assignments of one decision row: < 1,000 by construction (96 displayed discards x <= 7 cells, 64 meld tiles,
+                       // 14 hand tiles x 4, the 34-wide rows); measured maximum 395 (enc_ops_high_water); an overflow is reported, never silent
+#endif
+#define ENC_FILLS 512  // whole-row fills of one decision row: <= 4 flag rows per displayed discard + ~100 scalar rows (measured maximum 145)
 #ifndef ENC_NT
 #define ENC_NT 1   // non-temporal stores for the plane stack: it is written once and never re-read by this kernel
+#endif
+
+#ifdef MJ_EMU
+// host emulation only: the largest op / fill lists seen (MJ_ENC_STATS=1 prints them at exit) — how ENC_OPS / ENC_FILLS were sized
+static int g_enc_max_ops = 0, g_enc_max_fills = 0;
+static inline void enc_ops_high_water(int n_ops, int n_fills) {
+    static bool reg = false;
+    if (!reg) {
+        reg = true;
+        if (getenv("MJ_ENC_STATS")) atexit([] { fprintf(stderr, "[enc] op list high water: %d ops, %d fills\n", g_enc_max_ops, g_enc_max_fills); });
+    }
+    if (n_ops > g_enc_max_ops) g_enc_max_ops = n_ops;
+    if (n_fills > g_enc_max_fills) g_enc_max_fills = n_fills;
+}
 #endif
 
 // ---------------------------------------------------------------- static row map
@@ -101,6 +125,15 @@ struct EncDerived {  // per-row scalars computed once in phase 2
     unsigned long long rowd[34];       // row of h - d in suit(d) (candidate discards only)
     unsigned long long U[34][3];       // candidate d, k-th other suit: merge(two untouched suits, rowd[d])
     float rowfill[256];                // per pass: value a whole tile row is filled with, < 0 = not filled
+    // The plane stack as an OP LIST (round 4): the scatter tasks run ONCE per decision row and record what they assign; every
+    // output pass then only zeroes its tile, applies the ops that fall into it and streams it out.  (Rounds 1-3 re-ran the whole
+    // task chain in every pass with the stores of the other passes masked off: four times the address arithmetic, kawa decoding
+    // and LUT reads, during which the workgroup issued no HBM store.)
+    int n_ops, n_fills;
+    float op_val[ENC_OPS];
+    float fill_val[ENC_FILLS];
+    unsigned short op_cell[ENC_OPS];   // row * 34 + column
+    unsigned short fill_row[ENC_FILLS];
 };
 
 template <class LN> MJD u64 enc_discard_candidates_aka(const LN& L, int s) {  // agent_helper.rs:35-79
@@ -147,7 +180,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         float4* dst4 = reinterpret_cast<float4*>(st);
         for (int i = tid; i < (int)(sizeof(TableOne) / 16); i += ENC_THREADS) dst4[i] = src[i];
         if (tid < 34) { D->furiten[tid] = 0; D->yaku[tid] = 0; }
-        if (tid == 0) D->uncond = 0;
+        if (tid == 0) { D->uncond = 0; D->n_ops = 0; D->n_fills = 0; }
     }
     __syncthreads();
 
@@ -372,29 +405,23 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
         }
     }
 
-    // ---- 3. passes
-    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)row * (C * 34));
-    for (int pass = 0; pass < ENC_PASSES; pass++) {
-        const int r0 = pass * TILE_ROWS, r1 = min(C, r0 + TILE_ROWS);
-        if (r0 >= C) break;
-        {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            constexpr int N4 = TILE_ROWS * 34 / 4;
-#pragma unroll
-            for (int k = 0; k < (N4 + ENC_THREADS - 1) / ENC_THREADS; k++) {
-                const int i = tid + k * ENC_THREADS;
-                if (i < N4) smem4[i] = z;
-            }
-            D->rowfill[tid] = -1.f;
-        }
-        __syncthreads();
+    // ---- 3. record: every task assigns its cells / row fills ONCE, into the op list
+    {
         auto put = [&](int r, int c, float v) {
-            if (r >= r0 && r < r1) tile[(r - r0) * 34 + c] = v;
+            const int i = atomicAdd(&D->n_ops, 1);
+            if (i < ENC_OPS) {
+                D->op_cell[i] = (unsigned short)(r * 34 + c);
+                D->op_val[i] = v;
+            }
         };
         auto fillr = [&](int r, float v) {
-            // `arr.fill(row, v)` is deferred: one LDS word now, merged into the row while it is streamed out (no row is
-            // both filled and assigned cell-wise in any obs version)
-            if (r >= r0 && r < r1) D->rowfill[r - r0] = v;
+            // `arr.fill(row, v)`: one entry, merged into the row while it is streamed out (no row is both filled and assigned
+            // cell-wise in any obs version)
+            const int i = atomicAdd(&D->n_fills, 1);
+            if (i < ENC_FILLS) {
+                D->fill_row[i] = (unsigned short)r;
+                D->fill_val[i] = v;
+            }
         };
         // obs_repr.rs:59-107 for one integer feature at row base `b`
         auto int_encode = [&](int b, u32 n_in, int cap, bool rescale, int rbf, int v0) {  // RBF values: rbf_v[v0 ..] (section 2d)
@@ -508,7 +535,7 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
             if (cans & CAN_AGARI) fillr(O::cans + 8, 1.f);
             if (cans & CAN_RYUKYOKU) fillr(O::cans + 9, 1.f);
         } else if (tid == 48) {
-            if (pass == 0) {  // mask (obs_repr.rs:422-562)
+            {  // mask (obs_repr.rs:422-562)
                 u64 m = 0;
                 if (!at_kan_select) {
                     if (cans & CAN_PASS) m |= BIT(45);
@@ -576,7 +603,6 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                 if (len - 1 - i < 18) slots[ns++] = O::self_kawa + 24 + (len - 1 - i) * 4;
                 for (int s = 0; s < ns; s++) {  // obs_repr.rs:714-734
                     const int b = slots[s];
-                    if (b + 4 <= r0 || b >= r1) continue;
                     for (int k = 0; k < nk; k++) put(b, deaka(KW_KAN(e, k)), 1.f);
                     put(b + 1, td, 1.f);
                     if (is_aka(t)) fillr(b + 2, 1.f);
@@ -588,7 +614,6 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                 if (len - 1 - i < 18) slots[ns++] = ob + 48 + (len - 1 - i) * 8;
                 for (int s = 0; s < ns; s++) {  // obs_repr.rs:736-773
                     const int b = slots[s];
-                    if (b + 8 <= r0 || b >= r1) continue;
                     if (KW_HAS_CP(e)) {
                         put(b, KW_CP_MIN(e), 1.f);
                         put(b + 1, KW_CP_MAX(e), 1.f);
@@ -616,6 +641,38 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
                 put(b + rr, td, 1.f);
                 if (KW_TEDASHI(e)) put(b + 3 + rr, td, 1.f);
             }
+        }
+    }
+    __syncthreads();
+    const int n_ops = min(D->n_ops, ENC_OPS), n_fills = min(D->n_fills, ENC_FILLS);
+    if (tid == 0 && (D->n_ops > ENC_OPS || D->n_fills > ENC_FILLS)) P.err_flag[0] = 1;  // capacity exceeded: the batch is reported as failed
+#ifdef MJ_EMU
+    enc_ops_high_water(D->n_ops, D->n_fills);
+#endif
+
+    // ---- 4. passes: zero a tile, apply the ops that fall into it, stream it out
+    float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)row * (C * 34));
+    for (int pass = 0; pass < ENC_PASSES; pass++) {
+        const int r0 = pass * TILE_ROWS, r1 = min(C, r0 + TILE_ROWS);
+        if (r0 >= C) break;
+        {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            constexpr int N4 = TILE_ROWS * 34 / 4;
+#pragma unroll
+            for (int k = 0; k < (N4 + ENC_THREADS - 1) / ENC_THREADS; k++) {
+                const int i = tid + k * ENC_THREADS;
+                if (i < N4) smem4[i] = z;
+            }
+            if (tid < TILE_ROWS) D->rowfill[tid] = -1.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < n_ops; i += ENC_THREADS) {
+            const int cell = (int)D->op_cell[i] - r0 * 34;
+            if (cell >= 0 && cell < (r1 - r0) * 34) tile[cell] = D->op_val[i];
+        }
+        for (int i = tid; i < n_fills; i += ENC_THREADS) {
+            const int r = (int)D->fill_row[i] - r0;
+            if (r >= 0 && r < r1 - r0) D->rowfill[r] = D->fill_val[i];
         }
         __syncthreads();
         {
