@@ -12,7 +12,7 @@
 //              per-workgroup hash set keyed by an EXACT 42-bit state id (see "state id" below; claimed by atomicCAS);
 //              the ordered child list of every state (slot, discard order key, draw count) goes to a pool in HBM;
 //   evaluate : for L = 0 .. s: level 0 in three passes (probe / dense thread-per-item scoring / sum), then every level
-//              by teams of 8, 16 or 32 lanes (one lane per remaining draw, sp_eval_team) that reproduce
+//              by teams of T - depth lanes (one lane per remaining draw, sp_eval_wave0 / sp_eval_wave) that reproduce
 //              draw_without_tegawari (calc.rs:447-561) with the reference's exact loop order (draw tiles ascending, aka
 //              after its plain tile; i, j ascending) and fold discards like discard_slow (calc.rs:563-637).
 // Memoisation in the reference is a pure cache, so evaluating every reachable state exactly once gives bit-identical
@@ -65,7 +65,7 @@ struct SpNode {                 // one 3n+1 state (608 bytes, 16-byte aligned ro
 };
 static_assert(sizeof(SpNode) == 608 && offsetof(SpNode, val) % 16 == 0 && offsetof(SpNode, sc) % 16 == 0, "SpNode layout");
 static_assert(offsetof(SpNode, child_off) % 8 == 0 && offsetof(SpNode, n_ch) == offsetof(SpNode, child_off) + 4 &&
-              offsetof(SpNode, sumreq) == offsetof(SpNode, child_off) + 6, "sp_eval_team reads the header as one u64");
+              offsetof(SpNode, sumreq) == offsetof(SpNode, child_off) + 6, "the evaluation reads the header as one u64");
 // A child-list entry: hash slot of the child | discard order key << 14 | last-discard-of-its-draw-entry << 23 |
 // draw count << 24 | invalid (hash set overflow) << 27.  Order: draw tile ascending, plain before red, discard ascending.
 #define SP_ENT_SLOT(e) ((e) & 0x3FFFu)
@@ -379,7 +379,7 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
 // draws (get_score: agari decomposition + yaku + fu) runs with every lane busy:
 //   probe : sp_l0_probe_chunk — which draws win (34 shanten probes per state) -> draw entries, one work item per entry
 //   score : THREAD per item, dense across the workgroup                  -> 4 scores per entry in the node (sc[])
-//   sum   : team per state — sp_eval_team<TW, 0> accumulates the scores in the reference's order
+//   sum   : team per state — sp_eval_wave0 accumulates the scores in the reference's order
 __device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
     SP_ASSUME_LDS(X);
     const int slot = item & 0x3FFF, idx = (item >> 14) & 31, t = (item >> 19) & 63, variant = (item >> 25) & 1;
@@ -863,244 +863,164 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
     }
 }
 
-// Per-team LDS of the evaluation: the folded child values of the current draw entry (double buffered: one team hand-off
-// per entry) and the numerators A[c][j] = tsumo_prob[c][j] * not_tsumo[j] of the state's probability table.  A team is
-// exactly T lanes wide (T = draws left, a constant of the row): floor(64 / T) teams per wavefront, so rows with 9 draws
-// left run 7 states per wavefront instead of 4.  Team scratch: nx[2][T + 1][4] then A[4][T] floats.
-#define SP_EVAL_LDS_FLOATS ((SP_THREADS / 64) * 1408)  /* per wavefront: level 0 (64 / T) teams x (12 T + 8) floats; levels > 0 SP_EVW_WAVE_FLOATS */
-MJD int sp_eval_lds_stride(int T) { return 12 * T + 8; }
-#ifndef SP_CH
-#define SP_CH (SP_WPS > 4 ? 4 : 8)  // children (or level-0 draw entries) fetched per round trip
-#endif
+// LDS of the evaluation: SP_EVW_WAVE_FLOATS per wavefront, split between its teams (a team is exactly T - off lanes wide, T = draws
+// left, a constant of the row: floor(64 / (T - off)) teams per wavefront, so rows with 9 draws left run 7 states per wavefront
+// instead of 4): levels > 0 park SP_EV_ENT rows-of-(T + 4) x 4 floats per team, level 0 SP_EV_ENT numerator rows of SP_EV0_STRIDE floats.
+#define SP_EVAL_LDS_FLOATS ((SP_THREADS / 64) * 1408)
 
-// Evaluate the states list[first], list[first + stride], ... (< end) of one level with a TEAM of T lanes, lane i = turn i:
-// tenpai / win / EV of calc.rs:447-561 into node.val[i].  LK = min(level, 2); TN = 8 / 16 / 17 bounds the unrolled turn loop
-// (rows with at most 8 / 16 / 17 draws left).
-//   level 0 : for every draw entry with a yaku, accumulate its scores;
-//   level > 0: walk the state's child list (written by sp_expand_chunk in the reference's order); per turn fold the
-//              children of a draw entry like discard_slow (max of (int)EV, then discard priority), then accumulate.
-// accumulate = calc.rs:486-548: lane i adds, for j = i .. T-1 in order, prob(i, j) = tsumo_prob[count][j] *
-// not_tsumo[j] / not_tsumo[i] times next[j + 1] — terms the reference skips (`break` on a zero probability, j < i for a
-// lane that runs all j) are added as +0.0 products instead of being branched over (x + 0.0 == x for the non-negative
-// sums here), so the unrolled j loop has no divergent control flow.
-// A state costs three DEPENDENT round trips to HBM / L2 (list -> node header -> child list -> child values) and little
-// arithmetic, so the loop is software-pipelined: while state k is being folded, the child list (level 0: scores) of state
-// k + 1 and the header of state k + 2 are already in flight.
-struct SpEvalFetch {  // what is prefetched per state
-    u32 slot;
-    u64 hdr;              // child_off | n_ch << 32 | sumreq << 48
-    u32 ent[SP_CH];       // level > 0: first SP_CH child-list entries
-    float m;              // not_tsumo_probs[turn of this lane] of the state's required-tile sum (a row of the shared table c_sp_nt)
-};
-template <int TN, int LK>
-__device__ __noinline__ void sp_eval_team(SpWork* W, SpCtx* X, float* TM, int first, int end, int stride, int lane_in_team, int off) {
-    // lane -> turn: a state `off` levels below the row's roots is reached after at least `off` draws, so nobody ever reads its
-    // values of the turns before that (a parent's lane of turn i reads val[j + 1], j >= i): the team is T - off lanes wide
-    const int ln = lane_in_team + off;  // this lane's turn
-    SP_ASSUME_LDS(X);
-    SP_ASSUME_LDS(TM);
-    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const int T = X->T;
-    float* const nxb = TM;                  // nx[buf][k][4]
-    float* const Ab = TM + 8 * (T + 1);     // A[c][j]
-    const bool assume_riichi = X->is_menzen && X->prefer_riichi;
-    const int hp_base = (int)(assume_riichi && X->calc_double_riichi && ln == 0);
-    const bool haitei = X->calc_haitei != 0;
-    const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
-
-    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)min(X->n_left, SP_NT_ROWS - 1) * (SP_NT_ROWS * SP_NT_STRIDE);  // this wall size
-    auto fetch_slot = [&](int i) -> u32 { return Wg->elist[min(i, end - 1)]; };
-    auto fetch_hdr = [&](u32 slot) -> u64 {
-        // one 8-byte load (level 0: past the L1 — the yaku bits were set by L2 atomics of the scoring pass)
-        SP_HBM unsigned long long* hp = reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off);
-        return LK > 0 ? *hp : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto fetch_ent = [&](SpEvalFetch& f) {  // what the header addresses: the child list and the not_tsumo row
-        f.m = nt_rows[min((int)((f.hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln];
-        if constexpr (LK > 0) {
-#pragma unroll
-            for (int q = 0; q < SP_CH; q++) f.ent[q] = Wg->pool[min((int)(u32)f.hdr + q, SP_POOL - 1)];
-        }
-    };
-    SpEvalFetch cur, nxt;
-    cur.slot = fetch_slot(first);
-    nxt.slot = fetch_slot(first + stride);
-    cur.hdr = fetch_hdr(cur.slot);
-    nxt.hdr = fetch_hdr(nxt.slot);
-    fetch_ent(cur);
-
-    for (int i = first; i < end; i += stride) {
-        SP_HBM SpNode& node = Wg->node[cur.slot];
-        const u32 child_off = (u32)cur.hdr;
-        const int n_ch = (int)((cur.hdr >> 32) & 0xFFFF);
-        // level > 0: the child values of the first batch; level 0: the scores / counts of the first draw entries
-        float v[SP_CH][4];
-        int cnt0[SP_CH];
-        if constexpr (LK > 0) {
-#pragma unroll
-            for (int q = 0; q < SP_CH; q++) {
-                const SP_HBM float* src = Wg->node[SP_ENT_SLOT(cur.ent[q])].val[ln];
-                const bool ok = q < n_ch && !(cur.ent[q] & SP_ENT_INVALID);
-#pragma unroll
-                for (int k = 0; k < 4; k++) v[q][k] = ok ? src[k] : 0.f;
-            }
-        } else {
-            // a tenpai state has 1.3 draw entries on average: only those are fetched (the count sits in the header already)
-#pragma unroll
-            for (int q = 0; q < SP_CH; q++) {
-                cnt0[q] = 1;
-#pragma unroll
-                for (int k = 0; k < 4; k++) v[q][k] = 0.f;
-                if (q < n_ch) {
-                    cnt0[q] = node.l0cnt[q];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v[q][k] = node.sc[q][k];
-                }
-            }
-        }
-        // a state with more than SP_CH children: the second batch of its child list is requested now, next to the first batch's
-        // values, instead of after them (one dependent round trip less in the middle of the fold)
-        u32 ent2[SP_CH];
-        if constexpr (LK > 0) {
-#pragma unroll
-            for (int q = 0; q < SP_CH; q++) ent2[q] = n_ch > SP_CH ? Wg->pool[min((int)child_off + SP_CH + q, SP_POOL - 1)] : 0u;
-        }
-        // in flight behind them: the next state's child list and the header of the state after it
-        SpEvalFetch nn;
-        nn.slot = fetch_slot(i + 2 * stride);
-        fetch_ent(nxt);
-        nn.hdr = fetch_hdr(nn.slot);
-
-        const float m_raw = cur.m;  // not_tsumo_probs[i] of this lane's turn
-        const bool lane_on = m_raw != 0.f;
-        const float my_m = lane_on ? m_raw : 1.f;
-        const float my_r = sp_rcp_refined(my_m);
-        const int eff_ln = lane_on ? ln : 127;  // `eff_ln <= j` == this lane has a term at turn j
-        mj_team_sync_n(T - off);  // the team's previous state is done with A[] / nx[]
-        Ab[ln] = tp0 * m_raw;
-        Ab[T + ln] = tp1 * m_raw;
-        Ab[2 * T + ln] = tp2 * m_raw;
-        Ab[3 * T + ln] = tp3 * m_raw;
-        mj_team_sync_n(T - off);
-        float acc_t = 0.f, acc_w = 0.f, acc_e = 0.f;  // lane i: tenpai[i], win[i], ev[i]
-
-        // one draw entry: scores (level 0) or the folded child values in nx[buf] (level > 0)
-        auto accumulate = [&](int count, int buf, float s0, float s1, float s2, float s3) {
-            const float* Ac = Ab + (count - 1) * T;
-            const float* nx = nxb + buf * 4 * (T + 1);
-            sp_static_for<0, TN>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if (j >= T || j < off) return;  // uniform (T and off are constants of the level): no lane of the team has a term before turn `off`
-                float prob = sp_div_domain(Ac[j], my_m, my_r);
-                prob = eff_ln <= j ? prob : 0.f;
-                if constexpr (LK == 0) {
-                    const int hp = hp_base + (int)(assume_riichi && j == ln) + (int)(haitei && j == T - 1);
-                    acc_w += prob;
-                    acc_e += prob * (hp == 0 ? s0 : hp == 1 ? s1 : hp == 2 ? s2 : s3);
-                } else {
-                    if constexpr (LK == 1) acc_t += prob;
-                    if (j < T - 1) {
-                        const float* vv = nx + 4 * (j + 1);
-                        if constexpr (LK > 1) acc_t += prob * vv[0];
-                        acc_w += prob * vv[1];
-                        acc_e += prob * vv[2];
-                    }
-                }
-            });
-        };
-
-        if constexpr (LK == 0) {
-            const u32 yaku = child_off;  // bit e: draw entry e has a yaku
-            for (int e0 = 0; e0 < n_ch; e0 += SP_CH) {
-                if (e0 > 0) {  // more than SP_CH draw entries (rare): fetch the next batch now
-#pragma unroll
-                    for (int q = 0; q < SP_CH; q++) {
-                        const int e = min(e0 + q, SP_L0_MAX - 1);
-                        cnt0[q] = node.l0cnt[e];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) v[q][k] = node.sc[e][k];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < SP_CH; q++) {
-                    if (e0 + q >= n_ch) break;
-                    if (!((yaku >> (e0 + q)) & 1)) continue;  // no yaku with this tile
-                    accumulate(min(max(cnt0[q], 1), 4), 0, v[q][0], v[q][1], v[q][2], v[q][3]);
-                }
-            }
-        } else {
-            // discard_slow (calc.rs:570-637) fold state of the current draw entry, per turn
-            float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
-            int max_value = INT_MIN, max_key = sp_discard_key(T_UNK), buf = 0;
-            for (int c0 = 0; c0 < n_ch; c0 += SP_CH) {
-                if (c0 > 0) {  // more than SP_CH children: the second batch of entries is here already, later ones are fetched now
-#pragma unroll
-                    for (int q = 0; q < SP_CH; q++) cur.ent[q] = c0 == SP_CH ? ent2[q] : Wg->pool[min((int)child_off + c0 + q, SP_POOL - 1)];
-#pragma unroll
-                    for (int q = 0; q < SP_CH; q++) {
-                        const SP_HBM float* src = Wg->node[SP_ENT_SLOT(cur.ent[q])].val[ln];
-                        const bool ok = c0 + q < n_ch && !(cur.ent[q] & SP_ENT_INVALID);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) v[q][k] = ok ? src[k] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < SP_CH; q++) {
-                    if (c0 + q >= n_ch) break;
-                    const u32 e = cur.ent[q];
-                    if (e & SP_ENT_INVALID) {
-                        X->overflow = 1;
-                    } else {
-                        const int value = __float_as_int(v[q][3]);  // `as i32` of the child's EV (maximize_win_prob = false)
-                        const int key = (int)SP_ENT_KEY(e);       // cmp_discard_priority(dt, max_tile) > 0  <=>  key > max_key
-                        if (value > max_value || (value == max_value && key > max_key)) {
-                            nx_t = v[q][0];
-                            nx_w = v[q][1];
-                            nx_e = v[q][2];
-                            max_value = value;
-                            max_key = key;
-                        }
-                    }
-                    if (e & SP_ENT_LAST) {  // last child of this draw entry (uniform in the team)
-                        float* dst = nxb + (buf * (T + 1) + ln) * 4;
-                        dst[0] = nx_t; dst[1] = nx_w; dst[2] = nx_e; dst[3] = 0.f;
-                        mj_team_sync_n(T - off);
-                        accumulate(min(max((int)SP_ENT_COUNT(e), 1), 4), buf, 0.f, 0.f, 0.f, 0.f);
-                        buf ^= 1;
-                        nx_t = nx_w = nx_e = -3.40282347e+38f;
-                        max_value = INT_MIN;
-                        max_key = sp_discard_key(T_UNK);
-                    }
-                }
-            }
-        }
-        SP_HBM float* dst = node.val[ln];
-        dst[0] = acc_t; dst[1] = acc_w; dst[2] = acc_e; dst[3] = __int_as_float((int)acc_e);
-        cur = nxt;
-        nxt = nn;
-    }
-}
-
-// ---- Levels > 0, round 4: the WHOLE wavefront walks through the evaluation in lock-step (uniform control flow), its teams
-// side by side.  sp_eval_team above (still used for level 0) lets every team run the accumulate — T iterations of
-// {LDS read, division, 3 multiply-adds} — at ITS OWN draw-entry boundaries: with 3-4 teams per wavefront the boundaries
-// rarely coincide, so the wavefront executed the accumulate up to 3-4 times per entry position with a third of its lanes,
-// and every turn of the unrolled loop was its own basic block behind an exec-mask branch (three LDS reads, a wait, eight
-// VALU, three SALU).  Here a STEP = {fold SP_EV_ENT children per team (selects, no branches), park every completed draw
-// entry's folded row in the team's LDS buffer, issue the loads of the next step, accumulate ALL parked entries of ALL teams
-// together}: one b128 LDS read per turn (the row {nx_t, nx_w, nx_e, A}: the numerator A[j] = tsumo_prob[count][j] *
-// not_tsumo[j] rides in the spare word of row j + 1), turns in groups of four behind one scalar branch, rows past T are zero
-// (+0.0 terms, like the dead turns of sp_eval_team).  The loads of the next step (child values, next child-list entries,
-// the next states' headers) are issued before the accumulate and consumed after it.  Same f32 operation order per lane as
-// sp_eval_team: entries in list order, turns ascending.
+// Evaluation (bottom-up), by TEAMS of T - off lanes, lane = turn: tenpai / win / EV of calc.rs:447-561 into node.val[turn].
+// A state `off` levels below the row's roots is reached after at least `off` draws, so nobody ever reads its values of the turns
+// before that (a parent's lane of turn i reads val[j + 1], j >= i): the team is T - off lanes wide.
+//   level 0 : for every draw entry with a yaku, accumulate its scores (sp_eval_wave0);
+//   level > 0: walk the state's child list (written by sp_expand_chunk in the reference's order); per turn fold the children of a
+//              draw entry like discard_slow (max of (int)EV, then discard priority), then accumulate (sp_eval_wave).
+// accumulate = calc.rs:486-548: lane i adds, for j = i .. T-1 in order, prob(i, j) = tsumo_prob[count][j] * not_tsumo[j] /
+// not_tsumo[i] times next[j + 1] — terms the reference skips (`break` on a zero probability, j < i for a lane that runs all j)
+// are added as +0.0 products instead of being branched over (x + 0.0 == x for the non-negative sums here).
+// The wavefront runs in lock-step, its teams side by side (uniform control flow): rounds 1-3 let every team run its accumulate at
+// its own draw-entry boundaries (sp_eval_team: a third of the lanes per pass, every turn its own basic block behind an exec-mask
+// branch); round 4 parks what the teams produce in LDS and accumulates all teams together.
 #define SP_EV_ENT 4                       // children folded per step = upper bound of the entries parked per step
 #define SP_EVW_WAVE_FLOATS 1408           // LDS per wavefront: teams x SP_EV_ENT x (T + 4) rows x 4 floats (T = 17: 4 teams)
 MJD int sp_evw_team_floats(int T) { return SP_EV_ENT * (T + 4) * 4; }
 struct alignas(16) SpF4 { float x, y, z, w; };
+#define SP_EV0_STRIDE 24                  // level 0: floats per parked numerator row A[turn] (>= T + 4, a multiple of 4)
+
+// Level 0 (tenpai states): a draw entry is a winning draw with its four scores (sp_l0_score) and its wall count; nothing to fold.
+// Per step up to SP_EV_ENT entries of every team: lane j parks A[j] = tsumo_prob[count][j] * not_tsumo[j], then every lane i adds
+// prob(i, j) and prob(i, j) * score for j = i .. T-1 (the score picked by riichi-ippatsu at j == i, haitei at j == T-1: calc.rs:510-527).
+template <int TN>
+__device__ __noinline__ void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int first, int end, int stride, int lane_in_team, int off_,
+                                           int team_in_wave, bool team_on) {
+    SP_ASSUME_LDS(X);
+    SP_ASSUME_LDS(WL);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    const int T = __builtin_amdgcn_readfirstlane(X->T), off = __builtin_amdgcn_readfirstlane(off_);
+    const int ln = min(lane_in_team + off, SP_T - 1);  // this lane's turn (lanes outside any team: clamped, never stored)
+    float* const eb = WL + (team_on ? team_in_wave : 0) * (SP_EV_ENT * SP_EV0_STRIDE);  // [SP_EV_ENT][SP_EV0_STRIDE]
+    if (team_on)
+        for (int r = lane_in_team; r < SP_EV_ENT * SP_EV0_STRIDE / 4; r += T - off) *reinterpret_cast<SpF4*>(eb + 4 * r) = SpF4{0.f, 0.f, 0.f, 0.f};
+    const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
+    const bool assume_riichi = X->is_menzen && X->prefer_riichi, haitei = X->calc_haitei != 0;
+    // which of the entry's four scores a term takes (hand points + 0..3 han): double riichi on turn 0, ippatsu on the lane's own
+    // turn, haitei on the last turn
+    const int hp_base = (int)(assume_riichi && X->calc_double_riichi && ln == 0);
+    const int hp_own = hp_base + (int)assume_riichi + (int)(haitei && ln == T - 1), hp_last = hp_base + (int)haitei;
+    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)min(X->n_left, SP_NT_ROWS - 1) * (SP_NT_ROWS * SP_NT_STRIDE);
+    const int last = max(end - 1, 0);
+    auto ld_slot = [&](int i) -> u32 { return Wg->elist[min(i, last)] & (SP_CAP - 1); };
+    auto ld_hdr = [&](u32 slot) -> u64 {  // past the L1: the yaku bits were set by L2 atomics of the scoring pass
+        return __hip_atomic_load(reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto ld_m = [&](u64 hdr) -> float { return nt_rows[min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln]; };
+    auto ld_sc = [&](u32 slot, int e) -> SpF4 {
+        const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(Wg->node[slot].sc[min(e, SP_L0_MAX - 1)]);
+        SpF4 r;
+        r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
+        return r;
+    };
+    auto ld_cnt4 = [&](u32 slot, int e0) -> u32 {  // l0cnt[e0 .. e0 + 3]
+        return *reinterpret_cast<const SP_HBM u32*>(&Wg->node[slot].l0cnt[min(e0, SP_L0_MAX + 3 - 4)]);
+    };
+    static_assert(offsetof(SpNode, l0cnt) % 4 == 0, "l0cnt is read four bytes at a time");
+    mj_team_sync<64>();
+
+    int i = first;
+    bool has = team_on && i < end;
+    u32 s0 = ld_slot(i), s1 = ld_slot(i + stride), s2 = ld_slot(i + 2 * stride);
+    u64 h0 = ld_hdr(s0), h1 = ld_hdr(s1);
+    float m_raw = ld_m(h0);
+    SpF4 sc[SP_EV_ENT];
+#pragma unroll
+    for (int q = 0; q < SP_EV_ENT; q++) sc[q] = ld_sc(s0, q);
+    u32 cw = ld_cnt4(s0, 0);
+    while (__ballot(has) != 0ull) {
+        const int n_ent = (int)((h0 >> 32) & 0xFFFF);
+        const u32 yaku = (u32)h0;  // bit e: draw entry e has a yaku
+        // in flight under this state: the next state's first entries, the header after it, the slot after that
+        const float m_n = ld_m(h1);
+        SpF4 scn[SP_EV_ENT];
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) scn[q] = ld_sc(s1, q);
+        const u32 cwn = ld_cnt4(s1, 0);
+        const u64 h2 = ld_hdr(s2);
+        const u32 s3 = ld_slot(i + 3 * stride);
+        const float my_m = m_raw != 0.f ? m_raw : 1.f, my_r = sp_rcp_refined(my_m);
+        float acc_w = 0.f, acc_e = 0.f;
+        int nmax = has ? n_ent : 0;  // the longest entry list of the wavefront's current states (uniform loop bound)
+        for (int d = 32; d > 0; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+        for (int e0 = 0; e0 < nmax; e0 += SP_EV_ENT) {
+            if (e0 > 0) {  // more than SP_EV_ENT draw entries (rare)
+#pragma unroll
+                for (int q = 0; q < SP_EV_ENT; q++) sc[q] = ld_sc(s0, e0 + q);
+                cw = ld_cnt4(s0, e0);
+            }
+            bool use[SP_EV_ENT];
+#pragma unroll
+            for (int q = 0; q < SP_EV_ENT; q++) {
+                use[q] = has && e0 + q < n_ent && ((yaku >> (e0 + q)) & 1);
+                const u32 cnt = (cw >> (8 * q)) & 0xFFu;
+                const float tpc = cnt <= 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
+                if (use[q]) eb[q * SP_EV0_STRIDE + ln] = tpc * m_raw;  // A[ln]
+            }
+            mj_team_sync<64>();
+#pragma unroll
+            for (int q = 0; q < SP_EV_ENT; q++) {
+                if (__ballot(use[q]) == 0ull) continue;
+                if (use[q]) {
+                    const float* ar = eb + q * SP_EV0_STRIDE;
+                    const float s_base = hp_base == 0 ? sc[q].x : sc[q].y;  // hp_base is 0 or 1
+                    const float s_own = hp_own == 0 ? sc[q].x : hp_own == 1 ? sc[q].y : hp_own == 2 ? sc[q].z : sc[q].w;
+                    const float s_last = hp_last == 0 ? sc[q].x : hp_last == 1 ? sc[q].y : sc[q].z;
+                    sp_static_for<0, (TN + 3) / 4>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        if (4 * g + 3 < off || 4 * g >= T) return;  // scalar
+                        const SpF4 a4 = *reinterpret_cast<const SpF4*>(ar + 4 * g);
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) {
+                            const int j = 4 * g + jj;
+                            float prob = sp_div_domain(av[jj], my_m, my_r);
+                            prob = ln <= j ? prob : 0.f;
+                            const float scj = j == ln ? s_own : j == T - 1 ? s_last : s_base;
+                            acc_w += prob;
+                            acc_e += prob * scj;
+                        }
+                    });
+                }
+            }
+            mj_team_sync<64>();
+        }
+        if (has) {
+            SP_HBM SpF4* dst = reinterpret_cast<SP_HBM SpF4*>(Wg->node[s0].val[ln]);
+            dst->x = 0.f; dst->y = acc_w; dst->z = acc_e; dst->w = __int_as_float((int)acc_e);
+        }
+        s0 = s1; s1 = s2; s2 = s3;
+        h0 = h1; h1 = h2;
+        m_raw = m_n;
+        cw = cwn;
+#pragma unroll
+        for (int q = 0; q < SP_EV_ENT; q++) sc[q] = scn[q];
+        i += stride;
+        has = team_on && i < end;
+    }
+}
+
+// ---- Levels > 0.  Rounds 1-3 (sp_eval_team) let every team run the accumulate — T iterations of {LDS read, division, 3
+// multiply-adds} — at ITS OWN draw-entry boundaries: with 3-4 teams per wavefront the boundaries rarely coincide, so the
+// wavefront executed the accumulate up to 3-4 times per entry position with a third of its lanes, and every turn of the
+// unrolled loop was its own basic block behind an exec-mask branch (three LDS reads, a wait, eight VALU, three SALU).
+// Here a STEP = {fold SP_EV_ENT children per team (selects, no branches), park every completed draw
+// entry's folded row in the team's LDS buffer, issue the loads of the next step, accumulate ALL parked entries of ALL teams
+// together}: one b128 LDS read per turn (the row {nx_t, nx_w, nx_e, A}: the numerator A[j] = tsumo_prob[count][j] *
+// not_tsumo[j] rides in the spare word of row j + 1), turns in groups of four behind one scalar branch, rows past T are zero
+// (+0.0 terms).  The loads of the next step (child values, next child-list entries,
+// the next states' headers) are issued before the accumulate and consumed after it.  The f32 operation order per lane is the
+// reference's: entries in list order, turns ascending.
 template <int TN, int LK>
 __device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int first, int end, int stride, int lane_in_team, int off_,
                                           int team_in_wave, bool team_on) {
-    static_assert(LK >= 1, "level 0 has no children: sp_eval_team<TN, 0>");
+    static_assert(LK >= 1, "level 0 has no children: sp_eval_wave0");
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(WL);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
@@ -1879,24 +1799,22 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                 sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
                 {
                     // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
-                    // ... of the turns that can be reached at this level: the first `off` turns are dead (see sp_eval_team)
+                    // ... of the turns that can be reached at this level: the first `off` turns are dead
                     const int off = min(cur_shanten - lv, T - 1), TW = T - off;
-                    const int wl = tid & 63, tpw = min(64 / TW, (SP_EVAL_LDS_FLOATS / (SP_THREADS / 64)) / sp_eval_lds_stride(T));  // lanes, LDS scratch
-                    const int tw = wl / TW, ln = wl - tw * TW;
-                    const int team = (tid >> 6) * tpw + tw, n_teams = (SP_THREADS / 64) * tpw;
-                    float* lds = s_tm.ev + team * sp_eval_lds_stride(T);
+                    const int wl = tid & 63, tw = wl / TW, ln = wl - tw * TW;
+                    float* wl_lds = s_tm.ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
                     const long long t_ev0 = P.prof ? wall_clock64() : 0;
                     if (lv == 0) {
-                        if (tw < tpw && b + team < e) {
-                            if (T <= 8) sp_eval_team<8, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else if (T <= 16) sp_eval_team<16, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
-                            else sp_eval_team<17, 0>(W, &X, lds, b + team, e, n_teams, ln, off);
-                        }
+                        const int tpw0 = min(64 / TW, SP_EVW_WAVE_FLOATS / (SP_EV_ENT * SP_EV0_STRIDE));
+                        const int team0 = (tid >> 6) * tpw0 + tw, n_teams0 = (SP_THREADS / 64) * tpw0;
+                        const bool on0 = tw < tpw0;
+                        if (T <= 8) sp_eval_wave0<8>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+                        else if (T <= 16) sp_eval_wave0<16>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+                        else sp_eval_wave0<17>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
                     } else {
                         // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
                         const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
                         const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
-                        float* wl_lds = s_tm.ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
                         const bool on = tw < tpw2;
                         if (T <= 8) {
                             if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);

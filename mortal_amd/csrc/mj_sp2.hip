@@ -984,7 +984,8 @@ __device__ __noinline__ void spg_eval_block(const SpG& G, float* WL, const u64* 
     } else {
         auto ld_ent = [&](u32 at) -> u64 { return pool[min(at, G.pool_cap - 1u)]; };
         auto ld_val = [&](u64 ent) -> SpF4 {  // one 16-byte load
-            const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(nodes[SPG_E_SLOT(ent)].val[ln]);
+            // (an entry past a child list's end is whatever the pool held: masked into the node array, its value never used)
+            const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(nodes[SPG_E_SLOT(ent) & G.cap_mask].val[ln]);
             SpF4 r;
             r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
             return r;

@@ -148,11 +148,11 @@ def test_sp_kernel_isa_has_no_flat_or_spilled_hot_paths(tmp_path):
     for m in re.finditer(r"^(_Z\d+(?:sp_\w+|mj_k_sp\w*)):.*?^\.Lfunc_end\d+:", text, re.S | re.M):
         funcs[m.group(1)] = m.group(0)
     names = " ".join(funcs)
-    for want in ("sp_expand_chunk", "sp_l0_probe_chunk", "sp_l0_score", "sp_eval_teamILi8ELi0E", "sp_eval_waveILi16ELi1E", "sp_eval_waveILi17ELi2E", "mj_k_sp"):
+    for want in ("sp_expand_chunk", "sp_l0_probe_chunk", "sp_l0_score", "sp_eval_wave0ILi8E", "sp_eval_waveILi16ELi1E", "sp_eval_waveILi17ELi2E", "mj_k_sp"):
         assert want in names, (want, sorted(funcs))
     for name, body in funcs.items():
         assert "flat_" not in body, name
-        if "sp_eval_team" in name or "sp_eval_wave" in name or "chunk" in name:
+        if "sp_eval_wave" in name or "chunk" in name:
             # scratch traffic only as callee-saved register saves / restores in the prologue and epilogue (once per call:
             # a call evaluates a team's whole share of a level), never inside the loops
             lines = body.split("\n")
