@@ -884,7 +884,7 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
 #define SP_EVW_WAVE_FLOATS 1408           // LDS per wavefront: teams x SP_EV_ENT x (T + 4) rows x 4 floats (T = 17: 4 teams)
 MJD int sp_evw_team_floats(int T) { return SP_EV_ENT * (T + 4) * 4; }
 struct alignas(16) SpF4 { float x, y, z, w; };
-#define SP_EV0_STRIDE 24                  // level 0: floats per parked numerator row A[turn] (>= T + 4, a multiple of 4)
+#define SP_EV0_STRIDE 24                  // level 0: floats per parked entry: the numerators A[turn] (20 >= T + 3) + the entry's 4 scores
 
 // Level 0 (tenpai states): a draw entry is a winning draw with its four scores (sp_l0_score) and its wall count; nothing to fold.
 // Per step up to SP_EV_ENT entries of every team: lane j parks A[j] = tsumo_prob[count][j] * not_tsumo[j], then every lane i adds
@@ -913,12 +913,12 @@ __device__ __noinline__ void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int f
         return __hip_atomic_load(reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto ld_m = [&](u64 hdr) -> float { return nt_rows[min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln]; };
-    auto ld_sc = [&](u32 slot, int e) -> SpF4 {
-        const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(Wg->node[slot].sc[min(e, SP_L0_MAX - 1)]);
-        SpF4 r;
-        r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
-        return r;
-    };
+    // an entry's four scores are kept as four scalars and picked by one-hot WEIGHTS (x * 1 + 0 + 0 + 0 is exact): a struct or array
+    // whose element is picked by a run-time index ends up in scratch behind flat loads
+    auto sc_ptr = [&](u32 slot, int e) -> const SP_HBM SpF4* { return reinterpret_cast<const SP_HBM SpF4*>(Wg->node[slot].sc[min(e, SP_L0_MAX - 1)]); };
+    const float wb0 = hp_base == 0 ? 1.f : 0.f, wb1 = hp_base == 1 ? 1.f : 0.f;
+    const float wo0 = hp_own == 0 ? 1.f : 0.f, wo1 = hp_own == 1 ? 1.f : 0.f, wo2 = hp_own == 2 ? 1.f : 0.f, wo3 = hp_own == 3 ? 1.f : 0.f;
+    const float wl0 = hp_last == 0 ? 1.f : 0.f, wl1 = hp_last == 1 ? 1.f : 0.f, wl2 = hp_last == 2 ? 1.f : 0.f;
     auto ld_cnt4 = [&](u32 slot, int e0) -> u32 {  // l0cnt[e0 .. e0 + 3]
         return *reinterpret_cast<const SP_HBM u32*>(&Wg->node[slot].l0cnt[min(e0, SP_L0_MAX + 3 - 4)]);
     };
@@ -930,18 +930,24 @@ __device__ __noinline__ void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int f
     u32 s0 = ld_slot(i), s1 = ld_slot(i + stride), s2 = ld_slot(i + 2 * stride);
     u64 h0 = ld_hdr(s0), h1 = ld_hdr(s1);
     float m_raw = ld_m(h0);
-    SpF4 sc[SP_EV_ENT];
+    float sx[SP_EV_ENT], sy[SP_EV_ENT], sz[SP_EV_ENT], sw[SP_EV_ENT];
 #pragma unroll
-    for (int q = 0; q < SP_EV_ENT; q++) sc[q] = ld_sc(s0, q);
+    for (int q = 0; q < SP_EV_ENT; q++) {
+        const SP_HBM SpF4* p = sc_ptr(s0, q);
+        sx[q] = p->x; sy[q] = p->y; sz[q] = p->z; sw[q] = p->w;
+    }
     u32 cw = ld_cnt4(s0, 0);
     while (__ballot(has) != 0ull) {
         const int n_ent = (int)((h0 >> 32) & 0xFFFF);
         const u32 yaku = (u32)h0;  // bit e: draw entry e has a yaku
         // in flight under this state: the next state's first entries, the header after it, the slot after that
         const float m_n = ld_m(h1);
-        SpF4 scn[SP_EV_ENT];
+        float nx_[SP_EV_ENT], ny_[SP_EV_ENT], nz_[SP_EV_ENT], nw_[SP_EV_ENT];
 #pragma unroll
-        for (int q = 0; q < SP_EV_ENT; q++) scn[q] = ld_sc(s1, q);
+        for (int q = 0; q < SP_EV_ENT; q++) {
+            const SP_HBM SpF4* p = sc_ptr(s1, q);
+            nx_[q] = p->x; ny_[q] = p->y; nz_[q] = p->z; nw_[q] = p->w;
+        }
         const u32 cwn = ld_cnt4(s1, 0);
         const u64 h2 = ld_hdr(s2);
         const u32 s3 = ld_slot(i + 3 * stride);
@@ -952,40 +958,55 @@ __device__ __noinline__ void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int f
         for (int e0 = 0; e0 < nmax; e0 += SP_EV_ENT) {
             if (e0 > 0) {  // more than SP_EV_ENT draw entries (rare)
 #pragma unroll
-                for (int q = 0; q < SP_EV_ENT; q++) sc[q] = ld_sc(s0, e0 + q);
+                for (int q = 0; q < SP_EV_ENT; q++) {
+                    const SP_HBM SpF4* p = sc_ptr(s0, e0 + q);
+                    sx[q] = p->x; sy[q] = p->y; sz[q] = p->z; sw[q] = p->w;
+                }
                 cw = ld_cnt4(s0, e0);
             }
-            bool use[SP_EV_ENT];
+            u32 use = 0;  // bit q: this team has a draw entry with a yaku in slot q of the step
 #pragma unroll
             for (int q = 0; q < SP_EV_ENT; q++) {
-                use[q] = has && e0 + q < n_ent && ((yaku >> (e0 + q)) & 1);
+                const bool u = has && e0 + q < n_ent && ((yaku >> (e0 + q)) & 1);
                 const u32 cnt = (cw >> (8 * q)) & 0xFFu;
                 const float tpc = cnt <= 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
-                if (use[q]) eb[q * SP_EV0_STRIDE + ln] = tpc * m_raw;  // A[ln]
+                if (u) {
+                    eb[q * SP_EV0_STRIDE + ln] = tpc * m_raw;  // A[ln]
+                    if (lane_in_team == 0) *reinterpret_cast<SpF4*>(eb + q * SP_EV0_STRIDE + 20) = SpF4{sx[q], sy[q], sz[q], sw[q]};  // the entry's scores ride along
+                }
+                use |= u ? (1u << q) : 0u;
             }
             mj_team_sync<64>();
-#pragma unroll
-            for (int q = 0; q < SP_EV_ENT; q++) {
-                if (__ballot(use[q]) == 0ull) continue;
-                if (use[q]) {
+#pragma nounroll
+            for (int q = 0; q < SP_EV_ENT; q++) {  // ONE copy of the accumulate (a dynamic loop over the parked entries)
+                const bool u = (use >> q) & 1;
+                if (__ballot(u) == 0ull) continue;
+                if (u) {
                     const float* ar = eb + q * SP_EV0_STRIDE;
-                    const float s_base = hp_base == 0 ? sc[q].x : sc[q].y;  // hp_base is 0 or 1
-                    const float s_own = hp_own == 0 ? sc[q].x : hp_own == 1 ? sc[q].y : hp_own == 2 ? sc[q].z : sc[q].w;
-                    const float s_last = hp_last == 0 ? sc[q].x : hp_last == 1 ? sc[q].y : sc[q].z;
+                    const SpF4 sq = *reinterpret_cast<const SpF4*>(ar + 20);
+                    // picked by one-hot weights (x * 1 + 0 + 0 + 0 is exact): a run-time index into a register tuple would go through scratch
+                    const float s_base = sq.x * wb0 + sq.y * wb1;  // hp_base is 0 or 1
+                    const float s_own = sq.x * wo0 + sq.y * wo1 + sq.z * wo2 + sq.w * wo3;
+                    const float s_last = sq.x * wl0 + sq.y * wl1 + sq.z * wl2;  // hp_last <= 2
                     sp_static_for<0, (TN + 3) / 4>([&](auto gc) {
                         constexpr int g = decltype(gc)::value;
                         if (4 * g + 3 < off || 4 * g >= T) return;  // scalar
                         const SpF4 a4 = *reinterpret_cast<const SpF4*>(ar + 4 * g);
-                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) {
-                            const int j = 4 * g + jj;
-                            float prob = sp_div_domain(av[jj], my_m, my_r);
-                            prob = ln <= j ? prob : 0.f;
-                            const float scj = j == ln ? s_own : j == T - 1 ? s_last : s_base;
-                            acc_w += prob;
-                            acc_e += prob * scj;
-                        }
+                        const float av0 = a4.x, av1 = a4.y, av2 = a4.z, av3 = a4.w;
+                        const float so_ = s_own, sl_ = s_last, sb_ = s_base;  // values, not the lambda's references (else: pointer selects + flat loads)
+#define SP_EV0_TERM(J, A)                                                        \
+    {                                                                            \
+        float prob_ = sp_div_domain((A), my_m, my_r);                            \
+        prob_ = ln <= (J) ? prob_ : 0.f;                                         \
+        const float scj_ = (J) == ln ? so_ : (J) == T - 1 ? sl_ : sb_;           \
+        acc_w += prob_;                                                          \
+        acc_e += prob_ * scj_;                                                   \
+    }
+                        SP_EV0_TERM(4 * g, av0)
+                        SP_EV0_TERM(4 * g + 1, av1)
+                        SP_EV0_TERM(4 * g + 2, av2)
+                        SP_EV0_TERM(4 * g + 3, av3)
+#undef SP_EV0_TERM
                     });
                 }
             }
@@ -1000,7 +1021,9 @@ __device__ __noinline__ void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int f
         m_raw = m_n;
         cw = cwn;
 #pragma unroll
-        for (int q = 0; q < SP_EV_ENT; q++) sc[q] = scn[q];
+        for (int q = 0; q < SP_EV_ENT; q++) {
+            sx[q] = nx_[q]; sy[q] = ny_[q]; sz[q] = nz_[q]; sw[q] = nw_[q];
+        }
         i += stride;
         has = team_on && i < end;
     }
