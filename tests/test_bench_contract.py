@@ -1,6 +1,6 @@
-"""The driver's bench.py contract, checked on the committed line of the last GPU run (profiles/r03_bench_v4.json) and on
-bench.py's argument defaults — no GPU needed.  Guards against drift between the JSON the driver parses, BASELINE.json's
-metric, and the numbers quoted in DESIGN.md §7."""
+"""The driver's bench.py contract, checked on the committed line of the last builder GPU run (profiles/r04_bench_v4.json), on the
+driver's own records (BENCH_r0N.json, when present) and on bench.py's argument defaults — no GPU needed.  Guards against drift
+between the JSON the driver parses, BASELINE.json's metric, and the numbers quoted in DESIGN.md §7."""
 import json
 import os
 import re
@@ -9,8 +9,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r03_bench_v4.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_bench_v4.json")) as f:
         return json.load(f)
+
+
+def _driver_lines():
+    """(round, parsed bench line) of every BENCH_r0N.json the driver left in the repository root."""
+    import glob
+
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "BENCH_r[0-9][0-9].json"))):
+        with open(f) as fh:
+            d = json.load(fh)
+        p = d.get("parsed") or d
+        if isinstance(p, dict) and "value" in p:
+            out.append((os.path.basename(f)[6:9], p))
+    return out
 
 
 def test_committed_bench_line_has_the_contract_keys_and_consistent_arithmetic():
@@ -34,7 +48,10 @@ def test_committed_bench_line_has_the_contract_keys_and_consistent_arithmetic():
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2  # no wasted re-reads / rewrites
     s = d["roofline_sp"]
     assert s["bound"] == "valu" and s["from_static_profile"] is True and s["stale"] is False  # the PMC summary matches the kernel sources
-    assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-6 and s["peak"] < s["peak_f32_fma"]
+    # `frac` is priced against the guide's VALU issue peak (comparable across rounds); the builder's micro-benchmark rate is a separate key
+    assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-6 and abs(s["peak"] - 1228.8) < 0.01 and s["peak_measured_int_issue"] < s["peak"]
+    assert abs(s["frac_of_measured_int_issue"] - s["achieved"] / s["peak_measured_int_issue"]) < 1e-6
+    assert abs(s["states_per_sec"] - s["states_per_launch"] / (s["avg_launch_ms"] * 1e-3)) / s["states_per_sec"] < 1e-3
     assert abs(s["achieved"] - s["valu_insts_per_state"] * s["states_per_launch"] / (s["avg_launch_ms"] * 1e-3) / 1e9) / s["achieved"] < 1e-3
     assert s["static_profile"]["measured_at_tables"] == 65536 and "65536 tables" in r["traffic_source"]
     k = d["kernel_ms_per_step"]
@@ -55,6 +72,22 @@ def test_design_quotes_the_committed_numbers():
     assert head in text, head
     assert f"{d['ms_per_step']:.1f} ms/cycle" in text
     assert f"`mj_k_sp` {d['kernel_ms_per_step']['mj_k_sp']:.1f} ms" in text
+    assert "builder-run" in text  # the committed line is the builder's box; the numbers of record are the driver's
+    # ... and the driver's last record is quoted next to it (DESIGN quoted the builder's best box only)
+    drv = [(r, p) for r, p in _driver_lines() if r == "r03"]
+    if drv:
+        p = drv[0][1]
+        assert f"{p['value'] / 1e6:.3f} M env steps/s" in text and f"{p['ms_per_step']:.1f} ms/cycle" in text
+
+
+def test_driver_records_are_consistent_with_the_contract():
+    """Every BENCH_r0N.json the driver wrote: headline keys, the metric, the roofline and CPU-baseline objects; the value rises."""
+    prev = 0.0
+    for rnd, p in _driver_lines():
+        assert p["unit"] == "env steps/s" and p["higher_is_better"] is True and p["n_gpus"] == 1, rnd
+        assert p["value"] > prev and p["ms_per_step"] > 0, rnd
+        assert "roofline" in p and "cpu_baseline" in p, rnd
+        prev = p["value"]
 
 
 def test_bench_defaults_match_the_driver_contract():
