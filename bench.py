@@ -156,80 +156,109 @@ def _phase_ticks(pool):
 
 
 def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmup, bufs, engine=None, barrier=None,
-             deal_algo=None):
-    """One workload: pool of N tables, `preroll` untimed cycles (cheap v3 encode), `warmup` untimed and `steps` timed cycles
-    of step + encode(+SP) + policy.  Returns the raw measurements (host wall time, HIP-event kernel times, counters)."""
+             deal_algo=None, n_pools=1):
+    """One workload: N tables (as n_pools pools of N / n_pools tables, each on its own HIP stream), `preroll` untimed cycles (cheap
+    v3 encode), `warmup` untimed and `steps` timed cycles of step + encode(+SP) + policy.  Returns the raw measurements (host wall
+    time, HIP-event kernel times, counters).
+
+    n_pools > 1 (--pools): the tables are INDEPENDENT, so the pool can be cut into halves that run the same cycle one after the
+    other on two streams: while one half's SP kernel drains (its persistent workgroups hold every register of the chip until they
+    exit), the other half's step / snapshot / encode kernels fill the CUs that fall idle.  Every table still advances once per
+    cycle; `value` counts the env steps of all pools."""
     import numpy as np
     import torch
 
     obs, masks, act = bufs
-    seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(N)]
-    pool = pool_cls(N, version=version, deal_algo=deal_algo, device=str(dev), max_rows=2 * N)
-    pool.reset(seeds, game_ids=np.arange(N), n_games_total=N)
-    pool.set_refill(world * N // 4)  # a finished table restarts on a seed no other table/rank uses
-    if preroll > 0 and STAGGER[0]:
-        # table t enters play at cycle hash(t) % preroll: after the pre-roll the pool is spread over EVERY phase of a hanchan (a
-        # hanchan lasts ~3,100 cycles under the random policy).  Started all at once, the tables march in step for many
-        # generations and a timed window only ever sees one phase (round 2: late south round, before the first wave of restarts)
-        pool.set_start_stagger(preroll)
-    C = pool.C
-    obs_v = obs[: 2 * N * C * 34].view(2 * N, C, 34)
-    obs_3 = obs[: 2 * N * 934 * 34].view(2 * N, 934, 34)
+    K = max(1, int(n_pools))
+    assert N % (4 * K) == 0, "pools hold whole duplicate-deal sets"
+    n = N // K
+    pools, streams, views = [], [], []
+    for k in range(K):
+        seeds = [(10000 + (g0 + k * n + g) // 4, KEY) for g in range(n)]
+        pool = pool_cls(n, version=version, deal_algo=deal_algo, device=str(dev), max_rows=2 * n)
+        pool.reset(seeds, game_ids=np.arange(n), n_games_total=n)
+        pool.set_refill(world * N // 4)  # a finished table restarts on a seed no other table / pool / rank uses
+        if preroll > 0 and STAGGER[0]:
+            # table t enters play at cycle hash(t) % preroll: after the pre-roll the pool is spread over EVERY phase of a hanchan (a
+            # hanchan lasts ~3,100 cycles under the random policy).  Started all at once, the tables march in step for many
+            # generations and a timed window only ever sees one phase (round 2: late south round, before the first wave of restarts)
+            pool.set_start_stagger(preroll)
+        pools.append(pool)
+        streams.append(torch.cuda.current_stream() if K == 1 else torch.cuda.Stream(device=dev))
+        C = pool.C
+        r0 = 2 * n * k
+        views.append(dict(obs_v=obs[r0 * C * 34: (r0 + 2 * n) * C * 34].view(2 * n, C, 34),
+                          obs_3=obs[r0 * 934 * 34: (r0 + 2 * n) * 934 * 34].view(2 * n, 934, 34),
+                          masks=masks[r0: r0 + 2 * n], act=act[r0: r0 + 2 * n]))
+    C = pools[0].C
     use_net = [False]
 
-    def cycle(i, a_prev, ob):
-        n, _ = pool.step(a_prev, None)
-        pool.encode(0, ob, masks)
+    def cycle(k, i, a_prev, ob):
+        pool, vw = pools[k], views[k]
+        nr, _ = pool.step(a_prev, None)
+        pool.encode(0, ob, vw["masks"])
         if use_net[0]:
-            return engine.react_batch_device(ob[:n], masks[:n]), n
+            return engine.react_batch_device(ob[:nr], vw["masks"][:nr]), nr
         if policy == "greedy":
-            pool.greedy_policy(0, masks, ob, 0x9E3779B97F4A7C15, i & 0xFFFFFFFF, act)
+            pool.greedy_policy(0, vw["masks"], ob, 0x9E3779B97F4A7C15, i & 0xFFFFFFFF, vw["act"])
         else:
-            pool.random_policy(0, masks, 0x9E3779B97F4A7C15, i & 0xFFFFFFFF, act)
-        return act[:n], n
+            pool.random_policy(0, vw["masks"], 0x9E3779B97F4A7C15, i & 0xFFFFFFFF, vw["act"])
+        return vw["act"][:nr], nr
 
-    a_prev = None
+    def run(i0, i1, key, a_prev):
+        rows = 0
+        for i in range(i0, i1):
+            for k in range(K):
+                with torch.cuda.stream(streams[k]):
+                    a_prev[k], nr = cycle(k, i, a_prev[k], views[k][key])
+                rows += nr
+        return rows
+
+    a_prev = [None] * K
     # steady-state mix of game phases: a hanchan lasts a few thousand cycles under the random policy and its kyoku end at
     # different times, so after 3072 cycles the tables are spread over every phase (SP cost depends strongly on it)
     if preroll > 0:
-        pool.configure(0, version=3)
-        for i in range(-preroll, 0):
-            a_prev, _ = cycle(i, a_prev, obs_3)
-        pool.configure(0, version=version)
+        for pool in pools:
+            pool.configure(0, version=3)
+        run(-preroll, 0, "obs_3", a_prev)
+        for pool in pools:
+            pool.configure(0, version=version)
     use_net[0] = engine is not None
-    for i in range(warmup):
-        a_prev, _ = cycle(i, a_prev, obs_v)
+    run(0, warmup, "obs_v", a_prev)
     torch.cuda.synchronize()
     if barrier:
         barrier()
-    c0 = pool.counters()
-    ph0 = _phase_ticks(pool) if version == 4 else None
-    pool.encode_timing(True)
-    rows_timed = 0
+    c0 = [pool.counters() for pool in pools]
+    ph0 = [_phase_ticks(pool) for pool in pools] if version == 4 else None
+    for pool in pools:
+        pool.encode_timing(True)
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        a_prev, n = cycle(i, a_prev, obs_v)
-        rows_timed += n
+    rows_timed = run(warmup, warmup + steps, "obs_v", a_prev)
     torch.cuda.synchronize()
     if barrier:
         barrier()
     dt = time.perf_counter() - t0
-    c1 = pool.counters()
-    enc_ms, enc_launches = pool.encode_timing(False)
-    sp_ms, sp_launches = pool.sp_timing()
-    ph1 = _phase_ticks(pool) if ph0 is not None else None
-    code, tbl = pool.first_error()
-    if code:
-        raise SystemExit(f"table {tbl} in error {code}")
-    res = dict(steps=c1["steps"] - c0["steps"], games=c1["games"] - c0["games"], dt=dt, rows=rows_timed, enc_ms=enc_ms,
-               enc_launches=enc_launches, sp_ms=sp_ms, sp_launches=sp_launches, C=C, n_cycles=steps, sp_overflow=c1["sp_overflow"])
-    if ph0 is not None and ph1 is not None:
-        d = {k: ph1[k] - ph0[k] for k in ph1}
-        tot = max(1, sum(d[k] for k in ("setup", "expand", "level0", "eval", "write")))
-        res["sp_phases"] = {"share": {k: round(d[k] / tot, 4) for k in ("setup", "expand", "level0", "eval", "write")},
+    c1 = [pool.counters() for pool in pools]
+    enc_ms = enc_launches = sp_ms = sp_launches = 0
+    for pool in pools:
+        e_ms, e_n = pool.encode_timing(False)
+        s_ms, s_n = pool.sp_timing()
+        enc_ms, enc_launches, sp_ms, sp_launches = enc_ms + e_ms, enc_launches + e_n, sp_ms + s_ms, sp_launches + s_n
+        code, tbl = pool.first_error()
+        if code:
+            raise SystemExit(f"table {tbl} in error {code}")
+    ph1 = [_phase_ticks(pool) for pool in pools] if ph0 is not None else None
+    tot = lambda key: sum(b[key] - a[key] for a, b in zip(c0, c1))
+    res = dict(steps=tot("steps"), games=tot("games"), dt=dt, rows=rows_timed, enc_ms=enc_ms, enc_launches=enc_launches, sp_ms=sp_ms,
+               sp_launches=sp_launches, C=C, n_cycles=steps, sp_overflow=sum(c["sp_overflow"] for c in c1), n_pools=K)
+    if ph0 is not None and all(p is not None for p in ph0 + ph1):
+        d = {k: sum(b[k] - a[k] for a, b in zip(ph0, ph1)) for k in ph1[0]}
+        tot_t = max(1, sum(d[k] for k in ("setup", "expand", "level0", "eval", "write")))
+        res["sp_phases"] = {"share": {k: round(d[k] / tot_t, 4) for k in ("setup", "expand", "level0", "eval", "write")},
                             "states_per_step": d["states"] / steps, "rows_per_step": d["rows"] / steps, "overflows": d["overflow"]}
-    res["results"] = pool.results() if world > 1 else None
-    pool.close()
+    res["results"] = pools[0].results() if world > 1 else None
+    for pool in pools:
+        pool.close()
     return res
 
 
@@ -287,6 +316,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, what the driver's N = 1, 2, 4, 8 runs measure): --tables per GPU, total work grows with N; "
                          "strong: --tables is the TOTAL over all ranks (BASELINE.md C4's '65,536 total' point), each rank owns tables / N")
+    ap.add_argument("--pools", type=int, default=1,
+                    help="cut the tables of a GPU into this many independent pools on their own HIP streams (same cycle, one pool after the "
+                         "other): one pool's step / encode kernels run in the tail of the other's SP kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true", help="skip the extra workloads (obs v3, no pre-roll, greedy policy)")
     ap.add_argument("--launch-check", action="store_true",
@@ -369,7 +401,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    r = _measure(TablePool, N, g0, world, dev, args.version, args.preroll, args.policy, args.steps, args.warmup, bufs, engine, barrier)
+    r = _measure(TablePool, N, g0, world, dev, args.version, args.preroll, args.policy, args.steps, args.warmup, bufs, engine, barrier,
+                 n_pools=args.pools)
     steps, games, dt, rows_timed = r["steps"], r["games"], r["dt"], r["rows"]
     enc_ms, enc_launches, sp_ms, sp_launches, C = r["enc_ms"], r["enc_launches"], r["sp_ms"], r["sp_launches"], r["C"]
 
@@ -458,6 +491,7 @@ def main():
                 "start_stagger": bool(STAGGER[0] and args.preroll > 0),
                 "policy": args.policy,
                 "tables_per_gpu": N,
+                "pools_per_gpu": args.pools,
                 "obs_version": args.version,
                 "parallelism": f"tables sharded x{world}, no data-path collective (one RCCL gather of episode returns)",
             },

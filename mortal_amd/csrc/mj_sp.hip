@@ -51,6 +51,9 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #endif
 #define SP_WGS (4 * SP_WPS * 64 / SP_THREADS)  // resident workgroups per CU
 
+#ifndef SP_CC_N
+#define SP_CC_N 1024            // entries of the per-workgroup child cache in LDS (0 = off): row epoch << 56 | state id << 14 | slot
+#endif
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
 #define SP_L0_MAX 17            // winning draw entries per tenpai state (13 waits + 3 aka variants)
@@ -185,6 +188,8 @@ struct alignas(16) SpCtx {  // per-decision constants (LDS; the per-phase pipeli
     int overflow;
     unsigned long long* prof;  // optional phase timers (MJ_SP_PROF)
     unsigned long long pt[8];  // per-row sums of the expansion pass timers / counters (flushed once per row)
+    unsigned long long* cc;    // the workgroup's child cache in LDS (SP_CC_N entries; NULL: none) and this row's epoch (8 bits, never 0... see mj_k_sp)
+    unsigned cc_epoch;
     // candidates
     int n_cand;
     int cand_tile[SP_MAX_CAND], cand_slot[SP_MAX_CAND], cand_down[SP_MAX_CAND], cand_nreq[SP_MAX_CAND];
@@ -791,14 +796,17 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             E.pos = sp_dk_pos(E.dk);
             return E;
         };
-        auto finish = [&](const Ent& E, u64 first_old) {  // the rest of sp_insert after the first claim, the list and the child entry
+        auto finish = [&](const Ent& E, u64 first_old, int known) -> int {  // the rest of sp_insert after the first look, the list and the child entry
             const u64 tag = SP_TAG(E.dk);
             const SpState Sx = sp_chunk_state(C, E.s);
             u32 pos = E.pos;
             u64 old = first_old;
-            int cs = -1;
+            int cs = known;  // >= 0: the child cache knew the slot
             bool fresh = false;
-            for (int probe = 0; probe < SP_CAP; probe++) {
+#ifdef MJ_EMU
+            if (known >= 0 && Wg->tag[known] != tag) X->overflow = 1;  // a cache hit must name the slot that holds this very state
+#endif
+            for (int probe = 0; cs < 0 && probe < SP_CAP; probe++) {
                 if (old == 0ull) {
                     u64 k[4];
                     sp_key(sp_apply(Sx, E.tile, E.dt), k);
@@ -832,6 +840,20 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(E.dt) << 14) | (E.rank == E.nk - 1 ? SP_ENT_LAST : 0u) |
                             ((u32)E.count << 24);
             if (pos_out < SP_POOL) Wg->pool[pos_out] = ent;
+            return cs;
+        };
+        // The child cache (round 4): a child is looked up by ~6 parents, most of them neighbours in the level list, and five look-ups
+        // in six only need its slot.  A direct-mapped table in LDS remembers (state id -> slot) of the children this workgroup saw
+        // last: a hit costs one ds_read and no tag line from L2 / HBM (a 128-byte line per 8-byte tag otherwise).
+        unsigned long long* const cc = X->cc;
+        const u64 cc_ep = (u64)X->cc_epoch << 42;
+        auto cc_look = [&](const Ent& E) -> int {
+            if (!cc || !E.on) return -1;
+            const u64 v = cc[E.pos & (SP_CC_N - 1)];
+            return (v >> 14) == (cc_ep | E.dk) ? (int)(v & 0x3FFFu) : -1;
+        };
+        auto cc_put = [&](const Ent& E, int cs) {
+            if (cc && cs >= 0) cc[E.pos & (SP_CC_N - 1)] = ((cc_ep | E.dk) << 14) | (u64)(u32)cs;
         };
         for (int e0 = 0; e0 < n_entries; e0 += 2 * SP_NT) {
             const bool two = e0 + SP_NT < n_entries;  // uniform: a round with at most 64 entries decodes one entry per lane (-0.9 %)
@@ -840,16 +862,23 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
             B.on = false;
             if (two) B = decode(e0 + SP_NT + tid);
             u64 oa = 1ull, ob = 1ull;
+            const int ka = cc_look(A), kb = cc_look(B);
             // five edges in six find their child already there: LOOK before claiming (a plain load; within a row a tag only ever goes
             // from 0 to its final value, and the end-of-row reset is a store of this CU, so a stale value can only be a 0 — which
             // costs the atomic that would have been issued anyway).  mj_k_sp -3.0 % (round 4, same box): 144 M L2 atomics per launch
             // become ~25 M.
-            if (A.on) oa = Wg->tag[A.pos];
-            if (B.on) ob = Wg->tag[B.pos];
-            if (A.on && oa == 0ull) oa = sp_claim_tag(&Wg->tag[A.pos], SP_TAG(A.dk));
-            if (B.on && ob == 0ull) ob = sp_claim_tag(&Wg->tag[B.pos], SP_TAG(B.dk));
-            if (A.on) finish(A, oa);
-            if (B.on) finish(B, ob);
+            if (A.on && ka < 0) oa = Wg->tag[A.pos];
+            if (B.on && kb < 0) ob = Wg->tag[B.pos];
+            if (A.on && ka < 0 && oa == 0ull) oa = sp_claim_tag(&Wg->tag[A.pos], SP_TAG(A.dk));
+            if (B.on && kb < 0 && ob == 0ull) ob = sp_claim_tag(&Wg->tag[B.pos], SP_TAG(B.dk));
+            if (A.on) {
+                const int cs = finish(A, oa, ka);
+                if (ka < 0) cc_put(A, cs);
+            }
+            if (B.on) {
+                const int cs = finish(B, ob, kb);
+                if (kb < 0) cc_put(B, cs);
+            }
         }
         mj_team_sync<SP_NT>();
         if (prof) {
@@ -1746,6 +1775,11 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
         float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
         SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
     } s_tm;
+#if SP_CC_N > 0
+    __shared__ unsigned long long s_cc[SP_CC_N];  // the child cache of the expansion (sp_expand_chunk)
+    for (int i = threadIdx.x; i < SP_CC_N; i += SP_THREADS) s_cc[i] = 0ull;
+    unsigned n_graph_rows = 0;
+#endif
     SpWork* W = P.work + blockIdx.x;
     const int tid = threadIdx.x;
 
@@ -1779,6 +1813,20 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
         t_1 = wall_clock64();
         t_2 = t_3 = t_4 = t_1;
         if (with_probs) {
+#if SP_CC_N > 0
+            // a new row = a new epoch of the child cache (8 bits, 1..255; when they have gone round the cache is wiped)
+            n_graph_rows++;
+            if ((n_graph_rows & 255u) == 0u) {
+                n_graph_rows++;
+                for (int i = tid; i < SP_CC_N; i += SP_THREADS) s_cc[i] = 0ull;
+            }
+            if (tid == 0) {
+                X.cc = s_cc;
+                X.cc_epoch = n_graph_rows & 255u;
+            }
+#else
+            if (tid == 0) X.cc = nullptr;
+#endif
             // root states = level cur_shanten
             if (tid < n_cand) {  // one lane per candidate: the claims (one L2 atomic round trip each) run side by side
                 const int c = tid;
