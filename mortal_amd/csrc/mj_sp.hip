@@ -52,21 +52,25 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #define SP_WGS (4 * SP_WPS * 64 / SP_THREADS)  // resident workgroups per CU
 
 #ifndef SP_CC_N
-#define SP_CC_N 1024            // entries of the per-workgroup child cache in LDS (0 = off): row epoch << 56 | state id << 14 | slot
+#define SP_CC_N 2048            // entries of the per-workgroup child cache in LDS (0 = off): row epoch << 56 | state id << 14 | slot.
+                                // Measured (round 4, one box, mj_k_sp): none 20.01 ms, 512: 19.78, 1024: 19.73-19.77, 2048: 19.61 (16 KB: with the
+                                // rest 40.5 KB per workgroup, the last size that keeps four workgroups on a CU)
 #endif
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
 #define SP_L0_MAX 17            // winning draw entries per tenpai state (13 waits + 3 aka variants)
-struct SpNode {                 // one 3n+1 state (608 bytes, 16-byte aligned rows)
+struct SpNode {                 // one 3n+1 state (608 bytes, 16-byte aligned rows).  The first 64 bytes — key, header, level-0 counts — are
+                                // what the expansion / probe passes touch: ONE line (the header used to sit 576 bytes behind the key)
     u64 k0, k1, k2, k3;         // hand.mp | hand.sz + akas_in_hand<<48 | wall.mp | wall.sz + akas_in_wall<<48
-    float val[SP_T][4];         // per turn: tenpai prob, win prob, EV, bits of (int)EV (the fold key of discard_slow)
-    float sc[SP_L0_MAX][4];     // level 0: get_score() of every draw entry (sp_l0_score)
     u32 child_off;              // level > 0: first pool entry of the child list; level 0: bit e = draw entry e has a yaku
     unsigned short n_ch;        // level > 0: number of pool entries; level 0: number of draw entries
     u8 sumreq, n_ent;           // sum over the required tiles of their wall counts (row of the not_tsumo table); draw entries
     u8 l0cnt[SP_L0_MAX + 3];    // level 0: copies left in the wall of every draw entry (its tsumo_prob row)
+    u8 pad_[4];
+    float val[SP_T][4];         // per turn: tenpai prob, win prob, EV, bits of (int)EV (the fold key of discard_slow)
+    float sc[SP_L0_MAX][4];     // level 0: get_score() of every draw entry (sp_l0_score)
 };
-static_assert(sizeof(SpNode) == 608 && offsetof(SpNode, val) % 16 == 0 && offsetof(SpNode, sc) % 16 == 0, "SpNode layout");
+static_assert(sizeof(SpNode) == 608 && offsetof(SpNode, val) == 64 && offsetof(SpNode, sc) % 16 == 0, "SpNode layout");
 static_assert(offsetof(SpNode, child_off) % 8 == 0 && offsetof(SpNode, n_ch) == offsetof(SpNode, child_off) + 4 &&
               offsetof(SpNode, sumreq) == offsetof(SpNode, child_off) + 6, "the evaluation reads the header as one u64");
 // A child-list entry: hash slot of the child | discard order key << 14 | last-discard-of-its-draw-entry << 23 |
