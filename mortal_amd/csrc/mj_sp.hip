@@ -849,7 +849,12 @@ __device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, in
         // The child cache (round 4): a child is looked up by ~6 parents, most of them neighbours in the level list, and five look-ups
         // in six only need its slot.  A direct-mapped table in LDS remembers (state id -> slot) of the children this workgroup saw
         // last: a hit costs one ds_read and no tag line from L2 / HBM (a 128-byte line per 8-byte tag otherwise).
+#if SP_CC_N > 0
         unsigned long long* const cc = X->cc;
+        SP_ASSUME_LDS(cc);  // (a generic pointer would turn the look-up into a flat_load, which waits for every HBM gather in flight)
+#else
+        unsigned long long* const cc = nullptr;
+#endif
         const u64 cc_ep = (u64)X->cc_epoch << 42;
         auto cc_look = [&](const Ent& E) -> int {
             if (!cc || !E.on) return -1;
