@@ -250,6 +250,49 @@ MJD u32 sp_dk_pos(u64 dk) {  // first probe position
 static_assert(SP_CAP == 1 << 14, "sp_dk_pos returns 14 bits");
 #define SP_TAG(dk) ((dk) | (1ull << 63))  // never 0 (0 = empty slot)
 
+// ---- register pressure across the persistent row loop (round 4; every step measured inside one gpurun call)
+// mj_k_sp keeps 128 VGPRs / ~100 SGPRs for a loop body of 19 k instructions.  Two things sent registers through scratch memory,
+// and scratch traffic of 1,024 workgroups does not stay in L2 (4 MB per XCD):
+//  * a __noinline__ callee saves and restores its callee-saved VGPRs on every call: 37 stores + 37 loads per expansion chunk =
+//    19 KB per 16 states.  The expansion is therefore inlined into the kernel (one call site); the evaluation / level-0 functions
+//    stay calls (a call there is a wavefront's whole share of a level; inlining them was measured slower: their loops then spill).
+//  * lane-derived constants (lane -> suit / state index, LDS addresses) are loop-invariant, so the compiler computed them at the
+//    top of the kernel and spilled them (50 stores up front, reloads inside the probe passes).  An opaque copy of the lane id per
+//    row / per chunk stops the hoisting: the constants are recomputed (1-2 VALU) where they are used.
+// Measured: 20.93 -> 19.76 ms (inline) -> 18.45 ms (+ opaque lane id) on one box; 19.99 -> 18.17 ms on another.
+#ifndef SP_OPAQUE_TID
+#define SP_OPAQUE_TID 2  // 0: off, 1: per expansion chunk, 2: + per row of the queue
+#endif
+#if defined(MJ_EMU)
+#define SP_OPQ(level, v) (v)
+#else
+__device__ __forceinline__ int sp_opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
+#define SP_OPQ(level, v) ((SP_OPAQUE_TID) >= (level) ? sp_opaque_v(v) : (v))
+#endif
+// ... and of a uniform pointer (the table directory in constant memory, the work area).  Measured neutral to slightly slower
+// (18.82 vs 18.45 ms): off by default.
+#if defined(MJ_EMU) || !defined(SP_OPAQUE_PTR)
+#define SP_OPQ_PTR(level, p) (p)
+#else
+template <typename Tp> __device__ __forceinline__ Tp* sp_opaque_s(Tp* p) { asm volatile("" : "+s"(p)); return p; }
+#define SP_OPQ_PTR(level, p) ((SP_OPAQUE_PTR) >= (level) ? sp_opaque_s(p) : (p))
+#endif
+#ifndef SP_ATTR_EXPAND
+#define SP_ATTR_EXPAND __forceinline__
+#endif
+#ifndef SP_ATTR_L0P
+#define SP_ATTR_L0P __noinline__
+#endif
+#ifndef SP_ATTR_L0S
+#define SP_ATTR_L0S __noinline__
+#endif
+#ifndef SP_ATTR_EVAL
+#define SP_ATTR_EVAL __noinline__
+#endif
+#ifndef SP_ATTR_EVAL0
+#define SP_ATTR_EVAL0 __noinline__
+#endif
+
 template <class TagP>
 MJD u64 sp_claim_tag(TagP tagp, u64 h, u64 expected = 0ull) {  // atomicCAS(tag, 0, h) -> previous value (relaxed, agent scope)
     __hip_atomic_compare_exchange_strong(tagp, &expected, h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -389,7 +432,7 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
 //   probe : sp_l0_probe_chunk — which draws win (34 shanten probes per state) -> draw entries, one work item per entry
 //   score : THREAD per item, dense across the workgroup                  -> 4 scores per entry in the node (sc[])
 //   sum   : team per state — sp_eval_wave0 accumulates the scores in the reference's order
-__device__ __noinline__ void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
+__device__ SP_ATTR_L0S void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
     SP_ASSUME_LDS(X);
     const int slot = item & 0x3FFF, idx = (item >> 14) & 31, t = (item >> 19) & 63, variant = (item >> 25) & 1;
     SP_HBM SpNode& node = ((SP_HBM SpWork*)W)->node[slot];
@@ -496,7 +539,7 @@ __device__ __noinline__ u64 sp_keep_brute_dev(Hand g, int ld3, int Tg) { return 
 // Passes P0-P1c, shared by the expansion (L >= 1) and the level-0 probe (L == 0): state keys, row ids, optimal entries ->
 // req[s] = the draws left in the wall that lower the shanten number of state s.
 __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunk* C, const SpTabG& TG, int first, int n, int L) {
-    const int tid = threadIdx.x & (SP_NT - 1);
+    const int tid = SP_OPQ(1, (int)(threadIdx.x & (SP_NT - 1)));
     const int ld3 = X->len_div3;
     for (int task = tid; task < n * 4; task += SP_NT) {
         const int s = task >> 2, j = task & 3;
@@ -565,11 +608,11 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
 
 // Level 0: which draws win and one scoring work item per draw entry, in the reference's order (plain tile if a non-red
 // copy is left, then the red five); the node gets the entry counts, their number and the not_tsumo row.
-__device__ __noinline__ void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, int first, int n) {
+__device__ SP_ATTR_L0P void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, int first, int n) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(C);
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const SpTabG TG = sp_tab_g(c_sp_tab);
+    const SpTabG TG = sp_tab_g(*SP_OPQ_PTR(1, &c_sp_tab));
     sp_chunk_probe(Wg, X, C, TG, first, n, 0);
     const int s = threadIdx.x & (SP_NT - 1);
     if (s < n) {
@@ -610,12 +653,12 @@ __device__ __noinline__ void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
 }
 
 // Levels >= 1: required draws, shanten-keeping discards and the children of SP_NS states.
-__device__ __noinline__ void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, int first, int n, int L) {
+__device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, int first, int n, int L) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(C);
-    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
-    const SpTabG TG = sp_tab_g(c_sp_tab);
-    const int tid = threadIdx.x & (SP_NT - 1);
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)SP_OPQ_PTR(2, W);
+    const SpTabG TG = sp_tab_g(*SP_OPQ_PTR(1, &c_sp_tab));
+    const int tid = SP_OPQ(1, (int)(threadIdx.x & (SP_NT - 1)));
     const int ld3 = X->len_div3;
     // optional pass timers (MJ_SP_PROF): wave wall-clock per pass, summed into prof[8..13] by lane 0
     const bool prof = X->prof != nullptr;
@@ -939,7 +982,7 @@ struct alignas(16) SpF4 { float x, y, z, w; };
 // Per step up to SP_EV_ENT entries of every team: lane j parks A[j] = tsumo_prob[count][j] * not_tsumo[j], then every lane i adds
 // prob(i, j) and prob(i, j) * score for j = i .. T-1 (the score picked by riichi-ippatsu at j == i, haitei at j == T-1: calc.rs:510-527).
 template <int TN>
-__device__ __noinline__ void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int first, int end, int stride, int lane_in_team, int off_,
+__device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int first, int end, int stride, int lane_in_team, int off_,
                                            int team_in_wave, bool team_on) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(WL);
@@ -1090,7 +1133,7 @@ __device__ __noinline__ void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int f
 // the next states' headers) are issued before the accumulate and consumed after it.  The f32 operation order per lane is the
 // reference's: entries in list order, turns ascending.
 template <int TN, int LK>
-__device__ __noinline__ void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int first, int end, int stride, int lane_in_team, int off_,
+__device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int first, int end, int stride, int lane_in_team, int off_,
                                           int team_in_wave, bool team_on) {
     static_assert(LK >= 1, "level 0 has no children: sp_eval_wave0");
     SP_ASSUME_LDS(X);
@@ -1790,7 +1833,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     unsigned n_graph_rows = 0;
 #endif
     SpWork* W = P.work + blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid_wg = threadIdx.x, tid = tid_wg;
 
     // the hash tags start empty: zeroed once when the work area is allocated, and every row clears the tags it set
 
@@ -1803,6 +1846,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     const int n_heavy = P.n_rows - P.queue[1 + 7];
     bool wave_mode = false;
     for (;;) {
+        const int tid = SP_OPQ(2, tid_wg);
         const long long t_a = P.prof ? wall_clock64() : 0;
         if (tid == 0) s_row = atomicAdd(P.queue, 1);
         __syncthreads();
