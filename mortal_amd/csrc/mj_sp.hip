@@ -476,6 +476,15 @@ MJD u32 sp_wave_scan_incl(u32 v) {
 #endif
 }
 
+// The value lane `lane` holds (wave-uniform lane number): v_readlane on the device, no LDS crossbar.
+MJD int sp_lane_get(int v, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MJ_EMU)
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
+#else
+    return __shfl(v, lane);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense expansion / level-0 probe: SP_NS states of one level at a time PER WAVEFRONT, every phase a THREAD-PER-TASK pass
 // over the 64 lanes, separated by wave-level LDS hand-offs (mj_team_sync<64>): no workgroup barrier inside a level, four
@@ -670,37 +679,23 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
     const long long t_probe = tq1 - tq0;
 
     // The draw items (state, required tile) are processed in sub-batches of whole states with at most SP_ITEM_CAP = 64 items:
-    // one lane per item.  A chunk with more items is split into sub-batches of about equal size.  The per-state item counts
-    // are read ONCE (16 bytes) and every prefix below is register arithmetic over static indices, not a chain of LDS reads.
-    u32 ntw[SP_NS / 4];
-#pragma unroll
-    for (int w = 0; w < SP_NS / 16; w++) {
-        const SpRec raw = reinterpret_cast<const SpRec*>(C->n_tiles)[w];  // 16-byte LDS reads
-        ntw[4 * w] = raw.x; ntw[4 * w + 1] = raw.y; ntw[4 * w + 2] = raw.z; ntw[4 * w + 3] = raw.w;
-    }
-    auto nt_of = [&](auto sc) -> int {  // static state index
-        constexpr int q = decltype(sc)::value;
-        return q < SP_NS ? (int)((ntw[q >> 2] >> (8 * (q & 3))) & 0xFFu) : 0;
-    };
-    int total_items = 0;
-    sp_static_for<0, SP_NS>([&](auto sc) { if (decltype(sc)::value < n) total_items += nt_of(sc); });
+    // one lane per item.  A chunk with more items is split into sub-batches of about equal size.  Lane q < n holds the item count
+    // of state q; ONE wavefront scan gives every prefix the sub-batch logic needs (round 4: the unrolled walk over the 16 states
+    // with its running sums was 370 instructions per sub-batch, a fifth of the layout pass another 100).
+    const int nt_lane = tid < n ? (int)C->n_tiles[tid] : 0;
+    const int pre_in = (int)sp_wave_scan_incl((u32)nt_lane), pre_ex = pre_in - nt_lane;
+    const int total_items = sp_lane_get(pre_in, SP_NT - 1);
     const int n_sub = (total_items + SP_ITEM_CAP - 1) / SP_ITEM_CAP, target = n_sub > 1 ? (total_items + n_sub - 1) / n_sub : SP_ITEM_CAP;
     for (int sb = 0; sb < n;) {
         long long tp0 = prof ? wall_clock64() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
-        int se = sb, n_items = 0;  // uniform over the wavefront
-        int my_first = 0;          // first item of state `tid`
-        {
-            bool stopped = false;
-            sp_static_for<0, SP_NS>([&](auto sc) {
-                constexpr int q = decltype(sc)::value;
-                if (q < sb || q >= n || stopped) return;
-                const int nt = nt_of(sc);
-                if (q > sb && (n_items + nt > SP_ITEM_CAP || n_items >= target)) { stopped = true; return; }
-                if (q == tid) my_first = n_items;
-                n_items += nt;
-                se = q + 1;
-            });
-        }
+        // the sub-batch [sb, se): state q > sb ends it if its items do not fit any more or the target is reached (both conditions
+        // are monotone in q, so the first lane that raises its hand is the end)
+        const int base = sp_lane_get(pre_ex, sb);
+        const bool stop = tid > sb && tid < n && (pre_in - base > SP_ITEM_CAP || pre_ex - base >= target);
+        const u64 stop_m = __ballot(stop);
+        const int se = stop_m ? __ffsll((long long)stop_m) - 1 : n;  // uniform over the wavefront
+        const int n_items = sp_lane_get(pre_ex, se) - base;          // (lane n holds 0 items: its exclusive prefix is the total)
+        const int my_first = pre_ex - base;                          // first item of state `tid`
         // item list: one lane per state walks its required-draw set (ascending); a state without draws left gets its header now
         if (tid >= sb && tid < se) {
             const int s = tid;
@@ -762,14 +757,9 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
             const int nvar = has_item && sp_aka_in_wall(S, my_t) ? (wc >= 2 ? 2 : 1) : 1;
             const int nkeep = __popcll(kept), my_ent = nvar * nkeep;
             const u32 pv = sp_wave_scan_incl(has_item ? ((u32)my_ent | ((u32)wc << 16) | ((u32)(nkeep ? nvar : 0) << 24)) : 0u);
-            int s_first = 0, s_n = 0;  // this lane's state: first item lane, items
-            sp_static_for<0, SP_NS>([&](auto sc) {
-                constexpr int q = decltype(sc)::value;
-                if (q < sb || q >= se) return;
-                const int nt = nt_of(sc);
-                if (q < my_s) s_first += nt;
-                if (q == my_s) s_n = nt;
-            });
+            // this lane's state: first item lane, items (one shuffle of the state lane's prefix | count)
+            const int sfn = __shfl((pre_ex - base) | (nt_lane << 16), has_item ? my_s : sb);  // (lanes before sb are never asked)
+            const int s_first = sfn & 0xFFFF, s_n = sfn >> 16;
             const int s_last = s_first + s_n - 1;
             const u32 before = __shfl(pv, max(s_first - 1, 0)), upto = __shfl(pv, max(s_last, 0)), all = __shfl(pv, SP_NT - 1);
             const u32 base = s_first > 0 ? before : 0u;
