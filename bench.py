@@ -49,31 +49,57 @@ STATE_READ_BYTES = 1500  # per-decision state read
 STAGGER = [True]  # --no-start-stagger: all tables start at once, like rounds 1-2 measured (the timed window then sees ONE phase)
 
 
-def _cpu_worker(version, budget_s, n_tables, wid):
-    """One CPU worker process: oracle arenas of n_tables tables, back to back, until the time budget is spent."""
+def _cpu_worker(version, budget_s, n_tables, wid, preroll):
+    """One CPU worker process: ONE oracle arena of n_tables tables under the protocol the GPU line is timed under — every slot
+    parked, slot t entering play at cycle hash(t) % preroll, finished slots refilled on a fresh seed — `preroll` untimed cycles
+    with masks only (no obs: the cheap way through the early game), then timed cycles with the obs of EVERY decision encoded
+    (v4: SP tables included) until the budget is spent."""
+    import numpy as np
     import oracle_lib as O
 
     O.lib()
+    g0 = wid * n_tables
+    seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(n_tables)]
+    algo = 0 if os.environ.get("MORTAL_AMD_DEAL_ALGO", "rand09").lower() in ("0", "rand08", "rand0.8", "0.8") else 1
+    arena = O.Arena(seeds, deal_algo=algo, enable_quick_eval=True, version=version, keep_log=False)  # pool.default_deal_algo()
+    stride = 1 << 24  # nonce stride of a restart: no other slot / worker uses the seed
+    nonce = [s[0] for s in seeds]
+    starts = np.zeros(n_tables, dtype=np.int64)
+    if preroll > 0:
+        arena.park()
+        starts = np.array([(((t * 2654435761) & 0xFFFFFFFF) >> 8) % preroll for t in range(n_tables)])
+    started = 0 if preroll > 0 else n_tables
+
+    def one_cycle(cycle, want_obs):
+        nonlocal started
+        if cycle < preroll:
+            for g in np.flatnonzero(starts == cycle).tolist():
+                nonce[g] += stride
+                arena.restart(g, nonce[g])
+                started += 1
+        rows = arena.poll()
+        n = len(rows)
+        if n:
+            obs, masks = arena.encode(0, n, want_obs=want_obs)
+            arena.commit(O.random_actions(masks, rows, cycle))
+        if arena.n_live < started:  # somebody finished: restart on a fresh seed (the pool's refill mode)
+            for g in range(n_tables):
+                if starts[g] <= cycle and arena.result(g)[1]:
+                    nonce[g] += stride
+                    arena.restart(g, nonce[g])
+        return n
+
+    t_pre = time.perf_counter()
+    for c in range(preroll):
+        one_cycle(c, False)
     t0 = time.perf_counter()
-    cycles = rows_total = steps = batches = 0
+    s0 = arena.steps
+    cycle, rows_total = preroll, 0
     while time.perf_counter() - t0 < budget_s:
-        g0 = (wid * 1000 + batches) * n_tables
-        seeds = [(10000 + (g0 + g) // 4, KEY) for g in range(n_tables)]
-        algo = 0 if os.environ.get("MORTAL_AMD_DEAL_ALGO", "rand09").lower() in ("0", "rand08", "rand0.8", "0.8") else 1
-        arena = O.Arena(seeds, deal_algo=algo, enable_quick_eval=True, version=version, keep_log=False)  # pool.default_deal_algo()
-        cycle = 0
-        while arena.n_live > 0 and time.perf_counter() - t0 < budget_s:
-            rows = arena.poll()
-            n = len(rows)
-            obs, masks = arena.encode(0, n, want_obs=True)  # the oracle encodes every decision like the GPU path
-            act = O.random_actions(masks, rows, cycle)
-            arena.commit(act)
-            cycle += 1
-            rows_total += n
-        steps += arena.steps
-        cycles += cycle
-        batches += 1
-    return dict(steps=steps, cycles=cycles, rows=rows_total, arenas=batches, dt=time.perf_counter() - t0)
+        rows_total += one_cycle(cycle, True)
+        cycle += 1
+    return dict(steps=arena.steps - s0, cycles=cycle - preroll, rows=rows_total, arenas=1, dt=time.perf_counter() - t0,
+                preroll_s=t0 - t_pre, preroll_steps=s0)
 
 
 def _usable_cores():
@@ -97,16 +123,45 @@ def _usable_cores():
     return cores
 
 
-def cpu_baseline(version, budget_s=12.0, n_tables=16):
-    """Oracle arena (CPU restatement) on a bounded sample of the same workload: one worker PROCESS per host core, each
-    running independent arenas (tables are independent, like the reference's rayon loop over games,
-    arena/game.rs:286-296).  value = sum over workers of steps_i / dt_i (all workers run concurrently)."""
+PUBLISHED_CONTEXT = ("the reference publishes ONE throughput figure for this path: 'up to 40K hanchans per hour' = 11.1 hanchan/s, "
+                     "Rust arena + Python net inference on an RTX 4090 + Ryzen 9 7950X, game batch size 2000 (docs/src/index.md:22,48); "
+                     "env steps/s are not published (BASELINE.md section 1), so vs_baseline stays null")
+
+
+def _native_oracle():
+    """BASELINE.md section 3 (fallback 2): the CPU restatement compiled -O3 -march=native ON the measurement host
+    (oracle/Makefile: native -> libmjoracle_native.so; never shipped).  Returns (path or None, flags string)."""
+    import subprocess
+
+    odir = os.path.join(ROOT, "oracle")
+    try:
+        subprocess.check_call(["make", "-C", odir, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        path = os.path.join(odir, "libmjoracle_native.so")
+        # (a library that was built on another host and does not run here must not cost the line: probe it in a child process)
+        ok = subprocess.call([sys.executable, "-c", f"import ctypes; ctypes.CDLL({path!r}).mjo_arena_n_live"], stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL) == 0
+        if ok:
+            return path, "-O3 -march=native (built on this host)"
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return None, "-O2 (portable build: the native build failed on this host)"
+
+
+def cpu_baseline(version, budget_s=30.0, tables_in_flight=2000, preroll=3072):
+    """Oracle arena (CPU restatement) on a bounded sample of the same workload, under the same protocol (staggered first starts
+    over `preroll` untimed cycles, refill): one worker PROCESS per host core, the reference's published batch of 2,000 games in
+    flight split over them (tables are independent, like the reference's rayon loop over games, arena/game.rs:286-296).
+    value = sum over workers of steps_i / dt_i (all workers run concurrently)."""
     import subprocess
 
     cores = _usable_cores()
+    n_tables = max(4, -(-tables_in_flight // cores // 4) * 4)  # whole duplicate-deal sets per worker
+    lib_path, flags = _native_oracle()
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    if lib_path:
+        env["MJ_ORACLE_LIB"] = lib_path
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), "--version", str(version),
-                               "--cpu-budget", str(budget_s), "--cpu-tables", str(n_tables)],
+                               "--cpu-budget", str(budget_s), "--cpu-tables", str(n_tables), "--cpu-preroll", str(preroll)],
                               stdout=subprocess.PIPE, env=env) for w in range(cores)]
     res = []
     for p in procs:
@@ -120,11 +175,13 @@ def cpu_baseline(version, budget_s=12.0, n_tables=16):
     import shutil
 
     toolchain = {"cargo": shutil.which("cargo"), "rustc": shutil.which("rustc")}  # probed on the measurement host
-    return dict(value=value, unit="env steps/s", cores=len(res), kind="port", reference_toolchain=toolchain,
-                sample=f"{len(res)} processes (1 per core) x arenas of {n_tables} tables for {budget_s:.0f}s each: "
-                       f"{tot['arenas']} arenas, {tot['cycles']} cycles, {tot['steps']} env steps, {tot['rows']} decisions "
-                       f"encoded (obs v{version}), random-legal policy, oracle/libmjoracle.so; the Rust reference is "
-                       f"not buildable here (no rustc)")
+    return dict(value=value, unit="env steps/s", cores=len(res), kind="port", reference_toolchain=toolchain, build=flags,
+                hanchan_per_hour_equiv=None, published_context=PUBLISHED_CONTEXT,
+                sample=f"{len(res)} processes (1 per core) x 1 arena of {n_tables} tables = {len(res) * n_tables} games in flight (the "
+                       f"reference's published batch size 2000), same protocol as the GPU line (first starts staggered over {preroll} "
+                       f"untimed mask-only cycles = {sum(r['preroll_s'] for r in res) / len(res):.1f} s, finished tables refilled), then "
+                       f"{budget_s:.0f} s timed: {tot['cycles']} cycles, {tot['steps']} env steps, {tot['rows']} decisions encoded "
+                       f"(obs v{version}), random-legal policy, oracle {flags}; the Rust reference is not buildable here (no rustc)")
 
 
 def _free_port():
@@ -248,15 +305,21 @@ def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmu
         if code:
             raise SystemExit(f"table {tbl} in error {code}")
     ph1 = [_phase_ticks(pool) for pool in pools] if ph0 is not None else None
-    tot = lambda key: sum(b[key] - a[key] for a, b in zip(c0, c1))
-    res = dict(steps=tot("steps"), games=tot("games"), dt=dt, rows=rows_timed, enc_ms=enc_ms, enc_launches=enc_launches, sp_ms=sp_ms,
+    def delta(key):
+        return sum(b[key] - a[key] for a, b in zip(c0, c1))
+
+    res = dict(steps=delta("steps"), games=delta("games"), dt=dt, rows=rows_timed, enc_ms=enc_ms, enc_launches=enc_launches, sp_ms=sp_ms,
                sp_launches=sp_launches, C=C, n_cycles=steps, sp_overflow=sum(c["sp_overflow"] for c in c1), n_pools=K)
     if ph0 is not None and all(p is not None for p in ph0 + ph1):
         d = {k: sum(b[k] - a[k] for a, b in zip(ph0, ph1)) for k in ph1[0]}
         tot_t = max(1, sum(d[k] for k in ("setup", "expand", "level0", "eval", "write")))
         res["sp_phases"] = {"share": {k: round(d[k] / tot_t, 4) for k in ("setup", "expand", "level0", "eval", "write")},
                             "states_per_step": d["states"] / steps, "rows_per_step": d["rows"] / steps, "overflows": d["overflow"]}
-    res["results"] = pools[0].results() if world > 1 else None
+    if world > 1:  # episode returns of EVERY pool of this rank (--pools K > 1 used to gather the first pool's only)
+        parts = [pool.results() for pool in pools]
+        res["results"] = (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+    else:
+        res["results"] = None
     for pool in pools:
         pool.close()
     return res
@@ -325,12 +388,14 @@ def main():
                     help="rendezvous only: spawn / join the --gpus N ranks, all-reduce one token over --dist-backend, print the rank "
                          "count on rank 0 and exit before any GPU work (CPU test of the launcher: tests/test_bench_contract.py)")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-tables", type=int, default=16, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="timed seconds of the CPU baseline (oracle, one process per core)")
+    ap.add_argument("--cpu-tables", type=int, default=2000,
+                    help="CPU baseline: games in flight over all cores (the reference's published batch size); for a --cpu-worker: its own tables")
+    ap.add_argument("--cpu-preroll", type=int, default=3072, help="CPU baseline: untimed mask-only cycles with staggered first starts")
     args = ap.parse_args()
     STAGGER[0] = not args.no_start_stagger
     if args.cpu_worker >= 0:
-        print(json.dumps(_cpu_worker(args.version, args.cpu_budget, args.cpu_tables, args.cpu_worker)))
+        print(json.dumps(_cpu_worker(args.version, args.cpu_budget, args.cpu_tables, args.cpu_worker, args.cpu_preroll)))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -357,8 +422,22 @@ def main():
             dist.all_reduce(t)
             assert int(t.item()) == world
             dist.destroy_process_group()
+        out = {"launch_check": True, "ranks": world, "gpus": args.gpus, "self_launched": os.environ.get("MORTAL_AMD_BENCH_SELF_LAUNCH") == "1"}
+        if world == 1 and args.dist_backend == "nccl" and torch.cuda.is_available():
+            # one GPU: a one-rank RCCL communicator and one all-reduce on the device, so that librccl is loaded and a collective
+            # has run at least once before the driver finds a multi-GPU node; no scaling claim
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                    device_id=torch.device("cuda:0"))
+            t = torch.ones(4, dtype=torch.float32, device="cuda:0")
+            dist.all_reduce(t)
+            g = [torch.empty_like(t)]
+            dist.all_gather(g, t)
+            torch.cuda.synchronize()
+            out["rccl_world1"] = bool((t == 1).all().item() and (g[0] == 1).all().item())
+            out["rccl_loaded"] = "rccl" in open("/proc/self/maps").read()
+            dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"launch_check": True, "ranks": world, "gpus": args.gpus, "self_launched": os.environ.get("MORTAL_AMD_BENCH_SELF_LAUNCH") == "1"}))
+            print(json.dumps(out))
         return
     if args.dist_backend == "nccl" and world > max(1, torch.cuda.device_count()):
         raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node has {torch.cuda.device_count()} "
@@ -431,9 +510,13 @@ def main():
             "obs_v3_random": _brief(_measure(TablePool, N, g0, world, dev, 3, args.preroll, "random", 10 * k, 10, bufs)),
             "obs_v4_random_no_preroll": _brief(_measure(TablePool, N, g0, world, dev, 4, 0, "random", k, 3, bufs)),
             "obs_v4_greedy": _brief(_measure(TablePool, N, g0, world, dev, 4, args.preroll, "greedy", k, 3, bufs)),
+            # BASELINE configs[1] (C2): 4,096 tables, random-action policy, env-step kernels (+ encode of every decision)
+            "cfg1_4096_v3": _brief(_measure(TablePool, 4096, g0, world, dev, 3, args.preroll, "random", 20 * k, 20, bufs)),
+            "cfg1_4096_v4": _brief(_measure(TablePool, 4096, g0, world, dev, 4, args.preroll, "random", 6 * k, 10, bufs)),
             "brain_v4": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs,
                                         other_ms=(dt * 1e3 - enc_ms - sp_ms) / args.steps),
-            "note": "brain_v4 = BASELINE configs[2]: full self-play cycle with a random-init net of the reference's Brain/DQN shape "
+            "note": "cfg1_4096_v3 / _v4 = BASELINE configs[1]: 4,096 tables, uniform-random legal policy, the same protocol as the headline; "
+                    "brain_v4 = BASELINE configs[2]: full self-play cycle with a random-init net of the reference's Brain/DQN shape "
                     "(192 channels x 40 blocks, fp16 autocast = torch.autocast's default on this backend like mortal/engine.py:46, greedy argmax) consuming the encoded batch in place on the same GPU; "
                     "2 timed cycles (the net takes seconds per 65 k-row batch); env_share = (step + encode + SP kernels) / cycle; "
                     "obs_v3_random = env-step + encode only (no SP block); obs_v4_random_no_preroll = every table in the first "
@@ -523,7 +606,10 @@ def main():
         if matrix:
             line["workloads"] = matrix
         if not args.no_cpu_baseline and world == 1 and args.policy == "random":  # reported at N=1 only (rank 0)
-            line["cpu_baseline"] = cpu_baseline(args.version, args.cpu_budget, args.cpu_tables)
+            cb = cpu_baseline(args.version, args.cpu_budget, args.cpu_tables, args.cpu_preroll)
+            # the published figure's unit, for the eye only: hanchan/h at the measured games-per-step ratio of the GPU run
+            cb["hanchan_per_hour_equiv"] = cb["value"] * (games / max(steps, 1)) * 3600.0
+            line["cpu_baseline"] = cb
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -3,11 +3,37 @@ mortal/train.py / train_grp.py build a `SummaryWriter`; this image has no `tenso
 package satisfies torch's import (`torch/utils/tensorboard/__init__.py` checks `tensorboard.__version__ >= 1.15`, then pulls
 protobuf / writer classes out of a dozen `tensorboard.*` sub-modules): every sub-module resolves to a stub whose attributes are
 inert classes, so `torch.utils.tensorboard.SummaryWriter(...)` constructs and every `add_*` / `flush` / `close` call is a no-op.
-Nothing is written anywhere.  A real tensorboard installation earlier on the path wins, as it should."""
+Nothing is written anywhere.
+
+INTEGRATION.md puts `compat/` FIRST on PYTHONPATH (the toml shim needs that), so this package would shadow a real tensorboard
+on a machine that has one and train.py's SummaryWriter would silently write nothing.  Therefore: at import the rest of sys.path
+is searched for a real `tensorboard`; if there is one it is loaded in this package's place (`sys.modules["tensorboard"]` becomes
+the real package), otherwise the no-op shim installs itself and says so once on stderr."""
 import importlib.abc
 import importlib.machinery
+import importlib.util
+import os
 import sys
 import types
+
+
+def _real_tensorboard():
+    """The spec of a `tensorboard` package found on sys.path outside this directory's parent, or None."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    others = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != here]
+    try:
+        return importlib.machinery.PathFinder.find_spec("tensorboard", others)
+    except (ImportError, ValueError):
+        return None
+
+
+_spec = _real_tensorboard()
+if _spec is not None and _spec.loader is not None:
+    _real = importlib.util.module_from_spec(_spec)
+    sys.modules[__name__] = _real  # `import tensorboard` (this very import) hands back the real package
+    _spec.loader.exec_module(_real)
+else:
+    print("mortal_amd compat: no tensorboard installed, SummaryWriter calls are no-ops (compat/tensorboard shim)", file=sys.stderr)
 
 __version__ = "2.15.0+mortal-amd-noop-shim"
 
@@ -106,5 +132,5 @@ class _NullEventFileWriter:
         pass
 
 
-if not any(isinstance(f, _Finder) for f in sys.meta_path):
+if _spec is None and not any(isinstance(f, _Finder) for f in sys.meta_path):  # (never next to a real tensorboard)
     sys.meta_path.append(_Finder())

@@ -15,7 +15,6 @@
 #include "mj_replay.hip"
 #include "mj_encode.hip"
 #include "mj_sp.hip"
-#include "mj_sp2.hip"
 
 static_assert(sizeof(MjAlgoQuery) == 72, "MjAlgoQuery layout");
 // include/mortal_amd.h mj_algo_query: one thread per query, the same device functions the step / encode / SP kernels call
@@ -153,11 +152,6 @@ struct MjPool {
     uint8_t* sp_cls = nullptr;      // [max_rows] cost class of a row
     unsigned long long* sp_err = nullptr;
     int* enc_flag = nullptr;        // [1] an encoder op list overflowed (reported with the SP overflows)
-    SpG spg = {};                   // the per-phase SP pipeline's work area (mj_sp2.hip), lazily allocated on the first v4 encode
-    bool spg_ready = false;
-    int sp_pipeline = -1;           // 0 = mj_k_sp (one row per workgroup), 1 = per-phase pipeline (MJ_SP_PIPELINE=phase), -1 = not decided yet
-    int spg_grid = 0;               // persistent workgroups per phase launch
-    int* spg_cnt = nullptr;         // [2 * SPG_N_CLASS] class counts / cursors of the setup order
     int* n_rows_host = nullptr;  // pinned
     unsigned long long* counters = nullptr;
     int* final_scores = nullptr;
@@ -268,15 +262,6 @@ int mj_tables_upload(const void* payload, size_t size) {
         if (upload(nt, &d_nt)) return -1;
         const float* d_ntc = d_nt;
         HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_sp_nt), &d_ntc, sizeof d_ntc));
-        {  // (c + 1) / x for every x = wall size - turn (mj_sp2.hip: the tsumo_prob entries of a state's row)
-            std::vector<float> tp(124 * 4);
-            spg_tp_build(tp.data());
-            float* d_tp = nullptr;
-            HIP_OK(hipMalloc(&d_tp, tp.size() * sizeof(float)));
-            HIP_OK(hipMemcpy(d_tp, tp.data(), tp.size() * sizeof(float), hipMemcpyHostToDevice));
-            const float* d_tpc = d_tp;
-            HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_spg_tp), &d_tpc, sizeof d_tpc));
-        }
     }
     auto g = build_gather();
     g_tables.n_gather = (int)g.size();
@@ -355,11 +340,6 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->sp_cls);
     hipFree(P->sp_err);
     hipFree(P->enc_flag);
-    if (P->spg_ready) {
-        hipFree(P->spg.tag); hipFree(P->spg.node); hipFree(P->spg.pool); hipFree(P->spg.items); hipFree(P->spg.ctx); hipFree(P->spg.rinfo);
-        hipFree(P->spg.ctl); hipFree(P->spg_cnt);
-        for (int l = 0; l < 4; l++) { hipFree(P->spg.raw[l]); hipFree(P->spg.lst[l]); hipFree(P->spg.blk[l]); }
-    }
     hipFree(P->log);
     hipFree(P->log_len);
     hipFree(P->rp_script); hipFree(P->rp_off); hipFree(P->rp_cursor); hipFree(P->rp_ev_index);
@@ -694,15 +674,9 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     }
     HIP_OK(hipGetLastError());
     if (ep.version == 4) {  // SP block, rows 889..1011
-        // Two implementations, bit-identical results.  Default: one decision row per persistent workgroup (mj_sp.hip: mj_k_sp).
-        // MJ_SP_PIPELINE=phase: the per-phase pipeline of mj_sp2.hip (every phase its own launch over the state graphs of ALL rows) —
-        // built and measured in round 4: 34.8 ms against 21.9 ms per cycle at 65,536 tables, because a row's states no longer meet
-        // in one CU's L1 / one XCD's L2 (profiles/r04_spg_*); kept selectable and covered by the parity tests.
-        if (P->sp_pipeline < 0) {  // decided once per pool, when its first obs-v4 batch is encoded
-            const char* pipe = getenv("MJ_SP_PIPELINE");
-            P->sp_pipeline = (pipe && strcmp(pipe, "phase") == 0) ? 1 : 0;
-        }
-        const bool legacy = P->sp_pipeline == 0;
+        // one decision row per persistent workgroup (mj_sp.hip: mj_k_sp).  Round 4 also built a per-phase pipeline (every phase its own launch
+        // over the state graphs of ALL rows: 34.8 ms against 21.9 ms, DESIGN.md section 6, profiles/r04_spg_*); it left the tree in round 5
+        // (git: mortal_amd/csrc/mj_sp2.hip up to commit 73bd82e).
         if (!P->sp_err) {
             HIP_OK(hipMalloc(&P->sp_err, 32 * sizeof(unsigned long long)));
             HIP_OK(hipMemset(P->sp_err, 0, 32 * sizeof(unsigned long long)));
@@ -715,7 +689,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
             HIP_OK(hipEventCreate(&s1));
             HIP_OK(hipEventRecord(s0, s));
         }
-        if (legacy) {
+        {
             if (!P->sp_work) {
                 P->sp_grid = 256 * SP_WGS;  // persistent workgroups: SP_WGS per CU, one decision row each at a time
                 if (P->sp_grid > P->max_rows) P->sp_grid = P->max_rows;  // never more rows than that in a launch (small pools: small work area)
@@ -741,75 +715,6 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
             hipLaunchKernelGGL(mj_k_order_classify, dim3((n + 255) / 256), dim3(256), 0, s, P->snap, sp.rows, n, P->sp_cls, P->sp_queue + 1);
             hipLaunchKernelGGL(mj_k_order_scatter, dim3((n + 255) / 256), dim3(256), 0, s, P->sp_cls, n, P->sp_queue + 1, P->sp_queue + 9, P->sp_order);
             hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
-        } else {
-            // ---- the per-phase pipeline (mj_sp2.hip): every phase its own launch over the state graphs of ALL rows
-            if (!P->spg_ready) {
-                SpG& g = P->spg;
-                // hash slots: a decision row has up to ~6 k states, a whole pool ~330 (steady state) to ~440 (every table in the first
-                // turns of E1) per table: 2,048 per table, at least 2^19 (small pools are all-heavy at cycle 0), at most 2^26
-                size_t cap = (size_t)1 << 19;
-                while (cap < (size_t)P->n_tables * 2048 && cap < ((size_t)1 << SPG_SLOT_BITS)) cap <<= 1;
-                if (const char* c = getenv("MJ_SPG_CAP_LOG2")) cap = (size_t)1 << std::max(12, std::min(SPG_SLOT_BITS, atoi(c)));  // tests: a small set (overflow paths)
-                g.cap_mask = (u32)(cap - 1);
-                g.lst_cap = (u32)std::max<size_t>(cap / 2, 1u << 12);
-                g.pool_cap = (u32)std::min<size_t>(std::max<size_t>(cap * 4, 4 * SPG_POOL_BLK), 0xFFFF0000u);
-                g.items_cap = (u32)std::max<size_t>(cap / 4, 1u << 12);
-                g.ctx_cap = (u32)P->max_rows;
-                HIP_OK(hipMalloc(&g.tag, cap * sizeof(u64)));
-                HIP_OK(hipMalloc(&g.node, cap * sizeof(SpNode)));
-                for (int l = 0; l < 4; l++) {
-                    HIP_OK(hipMalloc(&g.raw[l], (size_t)g.lst_cap * sizeof(u64)));
-                    HIP_OK(hipMalloc(&g.lst[l], (size_t)g.lst_cap * sizeof(u64)));
-                    HIP_OK(hipMalloc(&g.blk[l], (size_t)(g.lst_cap / SPG_BLK) * sizeof(u32)));
-                }
-                HIP_OK(hipMalloc(&g.pool, (size_t)g.pool_cap * sizeof(u64)));
-                HIP_OK(hipMalloc(&g.items, (size_t)g.items_cap * sizeof(u64)));
-                HIP_OK(hipMalloc(&g.ctx, (size_t)g.ctx_cap * sizeof(SpCtx)));
-                HIP_OK(hipMalloc(&g.rinfo, (size_t)g.ctx_cap * sizeof(SpGRow)));
-                HIP_OK(hipMalloc(&g.ctl, SPG_C_N * sizeof(u32)));
-                HIP_OK(hipMalloc(&P->spg_cnt, 2 * SPG_N_CLASS * sizeof(int)));
-                // persistent workgroups of 4 wavefronts: up to 8 per CU (the kernels' own occupancy decides how many are resident); small pools
-                // (tests, single tables) launch few: an idle workgroup still costs its launch
-                P->spg_grid = std::max(8, std::min(256 * 8, P->n_tables / 8 / 8 * 8));  // a multiple of 8: one contiguous piece of the work per XCD
-                if (const char* gr = getenv("MJ_SP_GRID")) P->spg_grid = std::max(1, std::min(P->spg_grid, atoi(gr)));
-                P->spg_ready = true;
-            }
-            const SpG& g = P->spg;
-            HIP_OK(hipMemsetAsync(g.tag, 0, ((size_t)g.cap_mask + 1) * sizeof(u64), s));
-            HIP_OK(hipMemsetAsync(g.ctl, 0, SPG_C_N * sizeof(u32), s));
-            HIP_OK(hipMemsetAsync(P->spg_cnt, 0, 2 * SPG_N_CLASS * sizeof(int), s));
-            SpGParams sp;
-            sp.g = g;
-            sp.snap = P->snap;
-            sp.rows = P->rows[agent & 1];
-            sp.n_rows = n;
-            sp.obs = obs;
-            sp.order = P->sp_order;
-            sp.err = P->sp_err;
-            sp.level = 0;
-            const int grid = P->spg_grid;
-            hipLaunchKernelGGL(mj_k_spg_classify, dim3((n + 255) / 256), dim3(256), 0, s, P->snap, sp.rows, n, P->sp_cls, P->spg_cnt);
-            hipLaunchKernelGGL(mj_k_spg_scatter, dim3((n + 255) / 256), dim3(256), 0, s, P->sp_cls, n, P->spg_cnt, P->spg_cnt + SPG_N_CLASS, P->sp_order);
-            hipLaunchKernelGGL(mj_k_spg_setup, dim3(std::min(grid, (n + 4 * SPG_SETUP_RUN - 1) / (4 * SPG_SETUP_RUN))), dim3(256), 0, s, sp);
-            const int rg_grid = std::max(1, std::min(grid, 512));
-            for (int L = 3; L >= 1; L--) {
-                sp.level = L;
-                hipLaunchKernelGGL(mj_k_spg_regroup, dim3(rg_grid), dim3(256), 0, s, sp);  // roots of L-shanten rows + children of level L + 1
-                hipLaunchKernelGGL(mj_k_spg_expand, dim3(grid), dim3(256), 0, s, sp);
-            }
-            sp.level = 0;
-            hipLaunchKernelGGL(mj_k_spg_regroup, dim3(rg_grid), dim3(256), 0, s, sp);
-            hipLaunchKernelGGL(mj_k_spg_probe, dim3(grid), dim3(256), 0, s, sp);
-            hipLaunchKernelGGL(mj_k_spg_score, dim3(grid), dim3(256), 0, s, sp);
-            hipLaunchKernelGGL(mj_k_spg_eval<0>, dim3(grid), dim3(256), 0, s, sp);
-            sp.level = 1;
-            hipLaunchKernelGGL(mj_k_spg_eval<1>, dim3(grid), dim3(256), 0, s, sp);
-            for (int L = 2; L <= 3; L++) {
-                sp.level = L;
-                hipLaunchKernelGGL(mj_k_spg_eval<2>, dim3(grid), dim3(256), 0, s, sp);
-            }
-            hipLaunchKernelGGL(mj_k_spg_write, dim3(grid), dim3(256), 0, s, sp);
-            hipLaunchKernelGGL(mj_k_spg_finish, dim3(1), dim3(64), 0, s, sp);
         }
         if (P->timing) {
             HIP_OK(hipEventRecord(s1, s));

@@ -178,7 +178,7 @@ MJD void sp_key(const SpState& s, u64 k[4]) {
     k[3] = s.w.sz | ((u64)((s.akas >> 3) & 7) << 48);
 }
 
-struct alignas(16) SpCtx {  // per-decision constants (LDS; the per-phase pipeline of mj_sp2.hip keeps a copy per row in HBM)
+struct alignas(16) SpCtx {  // per-decision constants (LDS)
     Melds melds;
     int len_div3, bakaze, jikaze, is_menzen, num_doras_in_fuuro, n_dora, calc_double_riichi, calc_haitei,
         prefer_riichi, T, n_left;

@@ -44,7 +44,9 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(LIB_PATH)
+    # bench.py's cpu_baseline workers load the -O3 -march=native build of the same sources (oracle/Makefile: native), built on the
+    # measurement host; everything else uses the portable library
+    L = C.CDLL(os.environ.get("MJ_ORACLE_LIB") or LIB_PATH)
     L.mjo_last_error.restype = C.c_char_p
     L.mjo_ps_new.restype = C.c_void_p
     L.mjo_ps_clone.restype = C.c_void_p

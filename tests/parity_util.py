@@ -103,7 +103,7 @@ def fake_q_values(masks, rows, cycle, seed):
 def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare_obs=True, obs_every=1,
                  policy_seed=0x9E3779B97F4A7C15, quick_eval=True, sp_rows_checked=False, verbose=True,
                  policy="random", guard=False, oracle_obs=False, compare_logs=False, deal_algo=0, refill=0, min_games=2,
-                 threads=0, obs_cycles=None, pool_cls=None, stagger=0, obs_slice=0):
+                 threads=0, obs_cycles=None, pool_cls=None, stagger=0, obs_slice=0, obs_slice_max=0):
     """Returns a dict with stats; raises AssertionError with a diagnostic on the first mismatch.
 
     refill = nonce stride: finished slots restart on (nonce + stride, key) on both sides (the pool's steady-state mode,
@@ -113,7 +113,8 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     mj_k_refill), i.e. on (nonce + stride, key) as game id t + n_tables; the oracle slot idles until that cycle the same way.
     obs_cycles: explicit set of cycles whose obs are compared (overrides obs_every); threads: oracle encode threads;
     obs_slice: compare the obs in slices of that many rows (the oracle encodes slice by slice: the 65,536-table pool's 8 GB
-    batch never exists twice on the host)."""
+    batch never exists twice on the host); obs_slice_max = k > 0: only k of those slices, spread evenly over the batch (rows are
+    ordered by table, and a table's phase does not depend on its index: any slice holds the batch's mix of decisions)."""
     import torch
 
     if pool_cls is None:
@@ -136,6 +137,7 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         pool.set_start_stagger(stagger)
         arena.park()
         starts = [(((t * 2654435761) & 0xFFFFFFFF) >> 8) % stagger for t in range(n_tables)]
+        starts_np = np.array(starts)
     gen_scores = {}
     pool.configure(0, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
     pool.configure(1, enable_quick_eval=quick_eval, enable_rule_based_agari_guard=guard)
@@ -146,7 +148,7 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     stats = dict(cycles=0, rows=0, obs_checked=0)
     for cycle in range(max_cycles):
         if starts is not None:
-            for g in range(n_tables):
+            for g in np.flatnonzero(starts_np == cycle).tolist():
                 if starts[g] == cycle:  # the device's refill kernel runs ahead of this cycle's step: in play from this cycle on
                     gen[g] = 1
                     nonce[g] += refill
@@ -194,7 +196,10 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         if n and not bool(masks_g.any(dim=1).all()):
             raise AssertionError(f"cycle {cycle}: a decision row without any legal action")
         if sliced:
-            for r0 in range(0, n, obs_slice):
+            firsts = list(range(0, n, obs_slice))
+            if obs_slice_max and len(firsts) > obs_slice_max:
+                firsts = [firsts[(k * (len(firsts) - 1)) // max(1, obs_slice_max - 1)] for k in range(obs_slice_max)]
+            for r0 in firsts:
                 r1 = min(n, r0 + obs_slice)
                 og = obs_g[r0:r1].cpu().numpy()
                 oo, _ = arena.encode(r0, r1, want_obs=True, threads=threads)
@@ -280,7 +285,10 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         stats["cycles"] += 1
         stats["rows"] += n
         if refill:
-            for g in range(n_tables):
+            # (a slot can only have finished if fewer games are live than have entered play: big pools skip the per-slot scan on the
+            # many cycles in which nobody finishes)
+            started = n_tables if starts is None else int((starts_np <= cycle).sum())
+            for g in (range(n_tables) if arena.n_live < started else ()):
                 sc, dn = arena.result(g)
                 if dn and (starts is None or starts[g] <= cycle):  # a parked slot is "finished" without having played
                     gen_scores[(g, gen[g])] = sc.copy()

@@ -52,19 +52,6 @@ def test_emu_lockstep_v4_one_workgroup_takes_every_row(oracle, emu, monkeypatch)
     assert st["obs_checked"] > 200 and st["counters"]["sp_overflow"] == 0
 
 
-def test_emu_lockstep_v4_per_phase_pipeline(oracle, emu, monkeypatch):
-    """MJ_SP_PIPELINE=phase: the per-phase SP pipeline (mj_sp2.hip: setup / regroup / expand / probe / score / eval / write as
-    separate launches over the state graphs of all rows) gives the same f32 bits as the oracle — many rows per launch, so that
-    chunks and evaluation blocks mix rows, plus the refill path."""
-    monkeypatch.setenv("MJ_SP_PIPELINE", "phase")
-    st = parity_util.run_lockstep(oracle, 32, version=4, max_cycles=12, obs_every=1, pool_cls=emu, sp_rows_checked=True,
-                                  policy="greedy", verbose=False)
-    assert st["obs_checked"] > 300 and st["counters"]["sp_overflow"] == 0
-    st = parity_util.run_lockstep(oracle, 3, version=4, max_cycles=20000, obs_every=30, pool_cls=emu, sp_rows_checked=True, refill=8,
-                                  min_games=1, deal_algo=1, verbose=False)
-    assert st["games_checked"] >= 3 and st["counters"]["sp_overflow"] == 0
-
-
 def test_emu_lockstep_older_obs_versions_and_guard(oracle, emu):
     for version in (1, 2):
         st = parity_util.run_lockstep(oracle, 2, version=version, max_cycles=150, obs_every=1, pool_cls=emu, policy="greedy",

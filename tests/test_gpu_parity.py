@@ -70,18 +70,6 @@ def test_lockstep_staggered_start_matches_benchmark_protocol(oracle):
     assert st["generations"][0] >= 3 and st["games_checked"] >= 512
 
 
-def test_lockstep_per_phase_pipeline(oracle, monkeypatch):
-    """MJ_SP_PIPELINE=phase: the per-phase SP pipeline (mj_sp2.hip; round 4's measured alternative to one row per workgroup, slower
-    for lack of locality but bit-identical) against the oracle: 256 tables at the start of E1 (the heaviest graphs, chunks and
-    evaluation blocks mixing rows) and the benchmark's refill mode."""
-    monkeypatch.setenv("MJ_SP_PIPELINE", "phase")
-    st = parity_util.run_lockstep(oracle, 256, version=4, max_cycles=40, obs_every=4, sp_rows_checked=True, policy="greedy", threads=8)
-    assert st["obs_checked"] > 1500 and st["counters"]["sp_overflow"] == 0
-    st = parity_util.run_lockstep(oracle, 48, version=4, max_cycles=20000, obs_every=6, sp_rows_checked=True, refill=12,
-                                  min_games=2, deal_algo=1, threads=8)
-    assert st["generations"][0] >= 2 and st["counters"]["sp_overflow"] == 0
-
-
 def test_lockstep_quick_eval_disabled(oracle):
     """enable_quick_eval = False (mortal.rs:210-250): single-candidate discards get a row, every ankan/kakan decision
     gets a kan-select row."""
@@ -160,6 +148,20 @@ def test_full_size_pool_against_the_oracle(oracle):
     st = parity_util.run_lockstep(oracle, 65536, version=3, max_cycles=48, obs_every=12, threads=16, obs_slice=8192, verbose=True)
     assert st["rows"] > 3_000_000 and st["obs_checked"] > 250_000 and st["cycles"] == 48
     assert st["counters"]["steps"] == st["oracle_steps"] == 48 * 65536
+
+
+def test_full_size_pool_v4_sp_staggered_against_the_oracle(oracle):
+    """The HEADLINE configuration and protocol against the oracle (at 65,536 tables the SP rows had only been compared
+    HIP-vs-HIP from a cold start): 65,536 tables, obs v4, uniform-random legal policy, refill + staggered first starts
+    (mj_pool_set_start_stagger, 200 cycles) so that the row queue of mj_k_sp holds every cost class at once and every persistent
+    workgroup takes MANY graph rows per launch (tag clearing, child-cache epochs, the one-row-per-wavefront tail) — row lists and
+    46-wide masks of every decision of 240 cycles, the WHOLE v4 obs including rows 889..1011 (f32 bit for bit, NaN-poisoned
+    buffers) on two sampled cycles for two 4,096-row slices each, the step counter, no SP overflow.
+    Reference: agent/mortal.rs:252-287, state/obs_repr.rs:564-624."""
+    st = parity_util.run_lockstep(oracle, 65536, version=4, max_cycles=240, obs_cycles={150, 239}, sp_rows_checked=True, refill=65536 // 4,
+                                  stagger=200, min_games=99, deal_algo=1, threads=16, obs_slice=4096, obs_slice_max=2, verbose=True)
+    assert st["cycles"] == 240 and st["rows"] > 9_000_000 and st["obs_checked"] >= 4 * 4096
+    assert st["counters"]["sp_overflow"] == 0 and st["counters"]["steps"] == st["oracle_steps"]
 
 
 @pytest.mark.parametrize("version,cycles", [(3, 48), (4, 14)])

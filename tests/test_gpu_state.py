@@ -85,21 +85,12 @@ def test_reference_state_scenario_on_device(name):
 
 
 def test_device_player_state_obs_matches_oracle(oracle):
-    """encode_obs through the single-table path equals the oracle's PlayerState.encode_obs on the benchmark kyoku
-    (hidden hands as "?"), all four obs versions."""
+    """encode_obs through the single-table path equals the oracle's PlayerState.encode_obs on every decision of the reference's
+    unconditional-tenpai scenario (state/test.rs; hidden hands as "?"), all four obs versions, bit for bit."""
     from libriichi.state import PlayerState
 
-    agree = rejected = dev_rejected = wrong_seat = 0
-    for scen in ("discard_candidates_with_unconditional_tenpai", "chi_at_0_shanten", "kakan_from_hand", "dora_count_after_kan", "double_chankan_ron"):
-        a_, r_, d_, w_ = _validate_scenario(oracle, PlayerState, scen)
-        agree, rejected, dev_rejected, wrong_seat = agree + a_, rejected + r_, dev_rejected + d_, wrong_seat + w_
-    print('validate_reaction', agree, rejected, dev_rejected, wrong_seat)
-    assert agree > 500 and 0 < rejected < agree and dev_rejected >= rejected + wrong_seat and wrong_seat >= 5
-
-
-def _validate_scenario(oracle, PlayerState, scen):
-    sc = T.SCEN[scen]
-    evs = [s["ev"] for s in sc["steps"] if "ev" in s and s["on"] == "ps"]
+    sc = T.SCEN["discard_candidates_with_unconditional_tenpai"]
+    evs = [s["ev"] for s in sc["steps"] if "ev" in s]
     pid = next(s["new"] for s in sc["steps"] if "new" in s)
     dev, ora = PlayerState(pid), oracle.PlayerState(pid)
     checked = 0
@@ -113,7 +104,7 @@ def _validate_scenario(oracle, PlayerState, scen):
                 assert (mg == mo).all()
                 assert (og.view(np.uint32) == oo.view(np.uint32)).all(), (ev, v)
                 checked += 1
-    assert checked >= 40
+    assert checked >= 40, checked
 
 
 def test_device_player_state_validate_reaction(oracle):
