@@ -147,7 +147,7 @@ struct MjPool {
     TableOne* snap = nullptr;
     SpWork* sp_work = nullptr;      // lazily allocated on the first v4 encode
     int sp_grid = 0;
-    int* sp_queue = nullptr;        // [0] row queue head, [1..8] / [9..16] class counts / cursors of the row sort
+    int* sp_queue = nullptr;        // [0] row queue head, [1..8] / [9..16] class counts / cursors of the row sort, [SP_Q_TAIL] head of the tail
     uint32_t* sp_order = nullptr;   // [max_rows] queue position -> row
     uint8_t* sp_cls = nullptr;      // [max_rows] cost class of a row
     unsigned long long* sp_err = nullptr;
@@ -696,9 +696,9 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
                 if (const char* g = getenv("MJ_SP_GRID")) P->sp_grid = std::max(1, std::min(P->sp_grid, atoi(g)));  // tests: few workgroups, many rows each (the row-to-row paths)
                 HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
                 for (int g = 0; g < P->sp_grid; g++) HIP_OK(hipMemsetAsync(P->sp_work[g].tag, 0, sizeof(P->sp_work[g].tag), s));  // empty hash sets
-                HIP_OK(hipMalloc(&P->sp_queue, 17 * sizeof(int)));
+                HIP_OK(hipMalloc(&P->sp_queue, SP_Q_WORDS * sizeof(int)));
             }
-            HIP_OK(hipMemsetAsync(P->sp_queue, 0, 17 * sizeof(int), s));
+            HIP_OK(hipMemsetAsync(P->sp_queue, 0, SP_Q_WORDS * sizeof(int), s));
             SpParams sp;
             sp.snap = P->snap;
             sp.rows = P->rows[agent & 1];

@@ -56,6 +56,11 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
                                 // Measured (round 4, one box, mj_k_sp): none 20.01 ms, 512: 19.78, 1024: 19.73-19.77, 2048: 19.61 (16 KB: with the
                                 // rest 40.5 KB per workgroup, the last size that keeps four workgroups on a CU)
 #endif
+#ifndef SP_TAIL_BATCH
+#define SP_TAIL_BATCH 4         // rows per pop in the tail of the queue (rows without a state graph, one row per wavefront)
+#endif
+#define SP_Q_TAIL 32            // index of the tail's head word in SpParams::queue
+#define SP_Q_WORDS 64
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
 #define SP_L0_MAX 17            // winning draw entries per tenpai state (13 waits + 3 aka variants)
@@ -120,7 +125,8 @@ struct SpParams {
     MjTablesDev tables;
     float* obs;                // [n_rows][1012][34]; rows 889.. are zero on entry (written by mj_k_encode<4>)
     SpWork* work;              // [gridDim.x]
-    int* queue;                // dynamic row queue (zeroed before launch); [1..8] class counts, [9..16] class cursors of the row sort
+    int* queue;                // dynamic row queue (zeroed before launch); [0] head of the rows with a state graph, [1..8] class counts,
+                               // [9..16] class cursors of the row sort, [SP_Q_TAIL] head of the queue's tail (rows without a graph)
     const uint32_t* order;     // [n_rows] queue position -> row index, heaviest cost class first (mj_k_order_classify / _scatter)
     unsigned long long* prof;  // NULL or [24] phase timers / counters (MJ_SP_PROF; mj_counters prints them)
     unsigned long long* err;   // [0] hash-capacity overflows, [1] rows; cycle sums: [2] setup [3] expand [4] eval L0 [5] eval L>0 [6] encode; [7] states
@@ -287,10 +293,10 @@ template <typename Tp> __device__ __forceinline__ Tp* sp_opaque_s(Tp* p) { asm v
 #define SP_ATTR_L0S __noinline__
 #endif
 #ifndef SP_ATTR_EVAL
-#define SP_ATTR_EVAL __noinline__
+#define SP_ATTR_EVAL __forceinline__  // into sp_eval_levels (one call per row)
 #endif
 #ifndef SP_ATTR_EVAL0
-#define SP_ATTR_EVAL0 __noinline__
+#define SP_ATTR_EVAL0 __forceinline__
 #endif
 
 template <class TagP>
@@ -966,7 +972,10 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
 #define SP_EVW_WAVE_FLOATS 1408           // LDS per wavefront: teams x SP_EV_ENT x (T + 4) rows x 4 floats (T = 17: 4 teams)
 MJD int sp_evw_team_floats(int T) { return SP_EV_ENT * (T + 4) * 4; }
 struct alignas(16) SpF4 { float x, y, z, w; };
-#define SP_EV0_STRIDE 24                  // level 0: floats per parked entry: the numerators A[turn] (20 >= T + 3) + the entry's 4 scores
+#define SP_EV0_STRIDE 28                  // level 0: floats per parked entry: the numerators A[turn] of the turns before the last (20 >= T + 3,
+                                          // zero from T - 1 on), the entry's 4 scores, the last turn's numerator
+#define SP_EV0_SC 20
+#define SP_EV0_LAST 24
 
 // Level 0 (tenpai states): a draw entry is a winning draw with its four scores (sp_l0_score) and its wall count; nothing to fold.
 // Per step up to SP_EV_ENT entries of every team: lane j parks A[j] = tsumo_prob[count][j] * not_tsumo[j], then every lane i adds
@@ -1000,7 +1009,10 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     auto sc_ptr = [&](u32 slot, int e) -> const SP_HBM SpF4* { return reinterpret_cast<const SP_HBM SpF4*>(Wg->node[slot].sc[min(e, SP_L0_MAX - 1)]); };
     const float wb0 = hp_base == 0 ? 1.f : 0.f, wb1 = hp_base == 1 ? 1.f : 0.f;
     const float wo0 = hp_own == 0 ? 1.f : 0.f, wo1 = hp_own == 1 ? 1.f : 0.f, wo2 = hp_own == 2 ? 1.f : 0.f, wo3 = hp_own == 3 ? 1.f : 0.f;
-    const float wl0 = hp_last == 0 ? 1.f : 0.f, wl1 = hp_last == 1 ? 1.f : 0.f, wl2 = hp_last == 2 ? 1.f : 0.f;
+    // the term of the last turn j = T - 1: the lane of that turn takes its own score, every other lane the haitei one
+    const int hp_fin = ln == T - 1 ? hp_own : hp_last;
+    const float wf0 = hp_fin == 0 ? 1.f : 0.f, wf1 = hp_fin == 1 ? 1.f : 0.f, wf2 = hp_fin == 2 ? 1.f : 0.f, wf3 = hp_fin == 3 ? 1.f : 0.f;
+    const int nl = T - ln;  // this lane's terms: turns ln .. T - 1
     auto ld_cnt4 = [&](u32 slot, int e0) -> u32 {  // l0cnt[e0 .. e0 + 3]
         return *reinterpret_cast<const SP_HBM u32*>(&Wg->node[slot].l0cnt[min(e0, SP_L0_MAX + 3 - 4)]);
     };
@@ -1053,8 +1065,12 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
                 const u32 cnt = (cw >> (8 * q)) & 0xFFu;
                 const float tpc = cnt <= 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
                 if (u) {
-                    eb[q * SP_EV0_STRIDE + ln] = tpc * m_raw;  // A[ln]
-                    if (lane_in_team == 0) *reinterpret_cast<SpF4*>(eb + q * SP_EV0_STRIDE + 20) = SpF4{sx[q], sy[q], sz[q], sw[q]};  // the entry's scores ride along
+                    // A[ln]; the LAST turn's numerator is parked apart and its place in the row stays zero: its term is the last one
+                    // of every lane, added after the row's loop with the haitei score (below)
+                    const float a = tpc * m_raw;
+                    eb[q * SP_EV0_STRIDE + ln] = ln == T - 1 ? 0.f : a;
+                    if (ln == T - 1) eb[q * SP_EV0_STRIDE + SP_EV0_LAST] = a;
+                    if (lane_in_team == 0) *reinterpret_cast<SpF4*>(eb + q * SP_EV0_STRIDE + SP_EV0_SC) = SpF4{sx[q], sy[q], sz[q], sw[q]};  // the entry's scores ride along
                 }
                 use |= u ? (1u << q) : 0u;
             }
@@ -1063,33 +1079,33 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             for (int q = 0; q < SP_EV_ENT; q++) {  // ONE copy of the accumulate (a dynamic loop over the parked entries)
                 const bool u = (use >> q) & 1;
                 if (__ballot(u) == 0ull) continue;
+                const float* ar = eb + q * SP_EV0_STRIDE;
+                const float* al = ar + ln;  // lane-relative turns (see sp_eval_wave): this lane's terms j = ln, ln + 1, ...
                 if (u) {
-                    const float* ar = eb + q * SP_EV0_STRIDE;
-                    const SpF4 sq = *reinterpret_cast<const SpF4*>(ar + 20);
+                    const SpF4 sq = *reinterpret_cast<const SpF4*>(ar + SP_EV0_SC);
                     // picked by one-hot weights (x * 1 + 0 + 0 + 0 is exact): a run-time index into a register tuple would go through scratch
                     const float s_base = sq.x * wb0 + sq.y * wb1;  // hp_base is 0 or 1
                     const float s_own = sq.x * wo0 + sq.y * wo1 + sq.z * wo2 + sq.w * wo3;
-                    const float s_last = sq.x * wl0 + sq.y * wl1 + sq.z * wl2;  // hp_last <= 2
+                    const float s_fin = sq.x * wf0 + sq.y * wf1 + sq.z * wf2 + sq.w * wf3;  // the last turn's score: haitei, or the lane's own
                     sp_static_for<0, (TN + 3) / 4>([&](auto gc) {
                         constexpr int g = decltype(gc)::value;
-                        if (4 * g + 3 < off || 4 * g >= T) return;  // scalar
-                        const SpF4 a4 = *reinterpret_cast<const SpF4*>(ar + 4 * g);
-                        const float av0 = a4.x, av1 = a4.y, av2 = a4.z, av3 = a4.w;
-                        const float so_ = s_own, sl_ = s_last, sb_ = s_base;  // values, not the lambda's references (else: pointer selects + flat loads)
-#define SP_EV0_TERM(J, A)                                                        \
-    {                                                                            \
-        float prob_ = sp_div_domain((A), my_m, my_r);                            \
-        prob_ = ln <= (J) ? prob_ : 0.f;                                         \
-        const float scj_ = (J) == ln ? so_ : (J) == T - 1 ? sl_ : sb_;           \
-        acc_w += prob_;                                                          \
-        acc_e += prob_ * scj_;                                                   \
-    }
-                        SP_EV0_TERM(4 * g, av0)
-                        SP_EV0_TERM(4 * g + 1, av1)
-                        SP_EV0_TERM(4 * g + 2, av2)
-                        SP_EV0_TERM(4 * g + 3, av3)
-#undef SP_EV0_TERM
+                        if (4 * g >= T - off) return;  // scalar
+                        if (4 * g < nl) {
+                            float a4[4];
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) a4[jj] = al[4 * g + jj];  // past T - 2: zero
+                            const float so_ = s_own, sb_ = s_base;  // values, not the lambda's references (else: pointer selects + flat loads)
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const float prob_ = sp_div_domain(a4[jj], my_m, my_r);
+                                acc_w += prob_;
+                                acc_e += prob_ * ((g == 0 && jj == 0) ? so_ : sb_);  // the lane's own turn first (riichi-ippatsu), then the plain score
+                            }
+                        }
                     });
+                    const float prob_l = sp_div_domain(ar[SP_EV0_LAST], my_m, my_r);  // j = T - 1
+                    acc_w += prob_l;
+                    acc_e += prob_l * s_fin;
                 }
             }
             mj_team_sync<64>();
@@ -1177,6 +1193,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     float nx_t = -3.40282347e+38f, nx_w = -3.40282347e+38f, nx_e = -3.40282347e+38f;
     int max_pack = -1;
     float* const row0 = eb + ln * 4;  // this lane's row of the first parked entry
+    const int nl = T - ln;            // this lane's terms: turns ln .. T - 1
 
     while (__ballot(has) != 0ull) {
         const int n_ch = (int)((h0 >> 32) & 0xFFFF);
@@ -1240,31 +1257,33 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
             s4 = ld_slot(i + 4 * stride);
         }
 
-        // ---- accumulate (calc.rs:486-548) the parked entries of every team, entry by entry, turns in groups of four
+        // ---- accumulate (calc.rs:486-548) the parked entries of every team, entry by entry.  Lane-RELATIVE turns (round 5): lane ln
+        // reads the rows of ITS terms j = ln, ln + 1, ... (row j + 1 = {nx_t, nx_w, nx_e of turn j + 1, A[j]}), four per group, and
+        // drops out (exec mask) once j passes T - 1 -- no term is ever computed to be masked away.  Rounds 1-4 read row j as a
+        // broadcast and multiplied the half of the (lane, turn) pairs with j < ln by a select: one v_cndmask per term, its 17
+        // compare masks hoisted into SGPR pairs and, at level 0, spilled to VGPR lanes (2 v_readlane per use).
         mj_team_sync<64>();
         const int kmax = __ballot(k >= 4) ? 4 : __ballot(k >= 3) ? 3 : __ballot(k >= 2) ? 2 : __ballot(k >= 1) ? 1 : 0;
         for (int en = 0; en < kmax; en++) {
-            if (en < k) {
-                const float* er = eb + en * rows * 4;
-                sp_static_for<0, (TN + 3) / 4>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value;
-                    if (4 * g + 3 < off || 4 * g >= T) return;  // scalar: turns before `off` have no lane, rows past T are zero
+            const float* er = row0 + 4 + en * rows * 4;  // row ln + 1 of entry en
+            const bool mine = en < k;
+            sp_static_for<0, (TN + 3) / 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (4 * g >= T - off) return;  // scalar: the team's first lane has T - off terms, nobody has more
+                if (mine && 4 * g < nl) {
                     SpF4 r[4];
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) r[jj] = *reinterpret_cast<const SpF4*>(er + (4 * g + jj + 1) * 4);
+                    for (int jj = 0; jj < 4; jj++) r[jj] = *reinterpret_cast<const SpF4*>(er + (4 * g + jj) * 4);  // rows past T are zero
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
-                        constexpr int j0 = 4 * g;
-                        const int j = j0 + jj;
-                        float prob = sp_div_domain(r[jj].w, my_m, my_r);
-                        prob = ln <= j ? prob : 0.f;
+                        const float prob = sp_div_domain(r[jj].w, my_m, my_r);
                         if constexpr (LK == 1) acc_t += prob;
                         else acc_t += prob * r[jj].x;
                         acc_w += prob * r[jj].y;
                         acc_e += prob * r[jj].z;
                     }
-                });
-            }
+                }
+            });
         }
         mj_team_sync<64>();  // the parked rows are consumed: the next step may overwrite them
 
@@ -1790,7 +1809,7 @@ struct SpWaveArea {
     TableOne st;
     SpCtx X;
 };
-__device__ __noinline__ void sp_light_row(const uint32_t* rows, const TableOne* snap, float* obs, unsigned long long* err, SpWork* W, SpWaveArea* A, int row) {
+__device__ __forceinline__ void sp_light_row(const uint32_t* rows, const TableOne* snap, float* obs, unsigned long long* err, SpWork* W, SpWaveArea* A, int row) {
     SP_ASSUME_LDS(A);
     const int lane = threadIdx.x & 63;
     SP_HBM float* out = (SP_HBM float*)obs + (size_t)row * (1012 * 34);
@@ -1808,15 +1827,104 @@ __device__ __noinline__ void sp_light_row(const uint32_t* rows, const TableOne* 
     mj_team_sync<64>();
 }
 
+// The tail of the queue, one wavefront: pop SP_TAIL_BATCH rows at a time until it is empty (one call per wavefront and launch).
+__device__ __noinline__ void sp_light_rows(const uint32_t* rows, const TableOne* snap, float* obs, unsigned long long* err, SpWork* W, SpWaveArea* A,
+                                           int* queue, const uint32_t* order, int n_heavy, int n_rows) {
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = n_heavy + atomicAdd(queue + SP_Q_TAIL, SP_TAIL_BATCH);
+        q = __shfl(q, 0);
+        if (q >= n_rows) break;
+        const int qe = min(q + SP_TAIL_BATCH, n_rows);
+        for (; q < qe; q++) sp_light_row(rows, snap, obs, err, W, A, (int)order[q]);
+    }
+}
+
+union SpTeams {                                  // the workgroup's LDS scratch, one phase at a time
+    TableOne st;                                 // the decision's table record: read during the row set-up only
+    SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
+    float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
+    SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
+};
+
+// Level-0 scoring: the workgroup's threads over the work items of the probe pass.  (The loop lives inside the call: a __noinline__
+// function saves and restores its callee-saved VGPRs per CALL, sp_l0_score ~18 of them.)
+__device__ __noinline__ void sp_l0_score_items(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, int n_items) {
+    SP_ASSUME_LDS(X);
+    for (int i = threadIdx.x; i < n_items; i += SP_THREADS) sp_l0_score(Tb, W, X, ((SP_HBM SpWork*)W)->items[i]);
+}
+
+// The evaluation of a row's state graph, bottom-up, all levels: one call per row.  Rounds 3-4 called sp_eval_wave / sp_eval_wave0
+// once per LEVEL; each call saved and restored the 30 callee-saved VGPRs the function uses (60 scratch operations, 15 KB per wavefront
+// and call): ~600 k wavefront-calls per launch = ~9 GB of scratch traffic that does not stay in L2 (4.6 GB of the 15 GB the kernel
+// writes to HBM per launch).  Returns the wall clock at the end of level 0 (phase timers).
+__device__ __noinline__ long long sp_eval_levels(SpWork* W, SpCtx* Xp, SpTeams* tm, int cur_shanten, int T, unsigned long long* prof_err, long long t_2) {
+    SP_ASSUME_LDS(Xp);
+    SP_ASSUME_LDS(tm);
+    SpCtx& X = *Xp;
+    const int tid = SP_OPQ(2, (int)threadIdx.x);
+    long long t_3 = t_2;
+    for (int lv = 0; lv <= cur_shanten; lv++) {
+        const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
+        if (lv == 0) {
+            if (tid == 0) X.n_items = 0;
+            __syncthreads();
+            const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
+            for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
+                sp_l0_probe_chunk(W, &X, &tm->wchunk[tid / SP_NT], c0, min(ns, e - c0));
+            __syncthreads();
+            const long long t_2a = wall_clock64();
+            sp_l0_score_items(c_mj_tables, W, &X, min(X.n_items, SP_ITEMS));
+            __syncthreads();
+            if (prof_err && tid == 0) {  // level-0 sub-phases: probe, scoring (the sum is the rest of the level-0 timer)
+                X.pt[7] += (unsigned long long)(t_2a - t_2);
+                atomicAdd(&prof_err[18], (unsigned long long)(wall_clock64() - t_2a));
+            }
+        }
+        sp_sort_level(W, reinterpret_cast<int*>(tm->ev), b, e);
+        {
+            // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
+            // ... of the turns that can be reached at this level: the first `off` turns are dead
+            const int off = min(cur_shanten - lv, T - 1), TW = T - off;
+            const int wl = tid & 63, tw = wl / TW, ln = wl - tw * TW;
+            float* wl_lds = tm->ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
+            const long long t_ev0 = prof_err ? wall_clock64() : 0;
+            if (lv == 0) {
+                const int tpw0 = min(64 / TW, SP_EVW_WAVE_FLOATS / (SP_EV_ENT * SP_EV0_STRIDE));
+                const int team0 = (tid >> 6) * tpw0 + tw, n_teams0 = (SP_THREADS / 64) * tpw0;
+                const bool on0 = tw < tpw0;
+                if (T <= 8) sp_eval_wave0<8>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+                else if (T <= 16) sp_eval_wave0<16>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+                else sp_eval_wave0<17>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+            } else {
+                // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
+                const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
+                const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
+                const bool on = tw < tpw2;
+                if (T <= 8) {
+                    if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                    else sp_eval_wave<8, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                } else if (T <= 16) {
+                    if (lv == 1) sp_eval_wave<16, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                    else sp_eval_wave<16, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                } else {
+                    if (lv == 1) sp_eval_wave<17, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                    else sp_eval_wave<17, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                }
+            }
+            if (prof_err && (tid & 63) == 0) atomicAdd(&prof_err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
+        }
+        __syncthreads();
+        if (lv == 0) t_3 = wall_clock64();
+    }
+    return t_3;
+}
+
 __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ int s_row;
-    __shared__ union SpTeams {
-        TableOne st;                                 // the decision's table record: read during the row set-up only
-        SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
-        float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
-        SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
-    } s_tm;
+    __shared__ SpTeams s_tm;
 #if SP_CC_N > 0
     __shared__ unsigned long long s_cc[SP_CC_N];  // the child cache of the expansion (sp_expand_chunk)
     for (int i = threadIdx.x; i < SP_CC_N; i += SP_THREADS) s_cc[i] = 0ull;
@@ -1840,8 +1948,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
         const long long t_a = P.prof ? wall_clock64() : 0;
         if (tid == 0) s_row = atomicAdd(P.queue, 1);
         __syncthreads();
-        if (s_row >= P.n_rows) break;
-        if (s_row >= n_heavy) { wave_mode = true; break; }
+        if (s_row >= n_heavy) { wave_mode = n_heavy < P.n_rows; break; }  // no graph rows left: on to the tail (its own head word)
         const int row = (int)P.order[s_row];
         if (P.prof) t_pop += wall_clock64() - t_a;
         long long t_0 = wall_clock64(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0;
@@ -1902,61 +2009,8 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                 __syncthreads();
             }
             t_2 = wall_clock64();
-            // evaluate bottom-up
-            for (int lv = 0; lv <= cur_shanten; lv++) {
-                const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-                if (lv == 0) {
-                    if (tid == 0) X.n_items = 0;
-                    __syncthreads();
-                    const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
-                    for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
-                        sp_l0_probe_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(ns, e - c0));
-                    __syncthreads();
-                    const long long t_2a = wall_clock64();
-                    const int n_items = min(X.n_items, SP_ITEMS);
-                    for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
-                    __syncthreads();
-                    if (P.prof && tid == 0) {  // level-0 sub-phases: probe, scoring (the sum is the rest of the level-0 timer)
-                        X.pt[7] += (unsigned long long)(t_2a - t_2);
-                        atomicAdd(&P.err[18], (unsigned long long)(wall_clock64() - t_2a));
-                    }
-                }
-                sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
-                {
-                    // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
-                    // ... of the turns that can be reached at this level: the first `off` turns are dead
-                    const int off = min(cur_shanten - lv, T - 1), TW = T - off;
-                    const int wl = tid & 63, tw = wl / TW, ln = wl - tw * TW;
-                    float* wl_lds = s_tm.ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
-                    const long long t_ev0 = P.prof ? wall_clock64() : 0;
-                    if (lv == 0) {
-                        const int tpw0 = min(64 / TW, SP_EVW_WAVE_FLOATS / (SP_EV_ENT * SP_EV0_STRIDE));
-                        const int team0 = (tid >> 6) * tpw0 + tw, n_teams0 = (SP_THREADS / 64) * tpw0;
-                        const bool on0 = tw < tpw0;
-                        if (T <= 8) sp_eval_wave0<8>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
-                        else if (T <= 16) sp_eval_wave0<16>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
-                        else sp_eval_wave0<17>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
-                    } else {
-                        // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
-                        const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
-                        const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
-                        const bool on = tw < tpw2;
-                        if (T <= 8) {
-                            if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                            else sp_eval_wave<8, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                        } else if (T <= 16) {
-                            if (lv == 1) sp_eval_wave<16, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                            else sp_eval_wave<16, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                        } else {
-                            if (lv == 1) sp_eval_wave<17, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                            else sp_eval_wave<17, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                        }
-                    }
-                    if (P.prof && (tid & 63) == 0) atomicAdd(&P.err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
-                }
-                __syncthreads();
-                if (lv == 0) t_3 = wall_clock64();
-            }
+            // evaluate bottom-up: ONE call per row (sp_eval_levels; the per-level evaluation functions are inlined there)
+            t_3 = sp_eval_levels(W, &X, &s_tm, cur_shanten, T, P.prof ? P.err : nullptr, t_2);
             t_4 = wall_clock64();
         }
 
@@ -2003,17 +2057,8 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
         atomicAdd(&P.err[22], (unsigned long long)t_reset);
     }
     // ---- the tail of the queue: every wavefront takes its own rows (set-up + encoder only, no workgroup barrier any more)
-    if (wave_mode) {
-        const int wv = tid >> 6, lane = tid & 63;
-        int q = s_row;  // the index this workgroup popped last goes to its first wavefront
-        if (wv != 0) {
-            if (lane == 0) q = atomicAdd(P.queue, 1);
-            q = __shfl(q, 0);
-        }
-        while (q < P.n_rows) {
-            sp_light_row(P.rows, P.snap, P.obs, P.err, W, &s_tm.wave[wv], (int)P.order[q]);
-            if (lane == 0) q = atomicAdd(P.queue, 1);
-            q = __shfl(q, 0);
-        }
-    }
+    // The tail has its own head word (another 128-byte line than the heavy rows' head) and is popped SP_TAIL_BATCH rows at a time:
+    // ~46 k light rows per launch against 4,096 wavefronts that need ~10 us per row ask for ~400 pops per microsecond, and one word
+    // serves ~88 (MI355X_MICROARCH.md, dequeue row) -- one row per atomic made the tail dequeue-bound.
+    if (wave_mode) sp_light_rows(P.rows, P.snap, P.obs, P.err, W, &s_tm.wave[tid >> 6], P.queue, P.order, n_heavy, P.n_rows);
 }

@@ -199,6 +199,7 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
             firsts = list(range(0, n, obs_slice))
             if obs_slice_max and len(firsts) > obs_slice_max:
                 firsts = [firsts[(k * (len(firsts) - 1)) // max(1, obs_slice_max - 1)] for k in range(obs_slice_max)]
+                firsts = sorted({max(0, min(r0, n - obs_slice)) for r0 in firsts})  # whole slices (the batch's last one is ragged)
             for r0 in firsts:
                 r1 = min(n, r0 + obs_slice)
                 og = obs_g[r0:r1].cpu().numpy()
