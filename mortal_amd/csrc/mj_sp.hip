@@ -293,10 +293,10 @@ template <typename Tp> __device__ __forceinline__ Tp* sp_opaque_s(Tp* p) { asm v
 #define SP_ATTR_L0S __noinline__
 #endif
 #ifndef SP_ATTR_EVAL
-#define SP_ATTR_EVAL __forceinline__  // into sp_eval_levels (one call per row)
+#define SP_ATTR_EVAL __noinline__
 #endif
 #ifndef SP_ATTR_EVAL0
-#define SP_ATTR_EVAL0 __forceinline__
+#define SP_ATTR_EVAL0 __noinline__
 #endif
 
 template <class TagP>
@@ -1809,7 +1809,7 @@ struct SpWaveArea {
     TableOne st;
     SpCtx X;
 };
-__device__ __forceinline__ void sp_light_row(const uint32_t* rows, const TableOne* snap, float* obs, unsigned long long* err, SpWork* W, SpWaveArea* A, int row) {
+__device__ __noinline__ void sp_light_row(const uint32_t* rows, const TableOne* snap, float* obs, unsigned long long* err, SpWork* W, SpWaveArea* A, int row) {
     SP_ASSUME_LDS(A);
     const int lane = threadIdx.x & 63;
     SP_HBM float* out = (SP_HBM float*)obs + (size_t)row * (1012 * 34);
@@ -1827,104 +1827,15 @@ __device__ __forceinline__ void sp_light_row(const uint32_t* rows, const TableOn
     mj_team_sync<64>();
 }
 
-// The tail of the queue, one wavefront: pop SP_TAIL_BATCH rows at a time until it is empty (one call per wavefront and launch).
-__device__ __noinline__ void sp_light_rows(const uint32_t* rows, const TableOne* snap, float* obs, unsigned long long* err, SpWork* W, SpWaveArea* A,
-                                           int* queue, const uint32_t* order, int n_heavy, int n_rows) {
-    const int lane = threadIdx.x & 63;
-    for (;;) {
-        int q = 0;
-        if (lane == 0) q = n_heavy + atomicAdd(queue + SP_Q_TAIL, SP_TAIL_BATCH);
-        q = __shfl(q, 0);
-        if (q >= n_rows) break;
-        const int qe = min(q + SP_TAIL_BATCH, n_rows);
-        for (; q < qe; q++) sp_light_row(rows, snap, obs, err, W, A, (int)order[q]);
-    }
-}
-
-union SpTeams {                                  // the workgroup's LDS scratch, one phase at a time
-    TableOne st;                                 // the decision's table record: read during the row set-up only
-    SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
-    float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
-    SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
-};
-
-// Level-0 scoring: the workgroup's threads over the work items of the probe pass.  (The loop lives inside the call: a __noinline__
-// function saves and restores its callee-saved VGPRs per CALL, sp_l0_score ~18 of them.)
-__device__ __noinline__ void sp_l0_score_items(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, int n_items) {
-    SP_ASSUME_LDS(X);
-    for (int i = threadIdx.x; i < n_items; i += SP_THREADS) sp_l0_score(Tb, W, X, ((SP_HBM SpWork*)W)->items[i]);
-}
-
-// The evaluation of a row's state graph, bottom-up, all levels: one call per row.  Rounds 3-4 called sp_eval_wave / sp_eval_wave0
-// once per LEVEL; each call saved and restored the 30 callee-saved VGPRs the function uses (60 scratch operations, 15 KB per wavefront
-// and call): ~600 k wavefront-calls per launch = ~9 GB of scratch traffic that does not stay in L2 (4.6 GB of the 15 GB the kernel
-// writes to HBM per launch).  Returns the wall clock at the end of level 0 (phase timers).
-__device__ __noinline__ long long sp_eval_levels(SpWork* W, SpCtx* Xp, SpTeams* tm, int cur_shanten, int T, unsigned long long* prof_err, long long t_2) {
-    SP_ASSUME_LDS(Xp);
-    SP_ASSUME_LDS(tm);
-    SpCtx& X = *Xp;
-    const int tid = SP_OPQ(2, (int)threadIdx.x);
-    long long t_3 = t_2;
-    for (int lv = 0; lv <= cur_shanten; lv++) {
-        const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
-        if (lv == 0) {
-            if (tid == 0) X.n_items = 0;
-            __syncthreads();
-            const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
-            for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
-                sp_l0_probe_chunk(W, &X, &tm->wchunk[tid / SP_NT], c0, min(ns, e - c0));
-            __syncthreads();
-            const long long t_2a = wall_clock64();
-            sp_l0_score_items(c_mj_tables, W, &X, min(X.n_items, SP_ITEMS));
-            __syncthreads();
-            if (prof_err && tid == 0) {  // level-0 sub-phases: probe, scoring (the sum is the rest of the level-0 timer)
-                X.pt[7] += (unsigned long long)(t_2a - t_2);
-                atomicAdd(&prof_err[18], (unsigned long long)(wall_clock64() - t_2a));
-            }
-        }
-        sp_sort_level(W, reinterpret_cast<int*>(tm->ev), b, e);
-        {
-            // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
-            // ... of the turns that can be reached at this level: the first `off` turns are dead
-            const int off = min(cur_shanten - lv, T - 1), TW = T - off;
-            const int wl = tid & 63, tw = wl / TW, ln = wl - tw * TW;
-            float* wl_lds = tm->ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
-            const long long t_ev0 = prof_err ? wall_clock64() : 0;
-            if (lv == 0) {
-                const int tpw0 = min(64 / TW, SP_EVW_WAVE_FLOATS / (SP_EV_ENT * SP_EV0_STRIDE));
-                const int team0 = (tid >> 6) * tpw0 + tw, n_teams0 = (SP_THREADS / 64) * tpw0;
-                const bool on0 = tw < tpw0;
-                if (T <= 8) sp_eval_wave0<8>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
-                else if (T <= 16) sp_eval_wave0<16>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
-                else sp_eval_wave0<17>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
-            } else {
-                // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
-                const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
-                const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
-                const bool on = tw < tpw2;
-                if (T <= 8) {
-                    if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                    else sp_eval_wave<8, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                } else if (T <= 16) {
-                    if (lv == 1) sp_eval_wave<16, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                    else sp_eval_wave<16, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                } else {
-                    if (lv == 1) sp_eval_wave<17, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                    else sp_eval_wave<17, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
-                }
-            }
-            if (prof_err && (tid & 63) == 0) atomicAdd(&prof_err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
-        }
-        __syncthreads();
-        if (lv == 0) t_3 = wall_clock64();
-    }
-    return t_3;
-}
-
 __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     __shared__ SpCtx X;
     __shared__ int s_row;
-    __shared__ SpTeams s_tm;
+    __shared__ union SpTeams {
+        TableOne st;                                 // the decision's table record: read during the row set-up only
+        SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
+        float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
+        SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
+    } s_tm;
 #if SP_CC_N > 0
     __shared__ unsigned long long s_cc[SP_CC_N];  // the child cache of the expansion (sp_expand_chunk)
     for (int i = threadIdx.x; i < SP_CC_N; i += SP_THREADS) s_cc[i] = 0ull;
@@ -2009,8 +1920,61 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                 __syncthreads();
             }
             t_2 = wall_clock64();
-            // evaluate bottom-up: ONE call per row (sp_eval_levels; the per-level evaluation functions are inlined there)
-            t_3 = sp_eval_levels(W, &X, &s_tm, cur_shanten, T, P.prof ? P.err : nullptr, t_2);
+            // evaluate bottom-up
+            for (int lv = 0; lv <= cur_shanten; lv++) {
+                const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
+                if (lv == 0) {
+                    if (tid == 0) X.n_items = 0;
+                    __syncthreads();
+                    const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
+                    for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
+                        sp_l0_probe_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(ns, e - c0));
+                    __syncthreads();
+                    const long long t_2a = wall_clock64();
+                    const int n_items = min(X.n_items, SP_ITEMS);
+                    for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
+                    __syncthreads();
+                    if (P.prof && tid == 0) {  // level-0 sub-phases: probe, scoring (the sum is the rest of the level-0 timer)
+                        X.pt[7] += (unsigned long long)(t_2a - t_2);
+                        atomicAdd(&P.err[18], (unsigned long long)(wall_clock64() - t_2a));
+                    }
+                }
+                sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
+                {
+                    // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
+                    // ... of the turns that can be reached at this level: the first `off` turns are dead
+                    const int off = min(cur_shanten - lv, T - 1), TW = T - off;
+                    const int wl = tid & 63, tw = wl / TW, ln = wl - tw * TW;
+                    float* wl_lds = s_tm.ev + (tid >> 6) * SP_EVW_WAVE_FLOATS;
+                    const long long t_ev0 = P.prof ? wall_clock64() : 0;
+                    if (lv == 0) {
+                        const int tpw0 = min(64 / TW, SP_EVW_WAVE_FLOATS / (SP_EV_ENT * SP_EV0_STRIDE));
+                        const int team0 = (tid >> 6) * tpw0 + tw, n_teams0 = (SP_THREADS / 64) * tpw0;
+                        const bool on0 = tw < tpw0;
+                        if (T <= 8) sp_eval_wave0<8>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+                        else if (T <= 16) sp_eval_wave0<16>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+                        else sp_eval_wave0<17>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
+                    } else {
+                        // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
+                        const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
+                        const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
+                        const bool on = tw < tpw2;
+                        if (T <= 8) {
+                            if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<8, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                        } else if (T <= 16) {
+                            if (lv == 1) sp_eval_wave<16, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<16, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                        } else {
+                            if (lv == 1) sp_eval_wave<17, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                            else sp_eval_wave<17, 2>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
+                        }
+                    }
+                    if (P.prof && (tid & 63) == 0) atomicAdd(&P.err[23], (unsigned long long)(wall_clock64() - t_ev0));  // wavefront time inside the evaluation (all levels)
+                }
+                __syncthreads();
+                if (lv == 0) t_3 = wall_clock64();
+            }
             t_4 = wall_clock64();
         }
 
@@ -2060,5 +2024,15 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     // The tail has its own head word (another 128-byte line than the heavy rows' head) and is popped SP_TAIL_BATCH rows at a time:
     // ~46 k light rows per launch against 4,096 wavefronts that need ~10 us per row ask for ~400 pops per microsecond, and one word
     // serves ~88 (MI355X_MICROARCH.md, dequeue row) -- one row per atomic made the tail dequeue-bound.
-    if (wave_mode) sp_light_rows(P.rows, P.snap, P.obs, P.err, W, &s_tm.wave[tid >> 6], P.queue, P.order, n_heavy, P.n_rows);
+    if (wave_mode) {
+        const int wv = tid >> 6, lane = tid & 63;
+        for (;;) {
+            int q = 0;
+            if (lane == 0) q = n_heavy + atomicAdd(P.queue + SP_Q_TAIL, SP_TAIL_BATCH);
+            q = __shfl(q, 0);
+            if (q >= P.n_rows) break;
+            const int qe = min(q + SP_TAIL_BATCH, P.n_rows);
+            for (; q < qe; q++) sp_light_row(P.rows, P.snap, P.obs, P.err, W, &s_tm.wave[wv], (int)P.order[q]);
+        }
+    }
 }
