@@ -223,6 +223,47 @@ struct alignas(16) SpCtx {  // per-decision constants (LDS)
 #define SP_HBM __attribute__((address_space(1)))
 #endif
 
+// The out-of-line phase functions receive their pointers in VGPRs (the calling convention), and an array element addressed through
+// such a pointer costs a 64-bit multiply-add plus 64-bit adds per access (v_mad_u64_u32, v_lshl_add_u64, v_add_co / v_addc: ~5 VALU,
+// 12 % of sp_eval_wave's VALU instructions in round 4).  sp_uniform() tells the compiler the pointer is the same in every lane (SGPR
+// pair); sp_ld / sp_st address the work area as base + a 32-bit BYTE offset (the area is 12.5 MB), which selects the
+// global_load vdst, voffset, s[base:base+1] form: one v_mad_u32_u24 per element address.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MJ_EMU)
+template <class Tp> __device__ __forceinline__ Tp* sp_uniform(Tp* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (Tp*)(((unsigned long long)hi << 32) | lo);
+}
+#else
+template <class Tp> MJD Tp* sp_uniform(Tp* p) { return p; }  // (host pass of the single-source compile, emulator)
+#endif
+template <class Tv, class Bp> __device__ __forceinline__ Tv sp_ld(Bp base, u32 byte_off) {  // scalar types
+#ifdef MJ_EMU
+    return *reinterpret_cast<const Tv*>(reinterpret_cast<const char*>(base) + byte_off);
+#else
+    return *reinterpret_cast<const SP_HBM Tv*>(reinterpret_cast<const SP_HBM char*>(base) + (unsigned long long)byte_off);
+#endif
+}
+struct alignas(16) SpF4 { float x, y, z, w; };
+template <class Bp> __device__ __forceinline__ SpF4 sp_ld4(Bp base, u32 byte_off) {  // one 16-byte load (member-wise: SP_HBM is an address space)
+#ifdef MJ_EMU
+    return *reinterpret_cast<const SpF4*>(reinterpret_cast<const char*>(base) + byte_off);
+#else
+    const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(reinterpret_cast<const SP_HBM char*>(base) + (unsigned long long)byte_off);
+    SpF4 r;
+    r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
+    return r;
+#endif
+}
+template <class Bp> __device__ __forceinline__ void sp_st4(Bp base, u32 byte_off, float x, float y, float z, float w) {
+#ifdef MJ_EMU
+    *reinterpret_cast<SpF4*>(reinterpret_cast<char*>(base) + byte_off) = SpF4{x, y, z, w};
+#else
+    SP_HBM SpF4* p = reinterpret_cast<SP_HBM SpF4*>(reinterpret_cast<SP_HBM char*>(base) + (unsigned long long)byte_off);
+    p->x = x; p->y = y; p->z = z; p->w = w;
+#endif
+}
+
 // ---- state id.  Every state of a row is the row's root hand/wall after some draws (wall -> hand, at most 3: one per
 // shanten level) and some discards (hand -> out, at most 4: the candidate's discard + one per level).  The wall of a state
 // is the root wall minus the multiset of drawn tiles, and its hand is the root hand plus that multiset minus the multiset
@@ -971,7 +1012,6 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
 #define SP_EV_ENT 4                       // children folded per step = upper bound of the entries parked per step
 #define SP_EVW_WAVE_FLOATS 1408           // LDS per wavefront: teams x SP_EV_ENT x (T + 4) rows x 4 floats (T = 17: 4 teams)
 MJD int sp_evw_team_floats(int T) { return SP_EV_ENT * (T + 4) * 4; }
-struct alignas(16) SpF4 { float x, y, z, w; };
 #define SP_EV0_STRIDE 28                  // level 0: floats per parked entry: the numerators A[turn] of the turns before the last (20 >= T + 3,
                                           // zero from T - 1 on), the entry's 4 scores, the last turn's numerator
 #define SP_EV0_SC 20
@@ -985,7 +1025,9 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
                                            int team_in_wave, bool team_on) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(WL);
-    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)sp_uniform(W);
+    SP_HBM SpNode* const nodeB = sp_uniform(&Wg->node[0]);  // uniform array bases + 32-bit byte offsets: see sp_uniform
+    SP_HBM u32* const elistB = sp_uniform(&Wg->elist[0]);
     const int T = __builtin_amdgcn_readfirstlane(X->T), off = __builtin_amdgcn_readfirstlane(off_);
     const int ln = min(lane_in_team + off, SP_T - 1);  // this lane's turn (lanes outside any team: clamped, never stored)
     float* const eb = WL + (team_on ? team_in_wave : 0) * (SP_EV_ENT * SP_EV0_STRIDE);  // [SP_EV_ENT][SP_EV0_STRIDE]
@@ -997,16 +1039,18 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     // turn, haitei on the last turn
     const int hp_base = (int)(assume_riichi && X->calc_double_riichi && ln == 0);
     const int hp_own = hp_base + (int)assume_riichi + (int)(haitei && ln == T - 1), hp_last = hp_base + (int)haitei;
-    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)min(X->n_left, SP_NT_ROWS - 1) * (SP_NT_ROWS * SP_NT_STRIDE);
+    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)__builtin_amdgcn_readfirstlane(min(X->n_left, SP_NT_ROWS - 1)) * (SP_NT_ROWS * SP_NT_STRIDE);
     const int last = max(end - 1, 0);
-    auto ld_slot = [&](int i) -> u32 { return Wg->elist[min(i, last)] & (SP_CAP - 1); };
+    auto ld_slot = [&](int i) -> u32 { return sp_ld<u32>(elistB, 4u * (u32)min(i, last)) & (SP_CAP - 1); };
     auto ld_hdr = [&](u32 slot) -> u64 {  // past the L1: the yaku bits were set by L2 atomics of the scoring pass
-        return __hip_atomic_load(reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(reinterpret_cast<SP_HBM unsigned long long*>(reinterpret_cast<SP_HBM char*>(nodeB) +
+                                                                               (unsigned long long)(slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, child_off))),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    auto ld_m = [&](u64 hdr) -> float { return nt_rows[min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln]; };
+    auto ld_m = [&](u64 hdr) -> float { return sp_ld<float>(nt_rows, 4u * ((u32)min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + (u32)ln)); };
     // an entry's four scores are kept as four scalars and picked by one-hot WEIGHTS (x * 1 + 0 + 0 + 0 is exact): a struct or array
     // whose element is picked by a run-time index ends up in scratch behind flat loads
-    auto sc_ptr = [&](u32 slot, int e) -> const SP_HBM SpF4* { return reinterpret_cast<const SP_HBM SpF4*>(Wg->node[slot].sc[min(e, SP_L0_MAX - 1)]); };
+    auto ld_sc = [&](u32 slot, int e) -> SpF4 { return sp_ld4(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, sc) + 16u * (u32)min(e, SP_L0_MAX - 1)); };
     const float wb0 = hp_base == 0 ? 1.f : 0.f, wb1 = hp_base == 1 ? 1.f : 0.f;
     const float wo0 = hp_own == 0 ? 1.f : 0.f, wo1 = hp_own == 1 ? 1.f : 0.f, wo2 = hp_own == 2 ? 1.f : 0.f, wo3 = hp_own == 3 ? 1.f : 0.f;
     // the term of the last turn j = T - 1: the lane of that turn takes its own score, every other lane the haitei one
@@ -1014,7 +1058,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     const float wf0 = hp_fin == 0 ? 1.f : 0.f, wf1 = hp_fin == 1 ? 1.f : 0.f, wf2 = hp_fin == 2 ? 1.f : 0.f, wf3 = hp_fin == 3 ? 1.f : 0.f;
     const int nl = T - ln;  // this lane's terms: turns ln .. T - 1
     auto ld_cnt4 = [&](u32 slot, int e0) -> u32 {  // l0cnt[e0 .. e0 + 3]
-        return *reinterpret_cast<const SP_HBM u32*>(&Wg->node[slot].l0cnt[min(e0, SP_L0_MAX + 3 - 4)]);
+        return sp_ld<u32>(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, l0cnt) + (u32)min(e0, SP_L0_MAX + 3 - 4));
     };
     static_assert(offsetof(SpNode, l0cnt) % 4 == 0, "l0cnt is read four bytes at a time");
     mj_team_sync<64>();
@@ -1027,8 +1071,8 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     float sx[SP_EV_ENT], sy[SP_EV_ENT], sz[SP_EV_ENT], sw[SP_EV_ENT];
 #pragma unroll
     for (int q = 0; q < SP_EV_ENT; q++) {
-        const SP_HBM SpF4* p = sc_ptr(s0, q);
-        sx[q] = p->x; sy[q] = p->y; sz[q] = p->z; sw[q] = p->w;
+        const SpF4 p = ld_sc(s0, q);
+        sx[q] = p.x; sy[q] = p.y; sz[q] = p.z; sw[q] = p.w;
     }
     u32 cw = ld_cnt4(s0, 0);
     while (__ballot(has) != 0ull) {
@@ -1039,8 +1083,8 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
         float nx_[SP_EV_ENT], ny_[SP_EV_ENT], nz_[SP_EV_ENT], nw_[SP_EV_ENT];
 #pragma unroll
         for (int q = 0; q < SP_EV_ENT; q++) {
-            const SP_HBM SpF4* p = sc_ptr(s1, q);
-            nx_[q] = p->x; ny_[q] = p->y; nz_[q] = p->z; nw_[q] = p->w;
+            const SpF4 p = ld_sc(s1, q);
+            nx_[q] = p.x; ny_[q] = p.y; nz_[q] = p.z; nw_[q] = p.w;
         }
         const u32 cwn = ld_cnt4(s1, 0);
         const u64 h2 = ld_hdr(s2);
@@ -1053,8 +1097,8 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             if (e0 > 0) {  // more than SP_EV_ENT draw entries (rare)
 #pragma unroll
                 for (int q = 0; q < SP_EV_ENT; q++) {
-                    const SP_HBM SpF4* p = sc_ptr(s0, e0 + q);
-                    sx[q] = p->x; sy[q] = p->y; sz[q] = p->z; sw[q] = p->w;
+                    const SpF4 p = ld_sc(s0, e0 + q);
+                    sx[q] = p.x; sy[q] = p.y; sz[q] = p.z; sw[q] = p.w;
                 }
                 cw = ld_cnt4(s0, e0);
             }
@@ -1111,8 +1155,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             mj_team_sync<64>();
         }
         if (has) {
-            SP_HBM SpF4* dst = reinterpret_cast<SP_HBM SpF4*>(Wg->node[s0].val[ln]);
-            dst->x = 0.f; dst->y = acc_w; dst->z = acc_e; dst->w = __int_as_float((int)acc_e);
+            sp_st4(nodeB, s0 * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, val) + 16u * (u32)ln, 0.f, acc_w, acc_e, __int_as_float((int)acc_e));
         }
         s0 = s1; s1 = s2; s2 = s3;
         h0 = h1; h1 = h2;
@@ -1144,7 +1187,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     static_assert(LK >= 1, "level 0 has no children: sp_eval_wave0");
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(WL);
-    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)sp_uniform(W);
     const int T = __builtin_amdgcn_readfirstlane(X->T), off = __builtin_amdgcn_readfirstlane(off_);
     const int ln = min(lane_in_team + off, SP_T - 1);  // this lane's turn (lanes outside any team: clamped, never stored)
     const int rows = T + 4;
@@ -1152,18 +1195,19 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     if (team_on)
         for (int r = lane_in_team; r < SP_EV_ENT * rows; r += T - off) *reinterpret_cast<SpF4*>(eb + 4 * r) = SpF4{0.f, 0.f, 0.f, 0.f};
     const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
-    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)min(X->n_left, SP_NT_ROWS - 1) * (SP_NT_ROWS * SP_NT_STRIDE);
+    const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)__builtin_amdgcn_readfirstlane(min(X->n_left, SP_NT_ROWS - 1)) * (SP_NT_ROWS * SP_NT_STRIDE);
     const int last = max(end - 1, 0);
-    auto ld_slot = [&](int i) -> u32 { return Wg->elist[min(i, last)] & (SP_CAP - 1); };
-    auto ld_hdr = [&](u32 slot) -> u64 { return *reinterpret_cast<SP_HBM unsigned long long*>(&Wg->node[slot].child_off); };
-    auto ld_m = [&](u64 hdr) -> float { return nt_rows[min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + ln]; };
-    auto ld_ent = [&](u32 at) -> u32 { return Wg->pool[min(at, (u32)(SP_POOL - 1))]; };
-    auto ld_val = [&](u32 ent) -> SpF4 {  // one 16-byte load (member-wise: SP_HBM is an address space)
-        const SP_HBM SpF4* p = reinterpret_cast<const SP_HBM SpF4*>(Wg->node[SP_ENT_SLOT(ent)].val[ln]);
-        SpF4 r;
-        r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
-        return r;
-    };
+    const u32 val_ln = (u32)offsetof(SpNode, val) + (u32)ln * 16u;  // this lane's turn inside a node
+    // one uniform base per array (an SGPR pair each): a constant array offset added to the 32-bit element offset would be folded into
+    // a 64-bit address again
+    SP_HBM SpNode* const nodeB = sp_uniform(&Wg->node[0]);
+    SP_HBM u32* const elistB = sp_uniform(&Wg->elist[0]);
+    SP_HBM u32* const poolB = sp_uniform(&Wg->pool[0]);
+    auto ld_slot = [&](int i) -> u32 { return sp_ld<u32>(elistB, 4u * (u32)min(i, last)) & (SP_CAP - 1); };
+    auto ld_hdr = [&](u32 slot) -> u64 { return sp_ld<unsigned long long>(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, child_off)); };
+    auto ld_m = [&](u64 hdr) -> float { return sp_ld<float>(nt_rows, 4u * ((u32)min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + (u32)ln)); };
+    auto ld_ent = [&](u32 at) -> u32 { return sp_ld<u32>(poolB, 4u * min(at, (u32)(SP_POOL - 1))); };
+    auto ld_val = [&](u32 ent) -> SpF4 { return sp_ld4(nodeB, SP_ENT_SLOT(ent) * (u32)sizeof(SpNode) + val_ln); };  // one 16-byte load
     mj_team_sync<64>();
 
     // the pipeline: state 0 = current, 1 = next (header, first entries and not_tsumo value loaded), 2 = header loaded, 3 = slot
@@ -1289,8 +1333,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
 
         // ---- end of a state: its values, then the pipeline moves up
         if (done) {
-            SP_HBM SpF4* dst = reinterpret_cast<SP_HBM SpF4*>(Wg->node[s0].val[ln]);
-            dst->x = acc_t; dst->y = acc_w; dst->z = acc_e; dst->w = __int_as_float((int)acc_e);
+            sp_st4(nodeB, s0 * (u32)sizeof(SpNode) + val_ln, acc_t, acc_w, acc_e, __int_as_float((int)acc_e));
             s0 = s1; s1 = s2; s2 = s3; s3 = s4;
             h0 = h1; h1 = h2; h2 = h3;
             m_raw = m_nxt; m_nxt = m_n2;
