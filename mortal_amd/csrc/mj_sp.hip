@@ -64,20 +64,26 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
 #define SP_L0_MAX 17            // winning draw entries per tenpai state (13 waits + 3 aka variants)
-struct SpNode {                 // one 3n+1 state (608 bytes, 16-byte aligned rows).  The first 64 bytes — key, header, level-0 counts — are
-                                // what the expansion / probe passes touch: ONE line (the header used to sit 576 bytes behind the key)
-    u64 k0, k1, k2, k3;         // hand.mp | hand.sz + akas_in_hand<<48 | wall.mp | wall.sz + akas_in_wall<<48
-    u32 child_off;              // level > 0: first pool entry of the child list; level 0: bit e = draw entry e has a yaku
+struct alignas(128) SpNode {    // one 3n+1 state: 256 bytes = exactly two 128-byte lines (round 5; rounds 1-4: 608 bytes with the state's
+                                // key and the level-0 scores inside, 16-byte value rows).  A parent reads val[] of its children, ~6
+                                // parents per child: those reads are what the evaluation costs (a timing-only build without them:
+                                // mj_k_sp 17.6 -> 15.8 ms), so a node holds nothing else but the header they come with
+    u32 child_off;              // level > 0: first pool entry of the child list; level 0: first work item (SpWork::items / l0sc)
     unsigned short n_ch;        // level > 0: number of pool entries; level 0: number of draw entries
     u8 sumreq, n_ent;           // sum over the required tiles of their wall counts (row of the not_tsumo table); draw entries
     u8 l0cnt[SP_L0_MAX + 3];    // level 0: copies left in the wall of every draw entry (its tsumo_prob row)
     u8 pad_[4];
-    float val[SP_T][4];         // per turn: tenpai prob, win prob, EV, bits of (int)EV (the fold key of discard_slow)
-    float sc[SP_L0_MAX][4];     // level 0: get_score() of every draw entry (sp_l0_score)
+    float val[SP_T][3];         // per turn: tenpai prob, win prob, EV ((int)EV, the fold key of discard_slow, is recomputed by the reader)
+    u8 pad2_[20];
 };
-static_assert(sizeof(SpNode) == 608 && offsetof(SpNode, val) == 64 && offsetof(SpNode, sc) % 16 == 0, "SpNode layout");
+static_assert(sizeof(SpNode) == 256 && offsetof(SpNode, val) == 32, "SpNode layout");
 static_assert(offsetof(SpNode, child_off) % 8 == 0 && offsetof(SpNode, n_ch) == offsetof(SpNode, child_off) + 4 &&
               offsetof(SpNode, sumreq) == offsetof(SpNode, child_off) + 6, "the evaluation reads the header as one u64");
+struct SpKeys {                 // a state's key and exact id, DENSE by list index (the order of creation): the expansion / probe passes
+                                // read the 16 states of a chunk as one contiguous block instead of 16 node lines + 16 tag lines
+    u64 k0, k1, k2, k3;         // hand.mp | hand.sz + akas_in_hand<<48 | wall.mp | wall.sz + akas_in_wall<<48
+    u64 dk;                     // state id (sp_dk_add)
+};
 // A child-list entry: hash slot of the child | discard order key << 14 | last-discard-of-its-draw-entry << 23 |
 // draw count << 24 | invalid (hash set overflow) << 27.  Order: draw tile ascending, plain before red, discard ascending.
 #define SP_ENT_SLOT(e) ((e) & 0x3FFFu)
@@ -85,14 +91,21 @@ static_assert(offsetof(SpNode, child_off) % 8 == 0 && offsetof(SpNode, n_ch) == 
 #define SP_ENT_LAST (1u << 23)
 #define SP_ENT_COUNT(e) (((e) >> 24) & 7u)
 #define SP_ENT_INVALID (1u << 27)
-struct SpWork {                // per-workgroup scratch in HBM (persistent workgroups)
+struct alignas(16) SpF4 { float x, y, z, w; };
+struct alignas(128) SpWork {   // per-workgroup scratch in HBM (persistent workgroups), 8.1 MB
     u64 tag[SP_CAP];           // 0 = empty, else state id | 1 << 63
-    SpNode node[SP_CAP];
+    SpNode node[SP_CAP];       // by hash slot
+    SpKeys keys[SP_CAP];       // by list index
     u32 list[SP_CAP];          // slots grouped by level: level L occupies [lvl_begin[L], lvl_end[L])
     u32 elist[SP_CAP];         // the same ranges ordered by child-list length for the evaluation (sp_sort_level)
     u32 pool[SP_POOL];         // child lists
-    u32 items[SP_ITEMS];       // level 0: (state, winning tile, variant) work items of the dense scoring pass
+    u32 items[SP_ITEMS];       // level 0: (list index, winning tile, variant) work items of the dense scoring pass
+    SpF4 l0sc[SP_ITEMS];       // level 0: get_score() of every work item (sp_l0_score), all zero = no yaku
+#ifdef MJ_EMU
+    u32 idx_of[SP_CAP];        // emulator only: slot -> list index, for the id <-> key bijection check on every hit
+#endif
 };
+static_assert(offsetof(SpWork, node) % 128 == 0 && sizeof(SpWork) % 128 == 0, "nodes on line boundaries");
 
 // build_not_tsumo_prob_table (calc.rs:148-167) for EVERY wall size, built once on the host and shared by all workgroups:
 // row [n_left][q] = P(no tile out of q useful ones on turns 0 .. j-1 | n_left tiles unseen), the running product
@@ -244,7 +257,6 @@ template <class Tv, class Bp> __device__ __forceinline__ Tv sp_ld(Bp base, u32 b
     return *reinterpret_cast<const SP_HBM Tv*>(reinterpret_cast<const SP_HBM char*>(base) + (unsigned long long)byte_off);
 #endif
 }
-struct alignas(16) SpF4 { float x, y, z, w; };
 template <class Bp> __device__ __forceinline__ SpF4 sp_ld4(Bp base, u32 byte_off) {  // one 16-byte load (member-wise: SP_HBM is an address space)
 #ifdef MJ_EMU
     return *reinterpret_cast<const SpF4*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -255,12 +267,31 @@ template <class Bp> __device__ __forceinline__ SpF4 sp_ld4(Bp base, u32 byte_off
     return r;
 #endif
 }
-template <class Bp> __device__ __forceinline__ void sp_st4(Bp base, u32 byte_off, float x, float y, float z, float w) {
+struct SpF3 { float x, y, z; };
+template <class Bp> __device__ __forceinline__ SpF3 sp_ld3(Bp base, u32 byte_off) {  // one 12-byte load
 #ifdef MJ_EMU
-    *reinterpret_cast<SpF4*>(reinterpret_cast<char*>(base) + byte_off) = SpF4{x, y, z, w};
+    return *reinterpret_cast<const SpF3*>(reinterpret_cast<const char*>(base) + byte_off);
 #else
-    SP_HBM SpF4* p = reinterpret_cast<SP_HBM SpF4*>(reinterpret_cast<SP_HBM char*>(base) + (unsigned long long)byte_off);
-    p->x = x; p->y = y; p->z = z; p->w = w;
+    const SP_HBM SpF3* p = reinterpret_cast<const SP_HBM SpF3*>(reinterpret_cast<const SP_HBM char*>(base) + (unsigned long long)byte_off);
+    SpF3 r;
+    r.x = p->x; r.y = p->y; r.z = p->z;
+    return r;
+#endif
+}
+template <class Bp> __device__ __forceinline__ void sp_st3(Bp base, u32 byte_off, float x, float y, float z) {
+#ifdef MJ_EMU
+    *reinterpret_cast<SpF3*>(reinterpret_cast<char*>(base) + byte_off) = SpF3{x, y, z};
+#else
+    SP_HBM SpF3* p = reinterpret_cast<SP_HBM SpF3*>(reinterpret_cast<SP_HBM char*>(base) + (unsigned long long)byte_off);
+    p->x = x; p->y = y; p->z = z;
+#endif
+}
+// `ev as i32` (calc.rs:600-615, the fold key of discard_slow): saturating, NaN -> 0 = v_cvt_i32_f32.  EVs are finite and below 2^19.
+MJD int sp_f2i(float v) {
+#if defined(MJ_EMU)
+    return v != v ? 0 : v >= 2147483648.f ? 2147483647 : v <= -2147483648.f ? (-2147483647 - 1) : (int)v;
+#else
+    return (int)v;
 #endif
 }
 
@@ -353,27 +384,45 @@ MJD SpState sp_apply(SpState s, int tile, int dt) {
     if (dt >= 0) sp_discard(s, dt);
     return s;
 }
+// A fresh state gets the next list index; its key and id go to the dense array there.
 template <class WP>
-__device__ __forceinline__ int sp_insert(WP W, SpCtx* X, u64 dk, const SpState& base, int tile, int dt, bool& fresh) {
+__device__ __forceinline__ void sp_new_state(WP W, SpCtx* X, u32 slot, u64 dk, const SpState& st) {
+    const int idx = atomicAdd(&X->n_list, 1);
+    if (idx < SP_CAP) {
+        u64 k[4];
+        sp_key(st, k);
+        W->list[idx] = slot;
+        auto& e = W->keys[idx];
+        e.k0 = k[0]; e.k1 = k[1]; e.k2 = k[2]; e.k3 = k[3]; e.dk = dk;
+#ifdef MJ_EMU
+        W->idx_of[slot] = (u32)idx;
+#endif
+    } else {
+        X->overflow = 1;
+    }
+}
+#ifdef MJ_EMU  // the emulator never pre-empts between the claim and the key write: check the bijection on every hit
+template <class WP>
+inline void sp_emu_check_hit(WP W, SpCtx* X, u32 slot, const SpState& st) {
+    u64 k[4];
+    sp_key(st, k);
+    const auto& e = W->keys[W->idx_of[slot]];
+    if (e.k0 != k[0] || e.k1 != k[1] || e.k2 != k[2] || e.k3 != k[3]) X->overflow = 1;
+}
+#endif
+template <class WP>
+__device__ __forceinline__ int sp_insert(WP W, SpCtx* X, u64 dk, const SpState& base, int tile, int dt) {  // (the row's root states)
     const u64 tag = SP_TAG(dk);
     u32 pos = sp_dk_pos(dk);
-    fresh = false;
     for (int probe = 0; probe < SP_CAP; probe++) {
         const u64 old = sp_claim_tag(&W->tag[pos], tag);
         if (old == 0ull) {
-            u64 k[4];
-            sp_key(sp_apply(base, tile, dt), k);
-            auto& n = W->node[pos];
-            n.k0 = k[0]; n.k1 = k[1]; n.k2 = k[2]; n.k3 = k[3];
-            fresh = true;
+            sp_new_state(W, X, pos, dk, sp_apply(base, tile, dt));
             return (int)pos;
         }
         if (old == tag) {
-#ifdef MJ_EMU  // the emulator never pre-empts between the claim and the key write: check the bijection on every hit
-            u64 k[4];
-            sp_key(sp_apply(base, tile, dt), k);
-            auto& n = W->node[pos];
-            if (n.k0 != k[0] || n.k1 != k[1] || n.k2 != k[2] || n.k3 != k[3]) X->overflow = 1;
+#ifdef MJ_EMU
+            sp_emu_check_hit(W, X, pos, sp_apply(base, tile, dt));
 #endif
             return (int)pos;
         }
@@ -479,19 +528,17 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
 //   probe : sp_l0_probe_chunk — which draws win (34 shanten probes per state) -> draw entries, one work item per entry
 //   score : THREAD per item, dense across the workgroup                  -> 4 scores per entry in the node (sc[])
 //   sum   : team per state — sp_eval_wave0 accumulates the scores in the reference's order
-__device__ SP_ATTR_L0S void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item) {
+__device__ SP_ATTR_L0S void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item, int item_idx) {
     SP_ASSUME_LDS(X);
-    const int slot = item & 0x3FFF, idx = (item >> 14) & 31, t = (item >> 19) & 63, variant = (item >> 25) & 1;
-    SP_HBM SpNode& node = ((SP_HBM SpWork*)W)->node[slot];
-    SpState S1 = sp_state_of(node);
+    const int li = item & 0x3FFF, t = (item >> 19) & 63, variant = (item >> 25) & 1;  // list index of the state, winning tile
+    SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
+    SpState S1 = sp_state_of(Wg->keys[li]);
     const int tile = variant ? akaize(t) : t;
     sp_deal(S1, tile);
     float scv[4];
-    if (sp_get_score(Tb, X, S1, tile, scv)) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) node.sc[idx][q] = scv[q];
-        __hip_atomic_fetch_or(&node.child_off, 1u << idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const bool yaku = sp_get_score(Tb, X, S1, tile, scv);  // a hand with a yaku scores > 0: all-zero scores mark "no yaku" for the summation
+    SP_HBM SpF4& dst = Wg->l0sc[item_idx];
+    dst.x = yaku ? scv[0] : 0.f; dst.y = yaku ? scv[1] : 0.f; dst.z = yaku ? scv[2] : 0.f; dst.w = yaku ? scv[3] : 0.f;
 }
 
 template <int J, int N, class F>
@@ -597,13 +644,12 @@ __device__ __noinline__ u64 sp_keep_brute_dev(Hand g, int ld3, int Tg) { return 
 __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpChunk* C, const SpTabG& TG, int first, int n, int L) {
     const int tid = SP_OPQ(1, (int)(threadIdx.x & (SP_NT - 1)));
     const int ld3 = X->len_div3;
-    for (int task = tid; task < n * 4; task += SP_NT) {
+    for (int task = tid; task < n * 4; task += SP_NT) {  // the chunk's states are neighbours in the dense key array: one contiguous read
         const int s = task >> 2, j = task & 3;
-        const u32 slot = Wg->list[first + s];
-        C->k[s][j] = reinterpret_cast<const SP_HBM u64*>(&Wg->node[slot])[j];  // k0..k3 lead the node
+        C->k[s][j] = reinterpret_cast<const SP_HBM u64*>(&Wg->keys[first + s])[j];  // k0..k3 lead the record
         if (j == 0) {
-            C->slot[s] = slot;
-            C->dk[s] = Wg->tag[slot] & ~(1ull << 63);
+            C->slot[s] = Wg->list[first + s];
+            C->dk[s] = Wg->keys[first + s].dk;
         }
     }
     mj_team_sync<SP_NT>();
@@ -693,14 +739,14 @@ __device__ SP_ATTR_L0P void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, i
             for (int variant = 0; variant < 2; variant++) {
                 if (variant == 0 ? (aka && wc < 2) : !aka) continue;
                 if (e < cnt) {
-                    if (base + e < SP_ITEMS) Wg->items[base + e] = slot | ((u32)e << 14) | ((u32)t << 19) | ((u32)variant << 25);
+                    if (base + e < SP_ITEMS) Wg->items[base + e] = (u32)(first + s) | ((u32)e << 14) | ((u32)t << 19) | ((u32)variant << 25);
                     else X->overflow = 1;
                     node.l0cnt[e] = (u8)(!aka ? wc : variant == 0 ? wc - 1 : 1);  // draw_without_tegawari's `count`
                 }
                 e++;
             }
         }
-        node.child_off = 0;  // bit i: draw entry i has a yaku (set by sp_l0_score)
+        node.child_off = (u32)min(base, SP_ITEMS - 1);  // the state's first work item: its scores are l0sc[child_off ...]
         node.n_ch = (unsigned short)cnt;
         node.sumreq = (u8)(sumreq & 0xFF);
         node.n_ent = (u8)cnt;
@@ -892,20 +938,13 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
 #endif
             for (int probe = 0; cs < 0 && probe < SP_CAP; probe++) {
                 if (old == 0ull) {
-                    u64 k[4];
-                    sp_key(sp_apply(Sx, E.tile, E.dt), k);
-                    auto& nd = Wg->node[pos];
-                    nd.k0 = k[0]; nd.k1 = k[1]; nd.k2 = k[2]; nd.k3 = k[3];
                     fresh = true;
                     cs = (int)pos;
                     break;
                 }
                 if (old == tag) {
-#ifdef MJ_EMU  // the emulator never pre-empts between the claim and the key write: check the bijection on every hit
-                    u64 k[4];
-                    sp_key(sp_apply(Sx, E.tile, E.dt), k);
-                    auto& nd = Wg->node[pos];
-                    if (nd.k0 != k[0] || nd.k1 != k[1] || nd.k2 != k[2] || nd.k3 != k[3]) X->overflow = 1;
+#ifdef MJ_EMU
+                    sp_emu_check_hit(Wg, X, pos, sp_apply(Sx, E.tile, E.dt));
 #endif
                     cs = (int)pos;
                     break;
@@ -915,11 +954,7 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
                 if (old == 0ull) old = sp_claim_tag(&Wg->tag[pos], tag);
             }
             if (cs < 0) X->overflow = 1;
-            if (fresh) {
-                const int idx = atomicAdd(&X->n_list, 1);
-                if (idx < SP_CAP) Wg->list[idx] = (u32)cs;
-                else X->overflow = 1;
-            }
+            if (fresh) sp_new_state(Wg, X, (u32)cs, E.dk, sp_apply(Sx, E.tile, E.dt));  // next list index: slot, key and id
             const int pos_out = C->child_base[E.s] + (int)C->coff[E.it] + E.local;
             const u32 ent = (cs < 0 ? SP_ENT_INVALID : (u32)cs) | ((u32)sp_discard_key(E.dt) << 14) | (E.rank == E.nk - 1 ? SP_ENT_LAST : 0u) |
                             ((u32)E.count << 24);
@@ -1042,15 +1077,14 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)__builtin_amdgcn_readfirstlane(min(X->n_left, SP_NT_ROWS - 1)) * (SP_NT_ROWS * SP_NT_STRIDE);
     const int last = max(end - 1, 0);
     auto ld_slot = [&](int i) -> u32 { return sp_ld<u32>(elistB, 4u * (u32)min(i, last)) & (SP_CAP - 1); };
-    auto ld_hdr = [&](u32 slot) -> u64 {  // past the L1: the yaku bits were set by L2 atomics of the scoring pass
-        return __hip_atomic_load(reinterpret_cast<SP_HBM unsigned long long*>(reinterpret_cast<SP_HBM char*>(nodeB) +
-                                                                               (unsigned long long)(slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, child_off))),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+    SP_HBM SpF4* const scB = sp_uniform(&Wg->l0sc[0]);
+    auto ld_hdr = [&](u32 slot) -> u64 { return sp_ld<unsigned long long>(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, child_off)); };
     auto ld_m = [&](u64 hdr) -> float { return sp_ld<float>(nt_rows, 4u * ((u32)min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + (u32)ln)); };
     // an entry's four scores are kept as four scalars and picked by one-hot WEIGHTS (x * 1 + 0 + 0 + 0 is exact): a struct or array
     // whose element is picked by a run-time index ends up in scratch behind flat loads
-    auto ld_sc = [&](u32 slot, int e) -> SpF4 { return sp_ld4(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, sc) + 16u * (u32)min(e, SP_L0_MAX - 1)); };
+    // (scores by work item: a state's draw entries are consecutive items, (u32)header = the first one; items past the state's own
+    // belong to other states -- finite values, never used)
+    auto ld_sc = [&](u64 hdr, int e) -> SpF4 { return sp_ld4(scB, 16u * min((u32)hdr + (u32)e, (u32)(SP_ITEMS - 1))); };
     const float wb0 = hp_base == 0 ? 1.f : 0.f, wb1 = hp_base == 1 ? 1.f : 0.f;
     const float wo0 = hp_own == 0 ? 1.f : 0.f, wo1 = hp_own == 1 ? 1.f : 0.f, wo2 = hp_own == 2 ? 1.f : 0.f, wo3 = hp_own == 3 ? 1.f : 0.f;
     // the term of the last turn j = T - 1: the lane of that turn takes its own score, every other lane the haitei one
@@ -1071,19 +1105,18 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     float sx[SP_EV_ENT], sy[SP_EV_ENT], sz[SP_EV_ENT], sw[SP_EV_ENT];
 #pragma unroll
     for (int q = 0; q < SP_EV_ENT; q++) {
-        const SpF4 p = ld_sc(s0, q);
+        const SpF4 p = ld_sc(h0, q);
         sx[q] = p.x; sy[q] = p.y; sz[q] = p.z; sw[q] = p.w;
     }
     u32 cw = ld_cnt4(s0, 0);
     while (__ballot(has) != 0ull) {
         const int n_ent = (int)((h0 >> 32) & 0xFFFF);
-        const u32 yaku = (u32)h0;  // bit e: draw entry e has a yaku
         // in flight under this state: the next state's first entries, the header after it, the slot after that
         const float m_n = ld_m(h1);
         float nx_[SP_EV_ENT], ny_[SP_EV_ENT], nz_[SP_EV_ENT], nw_[SP_EV_ENT];
 #pragma unroll
         for (int q = 0; q < SP_EV_ENT; q++) {
-            const SpF4 p = ld_sc(s1, q);
+            const SpF4 p = ld_sc(h1, q);
             nx_[q] = p.x; ny_[q] = p.y; nz_[q] = p.z; nw_[q] = p.w;
         }
         const u32 cwn = ld_cnt4(s1, 0);
@@ -1097,7 +1130,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             if (e0 > 0) {  // more than SP_EV_ENT draw entries (rare)
 #pragma unroll
                 for (int q = 0; q < SP_EV_ENT; q++) {
-                    const SpF4 p = ld_sc(s0, e0 + q);
+                    const SpF4 p = ld_sc(h0, e0 + q);
                     sx[q] = p.x; sy[q] = p.y; sz[q] = p.z; sw[q] = p.w;
                 }
                 cw = ld_cnt4(s0, e0);
@@ -1105,7 +1138,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             u32 use = 0;  // bit q: this team has a draw entry with a yaku in slot q of the step
 #pragma unroll
             for (int q = 0; q < SP_EV_ENT; q++) {
-                const bool u = has && e0 + q < n_ent && ((yaku >> (e0 + q)) & 1);
+                const bool u = has && e0 + q < n_ent && sx[q] != 0.f;  // a draw entry with a yaku (sp_l0_score)
                 const u32 cnt = (cw >> (8 * q)) & 0xFFu;
                 const float tpc = cnt <= 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
                 if (u) {
@@ -1155,7 +1188,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             mj_team_sync<64>();
         }
         if (has) {
-            sp_st4(nodeB, s0 * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, val) + 16u * (u32)ln, 0.f, acc_w, acc_e, __int_as_float((int)acc_e));
+            sp_st3(nodeB, s0 * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, val) + 12u * (u32)ln, 0.f, acc_w, acc_e);
         }
         s0 = s1; s1 = s2; s2 = s3;
         h0 = h1; h1 = h2;
@@ -1197,7 +1230,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     const float tp0 = X->tsumo_prob[0][ln], tp1 = X->tsumo_prob[1][ln], tp2 = X->tsumo_prob[2][ln], tp3 = X->tsumo_prob[3][ln];
     const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)__builtin_amdgcn_readfirstlane(min(X->n_left, SP_NT_ROWS - 1)) * (SP_NT_ROWS * SP_NT_STRIDE);
     const int last = max(end - 1, 0);
-    const u32 val_ln = (u32)offsetof(SpNode, val) + (u32)ln * 16u;  // this lane's turn inside a node
+    const u32 val_ln = (u32)offsetof(SpNode, val) + (u32)ln * 12u;  // this lane's turn inside a node
     // one uniform base per array (an SGPR pair each): a constant array offset added to the 32-bit element offset would be folded into
     // a 64-bit address again
     SP_HBM SpNode* const nodeB = sp_uniform(&Wg->node[0]);
@@ -1207,7 +1240,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     auto ld_hdr = [&](u32 slot) -> u64 { return sp_ld<unsigned long long>(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, child_off)); };
     auto ld_m = [&](u64 hdr) -> float { return sp_ld<float>(nt_rows, 4u * ((u32)min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + (u32)ln)); };
     auto ld_ent = [&](u32 at) -> u32 { return sp_ld<u32>(poolB, 4u * min(at, (u32)(SP_POOL - 1))); };
-    auto ld_val = [&](u32 ent) -> SpF4 { return sp_ld4(nodeB, SP_ENT_SLOT(ent) * (u32)sizeof(SpNode) + val_ln); };  // one 16-byte load
+    auto ld_val = [&](u32 ent) -> SpF3 { return sp_ld3(nodeB, SP_ENT_SLOT(ent) * (u32)sizeof(SpNode) + val_ln); };  // one 12-byte load
     mj_team_sync<64>();
 
     // the pipeline: state 0 = current, 1 = next (header, first entries and not_tsumo value loaded), 2 = header loaded, 3 = slot
@@ -1223,7 +1256,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
         entn[q] = ld_ent((u32)h0 + SP_EV_ENT + q);
         nent[q] = ld_ent((u32)h1 + q);
     }
-    SpF4 v[SP_EV_ENT];
+    SpF3 v[SP_EV_ENT];
 #pragma unroll
     for (int q = 0; q < SP_EV_ENT; q++) v[q] = ld_val(ent[q]);
 
@@ -1250,10 +1283,10 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
             const bool bad = (e & SP_ENT_INVALID) != 0;
             if (valid && bad) X->overflow = 1;
             // `as i32` of the child's EV (maximize_win_prob = false) above the discard order key (cmp_discard_priority > 0 <=> larger key)
-            const int pack = (__float_as_int(v[q].w) << 9) | (int)SP_ENT_KEY(e);
+            const int pack = (sp_f2i(v[q].z) << 9) | (int)SP_ENT_KEY(e);
 #ifdef MJ_EMU
             // the packing's range (the team's first lane reads a turn its children never wrote — nobody reads what it folds)
-            if (valid && !bad && lane_in_team > 0 && ((unsigned)__float_as_int(v[q].w) >> 22)) X->overflow = 1;
+            if (valid && !bad && lane_in_team > 0 && ((unsigned)sp_f2i(v[q].z) >> 22)) X->overflow = 1;
 #endif
             const bool better = valid && !bad && pack > max_pack;
             nx_t = better ? v[q].x : nx_t;
@@ -1279,7 +1312,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
         // ---- the loads of the next step: its children's values, the entries after them, and (used only when a state ends)
         // the pipeline's tail.  Issued by every lane whether or not its team advances: no divergent control flow.
         u32 up[SP_EV_ENT], upn[SP_EV_ENT], nent2[SP_EV_ENT];
-        SpF4 vn[SP_EV_ENT];
+        SpF3 vn[SP_EV_ENT];
         const u32 up_off = done ? (u32)h1 + SP_EV_ENT : (u32)h0 + (u32)c0 + SP_EV_ENT;
 #pragma unroll
         for (int q = 0; q < SP_EV_ENT; q++) up[q] = done ? nent[q] : entn[q];
@@ -1333,7 +1366,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
 
         // ---- end of a state: its values, then the pipeline moves up
         if (done) {
-            sp_st4(nodeB, s0 * (u32)sizeof(SpNode) + val_ln, acc_t, acc_w, acc_e, __int_as_float((int)acc_e));
+            sp_st3(nodeB, s0 * (u32)sizeof(SpNode) + val_ln, acc_t, acc_w, acc_e);
             s0 = s1; s1 = s2; s2 = s3; s3 = s4;
             h0 = h1; h1 = h2; h2 = h3;
             m_raw = m_nxt; m_nxt = m_n2;
@@ -1936,10 +1969,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                 const int c = tid;
                 SpState s = root;
                 if (can_discard) sp_discard(s, X.cand_tile[c]);
-                bool fresh;
-                const int slot = sp_insert(W, &X, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), s, -1, -1, fresh);
-                X.cand_slot[c] = slot;
-                if (fresh && slot >= 0) W->list[atomicAdd(&X.n_list, 1)] = (u32)slot;
+                X.cand_slot[c] = sp_insert(W, &X, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), s, -1, -1);
             }
             __syncthreads();
             if (tid == 0) {
@@ -1975,7 +2005,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                     __syncthreads();
                     const long long t_2a = wall_clock64();
                     const int n_items = min(X.n_items, SP_ITEMS);
-                    for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i]);
+                    for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i], i);
                     __syncthreads();
                     if (P.prof && tid == 0) {  // level-0 sub-phases: probe, scoring (the sum is the rest of the level-0 timer)
                         X.pt[7] += (unsigned long long)(t_2a - t_2);
