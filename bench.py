@@ -325,17 +325,18 @@ def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmu
     return res
 
 
-def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs, other_ms=None):
+def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs, other_ms=None, compile_net=False):
     """BASELINE configs[2] as a driver-timed workload: the policy/value net is PyTorch's (out of this path's scope), so what the
-    entry shows is the end-to-end rate and how small the environment's share of that cycle is."""
+    entry shows is the end-to-end rate and how small the environment's share of that cycle is.  compile_net: the same module under
+    torch.compile (PyTorch's inductor), chunks of 8,192 rows -- the cheap settings tools/brain_tune.py found (7 x the eager forward)."""
     import torch
 
     from mortal_amd.policy import DeviceEngine, PolicyNet
 
     try:
         torch.manual_seed(0)
-        engine = DeviceEngine(PolicyNet(version=4), 4, dev, enable_amp=True)
-        r = _measure(pool_cls, N, g0, world, dev, 4, preroll, "brain", 2, 1, bufs, engine)
+        engine = DeviceEngine(PolicyNet(version=4), 4, dev, enable_amp=True, compile_net=compile_net, max_batch=8192 if compile_net else 16384)
+        r = _measure(pool_cls, N, g0, world, dev, 4, preroll, "brain", 3 if compile_net else 2, 1, bufs, engine)
     except Exception as e:  # noqa: BLE001 - an extra workload must never cost the headline line
         return {"error": repr(e)[:300]}
     out = _brief(r)
@@ -345,7 +346,8 @@ def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs, other_ms=None):
     out["env_share_of_cycle"] = env_ms / out["ms_per_step"]
     out["env_ms_per_step"] = env_ms
     out["net"] = ("random-init Brain + DQN, 192 ch x 40 blocks, torch.autocast default dtype of the backend (fp16 on ROCm, exactly "
-                  "like mortal/engine.py:46), greedy")
+                  "like mortal/engine.py:46), greedy" + ("; module under torch.compile (inductor), 8,192-row chunks" if compile_net else
+                                                         "; eager, 16,384-row chunks (the unmodified setting)"))
     return out
 
 
@@ -515,10 +517,14 @@ def main():
             "cfg1_4096_v4": _brief(_measure(TablePool, 4096, g0, world, dev, 4, args.preroll, "random", 6 * k, 10, bufs)),
             "brain_v4": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs,
                                         other_ms=(dt * 1e3 - enc_ms - sp_ms) / args.steps),
+            "brain_v4_compiled": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs,
+                                                 other_ms=(dt * 1e3 - enc_ms - sp_ms) / args.steps, compile_net=True),
             "note": "cfg1_4096_v3 / _v4 = BASELINE configs[1]: 4,096 tables, uniform-random legal policy, the same protocol as the headline; "
                     "brain_v4 = BASELINE configs[2]: full self-play cycle with a random-init net of the reference's Brain/DQN shape "
                     "(192 channels x 40 blocks, fp16 autocast = torch.autocast's default on this backend like mortal/engine.py:46, greedy argmax) consuming the encoded batch in place on the same GPU; "
                     "2 timed cycles (the net takes seconds per 65 k-row batch); env_share = (step + encode + SP kernels) / cycle; "
+                    "brain_v4_compiled = the same module and autocast under torch.compile (PyTorch's inductor), 8,192-row chunks, 3 timed cycles: "
+                    "the net is PyTorch's by north_star, this only shows what its cheap settings buy (tools/brain_tune.py: 25 k -> 178 k rows/s); "
                     "obs_v3_random = env-step + encode only (no SP block); obs_v4_random_no_preroll = every table in the first "
                     "turns of E1 (17 draws left: the heaviest SP phase); obs_v4_greedy = tenpai-seeking policy on device "
                     "(mj_greedy_policy; pre-rolled with the same policy): hands at 0..3 shanten, the largest SP state graphs",

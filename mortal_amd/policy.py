@@ -106,8 +106,15 @@ class DeviceEngine:
 
     def __init__(self, net, version, device, name="mortal_amd", enable_amp=True, enable_quick_eval=True,
                  max_batch=16384, boltzmann_epsilon=0, boltzmann_temp=1, top_p=1, enable_rule_based_agari_guard=False,
-                 return_meta=False, seed=None):
+                 return_meta=False, seed=None, compile_net=False):
         self.net = net.to(device).eval()
+        # compile_net: torch.compile (inductor) of the same module under the same autocast -- PyTorch's own graph compiler, measured
+        # 7.1 x the eager forward on MI355X for the 192 x 40 net (tools/brain_tune.py).  Chunks then have ONE shape (max_batch rows,
+        # the batch's ragged tail is padded in a staging buffer) so that nothing is compiled twice.
+        self.compiled = bool(compile_net)
+        self._stage = None
+        if self.compiled:
+            self.net = torch.compile(self.net)
         self.version = version
         self.device = torch.device(device)
         self.name = name
@@ -134,14 +141,23 @@ class DeviceEngine:
         q_all = torch.empty((n, ACTION_SPACE), dtype=torch.float32, device=obs.device) if want_meta else None
         greedy_all = torch.empty(n, dtype=torch.bool, device=obs.device) if want_meta else None
         for i in range(0, n, self.max_batch):  # bounded activation memory at 65k-row batches
+            ob, mk = obs[i:i + self.max_batch], masks[i:i + self.max_batch]
+            m = ob.shape[0]
+            if self.compiled and m < self.max_batch:  # the ragged tail, padded to the one compiled shape (a legal action in every pad row)
+                if self._stage is None or self._stage[0].shape[0] != self.max_batch or self._stage[0].shape[1:] != ob.shape[1:]:
+                    self._stage = (torch.zeros((self.max_batch,) + tuple(ob.shape[1:]), dtype=ob.dtype, device=ob.device),
+                                   torch.ones((self.max_batch, masks.shape[1]), dtype=torch.bool, device=ob.device))
+                self._stage[0][:m] = ob
+                self._stage[1][:m] = mk
+                ob, mk = self._stage
             with torch.autocast(obs.device.type, enabled=self.enable_amp):
-                q = self.net(obs[i:i + self.max_batch], masks[i:i + self.max_batch])
-            act, is_greedy = boltzmann_actions(q, masks[i:i + self.max_batch], self.boltzmann_epsilon, self.boltzmann_temp,
-                                               self.top_p, self.generator)
-            out[i:i + self.max_batch] = act.to(torch.int32)
+                q = self.net(ob, mk)
+            q, mk = q[:m], mk[:m]
+            act, is_greedy = boltzmann_actions(q, mk, self.boltzmann_epsilon, self.boltzmann_temp, self.top_p, self.generator)
+            out[i:i + m] = act.to(torch.int32)
             if want_meta:
-                q_all[i:i + self.max_batch] = q.float()
-                greedy_all[i:i + self.max_batch] = is_greedy
+                q_all[i:i + m] = q.float()
+                greedy_all[i:i + m] = is_greedy
         return (out, q_all, greedy_all) if want_meta else out
 
     def react_batch(self, obs, masks, invisible_obs):
