@@ -64,21 +64,25 @@ __constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_uplo
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
 #define SP_L0_MAX 17            // winning draw entries per tenpai state (13 waits + 3 aka variants)
-struct alignas(128) SpNode {    // one 3n+1 state: 256 bytes = exactly two 128-byte lines (round 5; rounds 1-4: 608 bytes with the state's
-                                // key and the level-0 scores inside, 16-byte value rows).  A parent reads val[] of its children, ~6
-                                // parents per child: those reads are what the evaluation costs (a timing-only build without them:
-                                // mj_k_sp 17.6 -> 15.8 ms), so a node holds nothing else but the header they come with
+#define SP_EL_SLOT(v) ((v) & (SP_CAP - 1))  // an elist entry: hash slot | list index << 14
+#define SP_EL_IDX(v) ((v) >> 14)
+struct alignas(128) SpNode {    // one 3n+1 state's VALUES: 256 bytes = exactly two 128-byte lines, addressed by hash slot (round 5;
+                                // rounds 1-4: 608 bytes with the state's key, header and level-0 scores inside, 16-byte value rows).
+                                // A parent reads val[] of its children, ~6 parents per child: those reads are what the evaluation
+                                // costs (a timing-only build without them: mj_k_sp 17.6 -> 15.8 ms), so a node holds nothing else
+    float val[SP_T][3];         // per turn: tenpai prob, win prob, EV ((int)EV, the fold key of discard_slow, is recomputed by the reader)
+    u8 pad_[52];
+};
+static_assert(sizeof(SpNode) == 256 && offsetof(SpNode, val) == 0, "SpNode layout");
+struct alignas(16) SpHdr {      // a state's header, DENSE by list index: the level sort and the evaluation's state pipeline read a level's
+                                // headers from one contiguous range instead of one node line each
     u32 child_off;              // level > 0: first pool entry of the child list; level 0: first work item (SpWork::items / l0sc)
     unsigned short n_ch;        // level > 0: number of pool entries; level 0: number of draw entries
     u8 sumreq, n_ent;           // sum over the required tiles of their wall counts (row of the not_tsumo table); draw entries
-    u8 l0cnt[SP_L0_MAX + 3];    // level 0: copies left in the wall of every draw entry (its tsumo_prob row)
-    u8 pad_[4];
-    float val[SP_T][3];         // per turn: tenpai prob, win prob, EV ((int)EV, the fold key of discard_slow, is recomputed by the reader)
-    u8 pad2_[20];
+    u64 l0cnt2;                 // level 0: copies left in the wall of every draw entry, minus one, two bits each (its tsumo_prob row)
 };
-static_assert(sizeof(SpNode) == 256 && offsetof(SpNode, val) == 32, "SpNode layout");
-static_assert(offsetof(SpNode, child_off) % 8 == 0 && offsetof(SpNode, n_ch) == offsetof(SpNode, child_off) + 4 &&
-              offsetof(SpNode, sumreq) == offsetof(SpNode, child_off) + 6, "the evaluation reads the header as one u64");
+static_assert(sizeof(SpHdr) == 16 && offsetof(SpHdr, n_ch) == 4 && offsetof(SpHdr, sumreq) == 6 && offsetof(SpHdr, l0cnt2) == 8,
+              "the evaluation reads the header as one or two u64");
 struct SpKeys {                 // a state's key and exact id, DENSE by list index (the order of creation): the expansion / probe passes
                                 // read the 16 states of a chunk as one contiguous block instead of 16 node lines + 16 tag lines
     u64 k0, k1, k2, k3;         // hand.mp | hand.sz + akas_in_hand<<48 | wall.mp | wall.sz + akas_in_wall<<48
@@ -96,8 +100,9 @@ struct alignas(128) SpWork {   // per-workgroup scratch in HBM (persistent workg
     u64 tag[SP_CAP];           // 0 = empty, else state id | 1 << 63
     SpNode node[SP_CAP];       // by hash slot
     SpKeys keys[SP_CAP];       // by list index
+    SpHdr hdr[SP_CAP];         // by list index
     u32 list[SP_CAP];          // slots grouped by level: level L occupies [lvl_begin[L], lvl_end[L])
-    u32 elist[SP_CAP];         // the same ranges ordered by child-list length for the evaluation (sp_sort_level)
+    u32 elist[SP_CAP];         // the same ranges ordered by child-list length for the evaluation (sp_sort_level): slot | list index << 14
     u32 pool[SP_POOL];         // child lists
     u32 items[SP_ITEMS];       // level 0: (list index, winning tile, variant) work items of the dense scoring pass
     SpF4 l0sc[SP_ITEMS];       // level 0: get_score() of every work item (sp_l0_score), all zero = no yaku
@@ -721,7 +726,6 @@ __device__ SP_ATTR_L0P void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, i
         const SpState S = sp_chunk_state(C, s);
         const u64 req = C->req[s];
         const u32 slot = C->slot[s];
-        SP_HBM SpNode& node = Wg->node[slot];
         int cnt = 0, sumreq = 0;
         for (u64 rest = req; rest; rest &= rest - 1) {
             const int t = __ffsll((long long)rest) - 1;
@@ -729,6 +733,7 @@ __device__ SP_ATTR_L0P void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, i
             cnt += (!aka || S.w.get(t) >= 2) + aka;
             sumreq += S.w.get(t);
         }
+        u64 cnt2 = 0;
         if (cnt > SP_L0_MAX) { X->overflow = 1; cnt = SP_L0_MAX; }
         const int base = atomicAdd(&X->n_items, cnt);
         int e = 0;
@@ -741,15 +746,18 @@ __device__ SP_ATTR_L0P void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, i
                 if (e < cnt) {
                     if (base + e < SP_ITEMS) Wg->items[base + e] = (u32)(first + s) | ((u32)e << 14) | ((u32)t << 19) | ((u32)variant << 25);
                     else X->overflow = 1;
-                    node.l0cnt[e] = (u8)(!aka ? wc : variant == 0 ? wc - 1 : 1);  // draw_without_tegawari's `count`
+                    cnt2 |= (u64)(((!aka ? wc : variant == 0 ? wc - 1 : 1) - 1) & 3) << (2 * e);  // draw_without_tegawari's `count` (1..4)
                 }
                 e++;
             }
         }
-        node.child_off = (u32)min(base, SP_ITEMS - 1);  // the state's first work item: its scores are l0sc[child_off ...]
-        node.n_ch = (unsigned short)cnt;
-        node.sumreq = (u8)(sumreq & 0xFF);
-        node.n_ent = (u8)cnt;
+        (void)slot;
+        SP_HBM SpHdr& hd = Wg->hdr[first + s];
+        hd.child_off = (u32)min(base, SP_ITEMS - 1);  // the state's first work item: its scores are l0sc[child_off ...]
+        hd.n_ch = (unsigned short)cnt;
+        hd.sumreq = (u8)(sumreq & 0xFF);
+        hd.n_ent = (u8)cnt;
+        hd.l0cnt2 = cnt2;
     }
     mj_team_sync<SP_NT>();
 }
@@ -795,11 +803,11 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
             int it = my_first;
             for (u64 rest = C->req[s]; rest; rest &= rest - 1) C->item[it++] = (unsigned short)(s | ((__ffsll((long long)rest) - 1) << SP_SB));
             if (it == my_first) {
-                SP_HBM SpNode& node = Wg->node[C->slot[s]];
-                node.child_off = 0;
-                node.n_ch = 0;
-                node.sumreq = 0;
-                node.n_ent = 0;
+                SP_HBM SpHdr& hd = Wg->hdr[first + s];
+                hd.child_off = 0;
+                hd.n_ch = 0;
+                hd.sumreq = 0;
+                hd.n_ent = 0;
             }
         }
         mj_team_sync<SP_NT>();
@@ -867,11 +875,11 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
                     int child_base = atomicAdd(&X->n_pool, total);
                     if (child_base + total > SP_POOL) { X->overflow = 1; child_base = SP_POOL; total = 0; }
                     C->child_base[my_s] = child_base;
-                    SP_HBM SpNode& node = Wg->node[C->slot[my_s]];
-                    node.child_off = (u32)min(child_base, SP_POOL - 1);
-                    node.n_ch = (unsigned short)total;
-                    node.sumreq = (u8)(sumreq & 0xFF);
-                    node.n_ent = (u8)min(n_ent, 255);
+                    SP_HBM SpHdr& hd = Wg->hdr[first + my_s];
+                    hd.child_off = (u32)min(child_base, SP_POOL - 1);
+                    hd.n_ch = (unsigned short)total;
+                    hd.sumreq = (u8)(sumreq & 0xFF);
+                    hd.n_ent = (u8)min(n_ent, 255);
                 }
             }
             if (tid == 0) C->eoff[n_items] = (unsigned short)n_entries;
@@ -1076,9 +1084,11 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     const int hp_own = hp_base + (int)assume_riichi + (int)(haitei && ln == T - 1), hp_last = hp_base + (int)haitei;
     const SP_HBM float* const nt_rows = (const SP_HBM float*)c_sp_nt + (size_t)__builtin_amdgcn_readfirstlane(min(X->n_left, SP_NT_ROWS - 1)) * (SP_NT_ROWS * SP_NT_STRIDE);
     const int last = max(end - 1, 0);
-    auto ld_slot = [&](int i) -> u32 { return sp_ld<u32>(elistB, 4u * (u32)min(i, last)) & (SP_CAP - 1); };
+    auto ld_slot = [&](int i) -> u32 { return sp_ld<u32>(elistB, 4u * (u32)min(i, last)); };  // hash slot | list index << 14
     SP_HBM SpF4* const scB = sp_uniform(&Wg->l0sc[0]);
-    auto ld_hdr = [&](u32 slot) -> u64 { return sp_ld<unsigned long long>(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, child_off)); };
+    SP_HBM SpHdr* const hdrB = sp_uniform(&Wg->hdr[0]);
+    auto ld_hdr = [&](u32 el) -> u64 { return sp_ld<unsigned long long>(hdrB, 16u * SP_EL_IDX(el)); };
+    auto ld_cnt = [&](u32 el) -> u64 { return sp_ld<unsigned long long>(hdrB, 16u * SP_EL_IDX(el) + 8u); };  // two bits per draw entry: copies - 1
     auto ld_m = [&](u64 hdr) -> float { return sp_ld<float>(nt_rows, 4u * ((u32)min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + (u32)ln)); };
     // an entry's four scores are kept as four scalars and picked by one-hot WEIGHTS (x * 1 + 0 + 0 + 0 is exact): a struct or array
     // whose element is picked by a run-time index ends up in scratch behind flat loads
@@ -1091,10 +1101,6 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
     const int hp_fin = ln == T - 1 ? hp_own : hp_last;
     const float wf0 = hp_fin == 0 ? 1.f : 0.f, wf1 = hp_fin == 1 ? 1.f : 0.f, wf2 = hp_fin == 2 ? 1.f : 0.f, wf3 = hp_fin == 3 ? 1.f : 0.f;
     const int nl = T - ln;  // this lane's terms: turns ln .. T - 1
-    auto ld_cnt4 = [&](u32 slot, int e0) -> u32 {  // l0cnt[e0 .. e0 + 3]
-        return sp_ld<u32>(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, l0cnt) + (u32)min(e0, SP_L0_MAX + 3 - 4));
-    };
-    static_assert(offsetof(SpNode, l0cnt) % 4 == 0, "l0cnt is read four bytes at a time");
     mj_team_sync<64>();
 
     int i = first;
@@ -1108,7 +1114,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
         const SpF4 p = ld_sc(h0, q);
         sx[q] = p.x; sy[q] = p.y; sz[q] = p.z; sw[q] = p.w;
     }
-    u32 cw = ld_cnt4(s0, 0);
+    u64 cw = ld_cnt(s0);
     while (__ballot(has) != 0ull) {
         const int n_ent = (int)((h0 >> 32) & 0xFFFF);
         // in flight under this state: the next state's first entries, the header after it, the slot after that
@@ -1119,7 +1125,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             const SpF4 p = ld_sc(h1, q);
             nx_[q] = p.x; ny_[q] = p.y; nz_[q] = p.z; nw_[q] = p.w;
         }
-        const u32 cwn = ld_cnt4(s1, 0);
+        const u64 cwn = ld_cnt(s1);
         const u64 h2 = ld_hdr(s2);
         const u32 s3 = ld_slot(i + 3 * stride);
         const float my_m = m_raw != 0.f ? m_raw : 1.f, my_r = sp_rcp_refined(my_m);
@@ -1133,13 +1139,12 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
                     const SpF4 p = ld_sc(h0, e0 + q);
                     sx[q] = p.x; sy[q] = p.y; sz[q] = p.z; sw[q] = p.w;
                 }
-                cw = ld_cnt4(s0, e0);
             }
             u32 use = 0;  // bit q: this team has a draw entry with a yaku in slot q of the step
 #pragma unroll
             for (int q = 0; q < SP_EV_ENT; q++) {
                 const bool u = has && e0 + q < n_ent && sx[q] != 0.f;  // a draw entry with a yaku (sp_l0_score)
-                const u32 cnt = (cw >> (8 * q)) & 0xFFu;
+                const u32 cnt = ((u32)(cw >> (2 * (e0 + q))) & 3u) + 1u;
                 const float tpc = cnt <= 1 ? tp0 : cnt == 2 ? tp1 : cnt == 3 ? tp2 : tp3;
                 if (u) {
                     // A[ln]; the LAST turn's numerator is parked apart and its place in the row stays zero: its term is the last one
@@ -1188,7 +1193,7 @@ __device__ SP_ATTR_EVAL0 void sp_eval_wave0(SpWork* W, SpCtx* X, float* WL, int 
             mj_team_sync<64>();
         }
         if (has) {
-            sp_st3(nodeB, s0 * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, val) + 12u * (u32)ln, 0.f, acc_w, acc_e);
+            sp_st3(nodeB, SP_EL_SLOT(s0) * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, val) + 12u * (u32)ln, 0.f, acc_w, acc_e);
         }
         s0 = s1; s1 = s2; s2 = s3;
         h0 = h1; h1 = h2;
@@ -1236,8 +1241,9 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
     SP_HBM SpNode* const nodeB = sp_uniform(&Wg->node[0]);
     SP_HBM u32* const elistB = sp_uniform(&Wg->elist[0]);
     SP_HBM u32* const poolB = sp_uniform(&Wg->pool[0]);
-    auto ld_slot = [&](int i) -> u32 { return sp_ld<u32>(elistB, 4u * (u32)min(i, last)) & (SP_CAP - 1); };
-    auto ld_hdr = [&](u32 slot) -> u64 { return sp_ld<unsigned long long>(nodeB, slot * (u32)sizeof(SpNode) + (u32)offsetof(SpNode, child_off)); };
+    SP_HBM SpHdr* const hdrB = sp_uniform(&Wg->hdr[0]);
+    auto ld_slot = [&](int i) -> u32 { return sp_ld<u32>(elistB, 4u * (u32)min(i, last)); };  // hash slot | list index << 14
+    auto ld_hdr = [&](u32 el) -> u64 { return sp_ld<unsigned long long>(hdrB, 16u * SP_EL_IDX(el)); };
     auto ld_m = [&](u64 hdr) -> float { return sp_ld<float>(nt_rows, 4u * ((u32)min((int)((hdr >> 48) & 0xFF), SP_NT_ROWS - 1) * SP_NT_STRIDE + (u32)ln)); };
     auto ld_ent = [&](u32 at) -> u32 { return sp_ld<u32>(poolB, 4u * min(at, (u32)(SP_POOL - 1))); };
     auto ld_val = [&](u32 ent) -> SpF3 { return sp_ld3(nodeB, SP_ENT_SLOT(ent) * (u32)sizeof(SpNode) + val_ln); };  // one 12-byte load
@@ -1366,7 +1372,7 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
 
         // ---- end of a state: its values, then the pipeline moves up
         if (done) {
-            sp_st3(nodeB, s0 * (u32)sizeof(SpNode) + val_ln, acc_t, acc_w, acc_e);
+            sp_st3(nodeB, SP_EL_SLOT(s0) * (u32)sizeof(SpNode) + val_ln, acc_t, acc_w, acc_e);
             s0 = s1; s1 = s2; s2 = s3; s3 = s4;
             h0 = h1; h1 = h2; h2 = h3;
             m_raw = m_nxt; m_nxt = m_n2;
@@ -1395,32 +1401,27 @@ __device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] *
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int tid = threadIdx.x;
     if (e - b <= SP_SORT_MIN) {  // a handful of states (the root level): one round of teams whatever the order
-        for (int i = b + tid; i < e; i += SP_THREADS) Wg->elist[i] = Wg->list[i];
+        for (int i = b + tid; i < e; i += SP_THREADS) Wg->elist[i] = Wg->list[i] | ((u32)i << 14);
         __syncthreads();
         return;
     }
     if (tid < 64) hist[tid] = 0;
     __syncthreads();
-    auto cost_key = [&](u32 slot) {  // ~ fold work (children) + accumulate work (draw entries), longest first
-        const SP_HBM SpNode& nd = Wg->node[slot];
-        return 63 - min(((int)nd.n_ch + 4 * (int)nd.n_ent) >> 1, 63);
+    auto cost_key = [&](int i) {  // ~ fold work (children) + accumulate work (draw entries), longest first (headers: dense by list index)
+        const SP_HBM SpHdr& hd = Wg->hdr[i];
+        return 63 - min(((int)hd.n_ch + 4 * (int)hd.n_ent) >> 1, 63);
     };
-    // a thread's first four states keep their slot and key in registers between the two passes (levels up to 4 x 256 states:
-    // one dependent load chain instead of two)
+    // a thread's first four states keep their slot and key in registers between the two passes (levels up to 4 x 256 states)
     u32 my_slot[4];
     int my_key[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int i = b + tid + q * SP_THREADS;
-        my_slot[q] = i < e ? Wg->list[i] : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int i = b + tid + q * SP_THREADS;
-        my_key[q] = i < e ? cost_key(my_slot[q]) : 0;
+        my_slot[q] = i < e ? (Wg->list[i] | ((u32)i << 14)) : 0u;
+        my_key[q] = i < e ? cost_key(i) : 0;
         if (i < e) atomicAdd(&hist[my_key[q]], 1);
     }
-    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) atomicAdd(&hist[cost_key(Wg->list[i])], 1);
+    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) atomicAdd(&hist[cost_key(i)], 1);
     __syncthreads();
     if (tid < 64) {  // exclusive prefix over the 64 buckets: one wavefront scan
         const int c = hist[tid];
@@ -1432,10 +1433,7 @@ __device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] *
         const int i = b + tid + q * SP_THREADS;
         if (i < e) Wg->elist[b + atomicAdd(&hist[my_key[q]], 1)] = my_slot[q];
     }
-    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) {
-        const u32 slot = Wg->list[i];
-        Wg->elist[b + atomicAdd(&hist[cost_key(slot)], 1)] = slot;
-    }
+    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) Wg->elist[b + atomicAdd(&hist[cost_key(i)], 1)] = Wg->list[i] | ((u32)i << 14);
     __syncthreads();
 }
 
