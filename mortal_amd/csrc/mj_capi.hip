@@ -109,7 +109,7 @@ std::vector<float> build_rbf(int n_max, int cap, int intervals) {
 }
 
 size_t enc_lds_bytes(int version) {
-    int C = version == 1 ? 938 : version == 2 ? 942 : version == 3 ? 934 : 1012;
+    int C = enc_rows_written(version);
     int tile_rows = ((C + ENC_PASSES - 1) / ENC_PASSES + 1) & ~1;
     return (size_t)tile_rows * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + sizeof(EncDerived);
 }

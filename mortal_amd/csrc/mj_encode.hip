@@ -40,6 +40,8 @@ struct EncParams {
 };
 
 #define ENC_THREADS 256
+// obs v4: rows 889 .. 1011 (the SP block) belong to mj_k_sp; row 889 is only 8-byte aligned, so the split is at row 890 (889 leaves here as zeros)
+constexpr int enc_rows_written(int version) { return version == 1 ? 938 : version == 2 ? 942 : version == 3 ? 934 : 890; }
 #ifndef ENC_PASSES
 #define ENC_PASSES 8   // output passes per decision row = LDS tile of C / 8 rows.  With the op list a pass is {zero, apply, stream}: more,
                        // smaller tiles only cost barriers and buy resident workgroups (5 per CU at 8 passes).  Measured (round 4, one box,
@@ -162,7 +164,9 @@ template <int V>
 __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
     typedef Lay<V> O;
     constexpr int C = O::total;
-    constexpr int TILE_ROWS = ((C + ENC_PASSES - 1) / ENC_PASSES + 1) & ~1;  // even -> tile bytes % 16 == 0
+    constexpr int CW = enc_rows_written(V);  // the rows THIS kernel writes: all, or (v4) those below the SP block, which mj_k_sp writes whole
+    static_assert(CW % 2 == 0 || CW == C, "the streamed rows end on a 16-byte boundary");
+    constexpr int TILE_ROWS = ((CW + ENC_PASSES - 1) / ENC_PASSES + 1) & ~1;  // even -> tile bytes % 16 == 0
     MJ_DYN_SHARED(float4, smem4);
     float* tile = reinterpret_cast<float*>(smem4);
     TableOne* st = reinterpret_cast<TableOne*>(tile + TILE_ROWS * 34);
@@ -653,8 +657,8 @@ __global__ __launch_bounds__(ENC_THREADS) void mj_k_encode(EncParams P) {
     // ---- 4. passes: zero a tile, apply the ops that fall into it, stream it out
     float4* dst = reinterpret_cast<float4*>(P.obs + (size_t)row * (C * 34));
     for (int pass = 0; pass < ENC_PASSES; pass++) {
-        const int r0 = pass * TILE_ROWS, r1 = min(C, r0 + TILE_ROWS);
-        if (r0 >= C) break;
+        const int r0 = pass * TILE_ROWS, r1 = min(CW, r0 + TILE_ROWS);
+        if (r0 >= CW) break;
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             constexpr int N4 = TILE_ROWS * 34 / 4;

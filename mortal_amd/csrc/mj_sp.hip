@@ -222,7 +222,10 @@ struct alignas(16) SpCtx {  // per-decision constants (LDS)
     int n_cand;
     int cand_tile[SP_MAX_CAND], cand_slot[SP_MAX_CAND], cand_down[SP_MAX_CAND], cand_nreq[SP_MAX_CAND];
     u64 cand_req[SP_MAX_CAND];
-    u64 spec_req[2][34];  // row set-up: required draws of root - d for every held kind d, [1] = one shanten number up (4+ shanten roots)
+    u64 spec_req[2][34];  // row set-up: required draws of root - d for every held kind d, [1] = one shanten number up (4+ shanten roots);
+                          // row output: the 34-bit masks of block rows 2 .. 69 (sp_block_write)
+    u64 row7x[2];         // row output: masks of block rows 70 (the candidate with the most required tiles) and 71 (no discard)
+    signed char colcand[36];  // row output: tile column -> candidate whose table it shows (-1: none)
     int order[SP_MAX_CAND];
     float cand_tp0[SP_MAX_CAND], cand_wp0[SP_MAX_CAND], cand_ev0[SP_MAX_CAND];
 };
@@ -1514,6 +1517,61 @@ __global__ __launch_bounds__(256) void mj_k_order_scatter(const uint8_t* cls, in
     if (i < n) order[base[c] + r] = (uint32_t)i;
 }
 
+// The SP block of one decision row, rows 889 .. 1011 of obs v4 (obs_repr.rs:564-692), written WHOLE by this kernel since round 5 -- the
+// encoder stops at row 890 (rounds 1-4: mj_k_encode<4> zero-filled the 123 rows, 16.7 KB per decision, and mj_k_sp rewrote the cells that
+// are not zero: 1.1 GB per cycle written twice, the second time as scattered 4-byte stores into lines that had left the L2).
+//   block row 0 / 1 : max EV / 100 k and / 30 k in every column          (ev100 / ev30)
+//   block rows 2..69: required tiles per discard (34 keep + 34 shanten-down rows): bit column of rowm[row - 2]
+//   block row 70/71 : the candidate with the most required tiles / required tiles without a discard: row7[0 / 1]
+//   block rows 72.. : tenpai / win / EV tables, [3][SP_T] rows, column = the candidate's tile (tv: [candidate][turn][4], alive_n[candidate] =
+//                     number of leading turns with a positive tenpai probability: take_while of obs_repr.rs:655-660)
+// Row 889 (8-byte aligned only) goes out as 34 scalar stores (the encoder's tile holds zeros there), rows 890.. as one 8-byte store per lane.
+template <bool WAVE, int NT, class OutP>
+__device__ __forceinline__ void sp_block_write(OutP out, const int tid, const float ev100, const float ev30, const u64* rowm, const u64* row7,
+                                               const bool table_ok, const bool one_for_all, const signed char* colcand, const float* tv,
+                                               const int* alive_n, const int T) {
+    constexpr int O_SP = 889;  // Lay<4>::sp
+    if (tid < 34) out[O_SP * 34 + tid] = ev100;
+    // Three block rows per 51 lanes: lane -> (row in the group, column pair) is loop-invariant, an iteration is one mask read, two bit tests
+    // and one 8-byte store per lane.
+    constexpr int G = NT / 51;                       // groups of 3 rows in flight (1 for a wavefront, 5 for the workgroup)
+    const int grp = tid / 51, l51 = tid - 51 * grp;  // group, lane inside it
+    const int lr = l51 / 17, c2 = l51 - 17 * lr;     // row inside the group, column pair
+    const bool lane_on = grp < G;
+    // block rows 1 .. 71: EV / 30 k, then the required-tile masks
+    for (int r0 = 1 + 3 * grp; r0 < 72; r0 += 3 * G) {
+        const int rb = r0 + lr;
+        if (lane_on && rb < 72) {
+            float v0, v1;
+            if (rb == 1) {
+                v0 = v1 = ev30;
+            } else {
+                const u64 m = !rowm ? 0ull : rb < 70 ? rowm[rb - 2] : row7[rb - 70];
+                const u32 two = (u32)(m >> (2 * c2)) & 3u;
+                v0 = (float)(two & 1u);
+                v1 = (float)(two >> 1);
+            }
+            out[(O_SP + rb) * 34 + 2 * c2] = v0;
+            out[(O_SP + rb) * 34 + 2 * c2 + 1] = v1;
+        }
+    }
+    // block rows 72 .. 122: the tables, or zeros
+    for (int r0 = 72 + 3 * grp; r0 < 123; r0 += 3 * G) {
+        const int rb = r0 + lr;
+        if (lane_on && rb < 123) {
+            float v0 = 0.f, v1 = 0.f;
+            if (table_ok) {
+                const int t = rb - 72, kind = t >= 2 * SP_T ? 2 : t >= SP_T ? 1 : 0, turn = t - kind * SP_T;
+                const int ca = one_for_all ? 0 : (int)colcand[2 * c2], cb = one_for_all ? 0 : (int)colcand[2 * c2 + 1];
+                if (ca >= 0 && turn < T && turn < alive_n[ca]) v0 = tv[(ca * SP_T + turn) * 4 + kind];
+                if (cb >= 0 && turn < T && turn < alive_n[cb]) v1 = tv[(cb * SP_T + turn) * 4 + kind];
+            }
+            out[(O_SP + rb) * 34 + 2 * c2] = v0;
+            out[(O_SP + rb) * 34 + 2 * c2 + 1] = v1;
+        }
+    }
+}
+
 template <class P> struct SpF4Of { typedef const SpRec* type; };                    // 16-byte view of a table record pointer,
 template <> struct SpF4Of<const SP_HBM TableOne*> { typedef const SP_HBM SpRec* type; };  // in the pointer's own address space
 struct SpRowInfo {  // what the row set-up hands to the graph phases and to the encoder
@@ -1532,7 +1590,6 @@ template <bool WAVE> MJD void sp_sync() {  // the threads that process ONE row: 
 template <bool WAVE, int NT, class RowsP, class SnapP, class OutP>
 __device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork* W, SpCtx& X, TableOne* st, const int tid, const int row, OutP out,
                                                   unsigned long long* prof) {  // (never a reference to the kernel's parameter block: hipcc would copy it to scratch)
-    constexpr int O_SP = 889;  // Lay<4>::sp
     SpRowInfo R;
     R.ok = false;
     R.with_probs = false;
@@ -1592,10 +1649,8 @@ __device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork
             }
             sp_sync<WAVE>();
             const float v = X.cand_ev0[0];
-            if (tid < 34) {
-                out[(O_SP + 0) * 34 + tid] = fminf(fmaxf(v, 0.f), 100000.f) / 100000.f;
-                out[(O_SP + 1) * 34 + tid] = fminf(fmaxf(v, 0.f), 30000.f) / 30000.f;
-            }
+            sp_block_write<WAVE, NT>(out, tid, fminf(fmaxf(v, 0.f), 100000.f) / 100000.f, fminf(fmaxf(v, 0.f), 30000.f) / 30000.f, (const u64*)nullptr,
+                                     (const u64*)nullptr, false, false, (const signed char*)nullptr, (const float*)nullptr, (const int*)nullptr, 0);
             sp_sync<WAVE>();
             return R;
         }
@@ -1749,7 +1804,6 @@ __device__ __forceinline__ SpRowInfo sp_row_front(RowsP rows, SnapP snap, SpWork
 // Sorting of the candidates + the encoder block of obs v4 (rows 889..1011).
 template <bool WAVE, int NT, class OutP>
 __device__ __forceinline__ void sp_row_write(const SpNode* nodes, SpCtx& X, const SpRowInfo& R, const int tid, OutP out, float* tv_area) {
-    constexpr int O_SP = 889;  // Lay<4>::sp
     const int n_cand = R.n_cand, cur_shanten = R.cur_shanten, T = R.T, last_tsumo = R.last_tsumo;
     const bool with_probs = R.with_probs && tv_area != nullptr;  // (the queue tail of mj_k_sp: rows without a state graph, no staging area)
     const bool can_discard0 = R.can_discard0, after_riichi = R.after_riichi;
@@ -1800,37 +1854,38 @@ __device__ __forceinline__ void sp_row_write(const SpNode* nodes, SpCtx& X, cons
         {
             const int first = n_cand > 0 ? X.order[0] : -1;
             const float max_ev = (with_probs && first >= 0 && T > 0) ? X.cand_ev0[first] : 0.f;
-            if (tid < 34) {
-                out[(O_SP + 0) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 100000.f) / 100000.f;
-                out[(O_SP + 1) * 34 + tid] = fminf(fmaxf(max_ev, 0.f), 30000.f) / 30000.f;
-            }
-            // required tiles
+            // ---- the masks of block rows 2 .. 71 (required tiles), one 34-bit word per output row
+            u64* const rowm = &X.spec_req[0][0];  // (the set-up's speculative sets are consumed)
+            static_assert(sizeof(X.spec_req) == 68 * sizeof(u64), "block rows 2 .. 69 = [keep / shanten-down][34 discards]");
+            for (int i = tid; i < 68; i += NT) rowm[i] = 0ull;  // (NT = 64 for the rows a single wavefront processes)
+            if (tid < 2) X.row7x[tid] = 0ull;
+            if (tid < 34) X.colcand[tid] = -1;
+            sp_sync<WAVE>();
             if (can_discard0 && !after_riichi) {
-                for (int c = tid / 34; c < n_cand; c += NT / 34) {
-                    int t = tid % 34;
-                    if (tid >= (NT / 34) * 34) break;
-                    if ((X.cand_req[c] >> t) & 1) {
-                        int dtid = deaka(X.cand_tile[c]);
-                        out[(O_SP + 2 + (X.cand_down[c] ? 34 : 0) + dtid) * 34 + t] = 1.f;
-                    }
+                if (tid < n_cand) {
+                    const int dtid = deaka(X.cand_tile[tid]);
+                    rowm[(X.cand_down[tid] ? 34 : 0) + dtid] = X.cand_req[tid];
+                    X.colcand[dtid] = (signed char)tid;
                 }
-                if (tid == 0 && X.lvl_begin[4] >= 0) out[(O_SP + 70) * 34 + deaka(X.cand_tile[X.lvl_begin[4]])] = 1.f;
+                if (tid == 0 && X.lvl_begin[4] >= 0) X.row7x[0] = 1ull << deaka(X.cand_tile[X.lvl_begin[4]]);
             } else if (can_discard0) {
                 // discard after riichi: `cans.can_discard` is still true in the encoder (obs_repr.rs:580), the single
                 // candidate's tile was patched to the drawn tile (agent_helper.rs:588-590)
-                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 2 + deaka(last_tsumo)) * 34 + tid] = 1.f;
-                if (tid == 0) out[(O_SP + 70) * 34 + deaka(last_tsumo)] = 1.f;
+                if (tid == 0) {
+                    if (first >= 0) rowm[deaka(last_tsumo)] = X.cand_req[first];
+                    X.row7x[0] = 1ull << deaka(last_tsumo);
+                    if (n_cand > 0) X.colcand[deaka(last_tsumo)] = 0;
+                }
             } else {
-                if (tid < 34 && first >= 0 && ((X.cand_req[first] >> tid) & 1)) out[(O_SP + 71) * 34 + tid] = 1.f;
+                if (tid == 0 && first >= 0) X.row7x[1] = X.cand_req[first];
             }
             // sp table (obs_repr.rs:644-692)
             const float ev_scale = max_ev < 1.f ? 0.f : 1.f / max_ev;
             bool table_ok = with_probs && first >= 0 && X.cand_tp0[first] > 0.f;
+            float* tv = tv_area;  // [candidate slot * SP_T + turn][4]: tenpai, win, ev, alive
             if (table_ok) {  // uniform over the workgroup
                 // one load per (candidate, turn): the clamped values go to the LDS (the evaluation scratch is free now), and
-                // take_while(p > 0) on the tenpai probs becomes an AND over the lower turns' flags (instead of a chain of up to
-                // 17 dependent loads per thread)
-                float* tv = tv_area;  // [candidate slot * SP_T + turn][4]: tenpai, win, ev, alive
+                // take_while(p > 0) on the tenpai probs becomes a count of the leading positive turns
                 static_assert(SP_EVAL_LDS_FLOATS >= SP_MAX_CAND * SP_T * 4, "table staging fits the evaluation scratch");
                 const int n_src = can_discard0 ? n_cand : 1;
                 for (int q = tid; q < n_src * SP_T; q += NT) {
@@ -1848,33 +1903,16 @@ __device__ __forceinline__ void sp_row_write(const SpNode* nodes, SpCtx& X, cons
                     }
                 }
                 sp_sync<WAVE>();
-                auto alive_upto = [&](int c, int turn) {
-                    bool alive = true;
-                    for (int q = 0; q <= turn; q++) alive = alive && tv[(c * SP_T + q) * 4 + 3] != 0.f;
-                    return alive;
-                };
-                if (can_discard0) {
-                    for (int q = tid; q < n_cand * SP_T; q += NT) {
-                        const int c = q / SP_T, turn = q % SP_T;
-                        if (turn < T && alive_upto(c, turn)) {
-                            const int col = after_riichi ? deaka(last_tsumo) : deaka(X.cand_tile[c]);
-                            const float* src = tv + (c * SP_T + turn) * 4;
-                            out[(O_SP + 72 + turn) * 34 + col] = src[0];
-                            out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
-                            out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
-                        }
-                    }
-                } else {
-                    for (int w = tid; w < SP_T * 34; w += NT) {
-                        const int turn = w / 34, col = w % 34;
-                        if (turn >= T || !alive_upto(0, turn)) continue;
-                        const float* src = tv + turn * 4;
-                        out[(O_SP + 72 + turn) * 34 + col] = src[0];
-                        out[(O_SP + 72 + SP_T + turn) * 34 + col] = src[1];
-                        out[(O_SP + 72 + 2 * SP_T + turn) * 34 + col] = src[2];
-                    }
+                if (tid < n_src) {  // (the node slots are read: cand_slot now holds the candidates' alive counts)
+                    int n_alive = 0;
+                    while (n_alive < SP_T && tv[(tid * SP_T + n_alive) * 4 + 3] != 0.f) n_alive++;
+                    X.cand_slot[tid] = n_alive;
                 }
             }
+            sp_sync<WAVE>();
+            sp_block_write<WAVE, NT>(out, tid, fminf(fmaxf(max_ev, 0.f), 100000.f) / 100000.f, fminf(fmaxf(max_ev, 0.f), 30000.f) / 30000.f,
+                                     (const u64*)rowm, (const u64*)X.row7x, table_ok, !can_discard0, (const signed char*)X.colcand, (const float*)tv,
+                                     (const int*)X.cand_slot, T);
         }
 }
 
