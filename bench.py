@@ -531,9 +531,12 @@ def main():
         }
 
     if rank == 0:
-        bytes_per_row = C * 34 * 4 + 46 + STATE_READ_BYTES
+        # obs v4 since round 5: mj_k_encode<4> writes rows 0..889 of a decision, the SP block (rows 889..1011, 16.6 KB) is written whole by
+        # mj_k_sp (mj_encode.hip: enc_rows_written) -- the encoder's algorithmic bytes are those of the rows it writes
+        enc_rows = 890 if args.version == 4 else C
+        bytes_per_row = enc_rows * 34 * 4 + 46 + STATE_READ_BYTES
         achieved = rows_timed * bytes_per_row / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-        ceiling = _write_ceiling_gbs(bufs[0], int(rows_timed / max(args.steps, 1)) * C * 34 * 4)
+        ceiling = _write_ceiling_gbs(bufs[0], int(rows_timed / max(args.steps, 1)) * enc_rows * 34 * 4)
         # HBM traffic of the encode kernel from the separate rocprofv3 --pmc passes (tools/profile_round.sh ->
         # profiles/pmc_encode.json: WRITE_SIZE + 2 x FETCH_SIZE per decision), scaled to this run's rows per launch
         traffic = traffic_src = None
@@ -598,6 +601,7 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_per_row * rows_timed / max(enc_launches, 1),
                 "bytes_per_decision": bytes_per_row,
+                "obs_rows_written_per_decision": enc_rows,
                 "avg_launch_ms": enc_ms / max(enc_launches, 1),
                 "launches": enc_launches,
             },

@@ -97,7 +97,7 @@ struct SpKeys {                 // a state's key and exact id, DENSE by list ind
 #define SP_ENT_INVALID (1u << 27)
 struct alignas(16) SpF4 { float x, y, z, w; };
 struct alignas(128) SpWork {   // per-workgroup scratch in HBM (persistent workgroups), 8.1 MB
-    u64 tag[SP_CAP];           // 0 = empty, else state id | 1 << 63
+    u64 tag[SP_CAP];           // state id | row epoch << 42 | 1 << 63; a tag of another epoch (or 0) is an EMPTY slot
     SpNode node[SP_CAP];       // by hash slot
     SpKeys keys[SP_CAP];       // by list index
     SpHdr hdr[SP_CAP];         // by list index
@@ -106,6 +106,8 @@ struct alignas(128) SpWork {   // per-workgroup scratch in HBM (persistent workg
     u32 pool[SP_POOL];         // child lists
     u32 items[SP_ITEMS];       // level 0: (list index, winning tile, variant) work items of the dense scoring pass
     SpF4 l0sc[SP_ITEMS];       // level 0: get_score() of every work item (sp_l0_score), all zero = no yaku
+    u32 epoch;                 // the tag epoch of the last row with a state graph this workgroup processed (persists across launches)
+    u32 pad_[31];
 #ifdef MJ_EMU
     u32 idx_of[SP_CAP];        // emulator only: slot -> list index, for the id <-> key bijection check on every hit
 #endif
@@ -218,6 +220,7 @@ struct alignas(16) SpCtx {  // per-decision constants (LDS)
     unsigned long long pt[8];  // per-row sums of the expansion pass timers / counters (flushed once per row)
     unsigned long long* cc;    // the workgroup's child cache in LDS (SP_CC_N entries; NULL: none) and this row's epoch (8 bits, never 0... see mj_k_sp)
     unsigned cc_epoch;
+    unsigned tag_epoch;        // this row's epoch in the hash tags (sp_tag_free)
     // candidates
     int n_cand;
     int cand_tile[SP_MAX_CAND], cand_slot[SP_MAX_CAND], cand_down[SP_MAX_CAND], cand_nreq[SP_MAX_CAND];
@@ -334,7 +337,13 @@ MJD u32 sp_dk_pos(u64 dk) {  // first probe position
     return (h * 0x2C1B3C6Du) >> 18;  // top 14 bits: SP_CAP slots
 }
 static_assert(SP_CAP == 1 << 14, "sp_dk_pos returns 14 bits");
-#define SP_TAG(dk) ((dk) | (1ull << 63))  // never 0 (0 = empty slot)
+// Tags carry the EPOCH of the row that set them (21 bits between the 42-bit id and the valid bit): a slot whose tag belongs to another
+// row is empty, so nothing has to be cleared between rows (rounds 1-4: one 8-byte store per state, 0.7 GB per launch as 32-byte
+// sectors, after re-reading the list).  The epoch counts this workgroup's graph rows (SpWork::epoch, kept across launches); when
+// it wraps, once in 2 M rows, the table is wiped.
+#define SP_EPOCH_MAX 0x1FFFFFu
+#define SP_TAG(dk, ep) ((dk) | ((u64)(ep) << 42) | (1ull << 63))
+MJD bool sp_tag_free(u64 t, u32 ep) { return (u32)((t >> 42) & SP_EPOCH_MAX) != ep; }  // (0: epoch 0, never a row's epoch)
 
 // ---- register pressure across the persistent row loop (round 4; every step measured inside one gpurun call)
 // mj_k_sp keeps 128 VGPRs / ~100 SGPRs for a loop body of 19 k instructions.  Two things sent registers through scratch memory,
@@ -380,9 +389,10 @@ template <typename Tp> __device__ __forceinline__ Tp* sp_opaque_s(Tp* p) { asm v
 #endif
 
 template <class TagP>
-MJD u64 sp_claim_tag(TagP tagp, u64 h, u64 expected = 0ull) {  // atomicCAS(tag, 0, h) -> previous value (relaxed, agent scope)
+MJD u64 sp_claim_tag(TagP tagp, u64 h, u64 seen) {  // claim a slot seen empty (holding `seen`): atomicCAS(tag, seen, h) (relaxed, agent scope)
+    u64 expected = seen;                            // -> 0 = claimed, else the tag found there (of this row: only this workgroup writes its table)
     __hip_atomic_compare_exchange_strong(tagp, &expected, h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return expected;
+    return expected == seen ? 0ull : expected;
 }
 // hash-set insert of the state `base` + draw `tile` - discard `dt` (either may be -1) with id `dk`; returns the slot or -1 on
 // overflow.  `fresh`: this call created the slot and wrote the node's key — the state itself is built only then (an edge
@@ -420,10 +430,12 @@ inline void sp_emu_check_hit(WP W, SpCtx* X, u32 slot, const SpState& st) {
 #endif
 template <class WP>
 __device__ __forceinline__ int sp_insert(WP W, SpCtx* X, u64 dk, const SpState& base, int tile, int dt) {  // (the row's root states)
-    const u64 tag = SP_TAG(dk);
+    const u32 ep = X->tag_epoch;
+    const u64 tag = SP_TAG(dk, ep);
     u32 pos = sp_dk_pos(dk);
     for (int probe = 0; probe < SP_CAP; probe++) {
-        const u64 old = sp_claim_tag(&W->tag[pos], tag);
+        u64 old = W->tag[pos];
+        if (sp_tag_free(old, ep)) old = sp_claim_tag(&W->tag[pos], tag, old);
         if (old == 0ull) {
             sp_new_state(W, X, pos, dk, sp_apply(base, tile, dt));
             return (int)pos;
@@ -773,6 +785,7 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
     const SpTabG TG = sp_tab_g(*SP_OPQ_PTR(1, &c_sp_tab));
     const int tid = SP_OPQ(1, (int)(threadIdx.x & (SP_NT - 1)));
     const int ld3 = X->len_div3;
+    const u32 tag_ep = X->tag_epoch;
     // optional pass timers (MJ_SP_PROF): wave wall-clock per pass, summed into prof[8..13] by lane 0
     const bool prof = X->prof != nullptr;
     long long tq0 = prof ? wall_clock64() : 0, tq1 = 0;
@@ -938,7 +951,7 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
             return E;
         };
         auto finish = [&](const Ent& E, u64 first_old, int known) -> int {  // the rest of sp_insert after the first look, the list and the child entry
-            const u64 tag = SP_TAG(E.dk);
+            const u64 tag = SP_TAG(E.dk, tag_ep);
             const SpState Sx = sp_chunk_state(C, E.s);
             u32 pos = E.pos;
             u64 old = first_old;
@@ -962,7 +975,7 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
                 }
                 pos = (pos + 1) & (SP_CAP - 1);
                 old = Wg->tag[pos];
-                if (old == 0ull) old = sp_claim_tag(&Wg->tag[pos], tag);
+                if (sp_tag_free(old, tag_ep)) old = sp_claim_tag(&Wg->tag[pos], tag, old);
             }
             if (cs < 0) X->overflow = 1;
             if (fresh) sp_new_state(Wg, X, (u32)cs, E.dk, sp_apply(Sx, E.tile, E.dt));  // next list index: slot, key and id
@@ -1004,8 +1017,8 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
             // become ~25 M.
             if (A.on && ka < 0) oa = Wg->tag[A.pos];
             if (B.on && kb < 0) ob = Wg->tag[B.pos];
-            if (A.on && ka < 0 && oa == 0ull) oa = sp_claim_tag(&Wg->tag[A.pos], SP_TAG(A.dk));
-            if (B.on && kb < 0 && ob == 0ull) ob = sp_claim_tag(&Wg->tag[B.pos], SP_TAG(B.dk));
+            if (A.on && ka < 0 && sp_tag_free(oa, tag_ep)) oa = sp_claim_tag(&Wg->tag[A.pos], SP_TAG(A.dk, tag_ep), oa);
+            if (B.on && kb < 0 && sp_tag_free(ob, tag_ep)) ob = sp_claim_tag(&Wg->tag[B.pos], SP_TAG(B.dk, tag_ep), ob);
             if (A.on) {
                 const int cs = finish(A, oa, ka);
                 if (ka < 0) cc_put(A, cs);
@@ -1957,7 +1970,8 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     SpWork* W = P.work + blockIdx.x;
     const int tid_wg = threadIdx.x, tid = tid_wg;
 
-    // the hash tags start empty: zeroed once when the work area is allocated, and every row clears the tags it set
+    // the hash tags start empty (zeroed once when the work area is allocated); a row's tags carry its epoch, no row clears anything
+    unsigned tag_epoch = W->epoch;  // (uniform; written back when the workgroup leaves the row loop)
 
     const long long t_wg0 = P.prof ? wall_clock64() : 0;  // MJ_SP_PROF: workgroup lifetime / queue + reset time (err[19..22])
 #ifndef MJ_EMU
@@ -2001,6 +2015,15 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
 #else
             if (tid == 0) X.cc = nullptr;
 #endif
+            // a new row = a new epoch of the hash tags
+            if (tag_epoch >= SP_EPOCH_MAX) {  // wrapped (once in 2 M rows): wipe the table, start over
+                for (int i = tid; i < SP_CAP; i += SP_THREADS) W->tag[i] = 0ull;
+                tag_epoch = 0;
+                __syncthreads();
+            }
+            tag_epoch++;
+            if (tid == 0) X.tag_epoch = tag_epoch;
+            __syncthreads();
             // root states = level cur_shanten
             if (tid < n_cand) {  // one lane per candidate: the claims (one L2 atomic round trip each) run side by side
                 const int c = tid;
@@ -2107,19 +2130,13 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                 s_stat[16] += (unsigned long long)X.n_items;  // level-0 draw entries scored
             }
         }
-        // ---- reset the hash set for the next row
+        // ---- the hash set needs no reset (tag epochs); a row that overflowed it is counted
         const long long t_r = P.prof ? wall_clock64() : 0;
-        {
-            const int n = min(X.n_list, SP_CAP);
-            for (int i = tid; i < n; i += SP_THREADS) W->tag[W->list[i]] = 0ull;
-            if (X.overflow && tid == 0) {
-                s_stat[0] += 1ull;
-                for (int i = 0; i < SP_CAP; i++) W->tag[i] = 0ull;
-            }
-        }
+        if (X.overflow && tid == 0) s_stat[0] += 1ull;
         __syncthreads();
         if (P.prof) t_reset += wall_clock64() - t_r;
     }
+    if (tid == 0) W->epoch = tag_epoch;
     if (P.prof && tid == 0) {
         const unsigned long long life = (unsigned long long)(wall_clock64() - t_wg0);
         s_stat[19] += life;

@@ -128,7 +128,8 @@ def test_device_helpers_host_equivalence(tmp_path):
 
 
 # mj_k_sp as compiled at the end of round 5 (hipcc of ROCm 7.2.0); lower them when the kernel improves, never raise them unmeasured
-SP_MAX_VGPR_SPILLS, SP_MAX_SGPR_SPILLS, SP_MAX_SCRATCH_BYTES = 46, 212, 480
+# (the build measured at 13.9-14.4 ms in round 5: dense key / header arrays, 256-byte nodes, whole-block row writer, tag epochs)
+SP_MAX_VGPR_SPILLS, SP_MAX_SGPR_SPILLS, SP_MAX_SCRATCH_BYTES = 30, 224, 480
 
 
 def test_sp_kernel_isa_has_no_flat_or_spilled_hot_paths(tmp_path):
