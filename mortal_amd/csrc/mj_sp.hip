@@ -614,6 +614,9 @@ MJD int sp_lane_get(int v, int lane) {
 //   P4  (edge)         : hash-set insert of h + t - d, child-list entry
 // A state with a suit key whose neighbour lies past the end of the reference's table (SPT_FALLBACK, 8 one-suit 13-tile
 // patterns) takes the brute-force loops of the reference instead (sp_*_brute).
+#ifndef SP_EINFO_CAP
+#define SP_EINFO_CAP 192  // child entries per sub-batch whose (item, discard) the layout pass leaves in LDS (the rest: binary search, bit loop)
+#endif
 struct SpChunk {
     u64 k[SP_NS][4];        // state keys (hand.mp, hand.sz | akas, wall.mp, wall.sz | akas)
     u64 dk[SP_NS];          // state ids
@@ -638,6 +641,8 @@ struct SpChunk {
     unsigned short item[SP_ITEM_CAP];       // state | tile << SP_SB
     unsigned short coff[SP_ITEM_CAP];       // offset of the item's first child inside the state's child list
     unsigned short eoff[SP_ITEM_CAP + 2];   // prefix sums of the child entries over the items
+    u32 einfo[SP_EINFO_CAP];                // the sub-batch's first child entries, decoded by their item lane in the layout pass:
+                                            // item | kept discard << 6 | draw variant << 12 | last discard of the draw entry << 13
 };
 #define SP_NT 64  // co-operating threads of a chunk
 #define SP_SB (SP_NS > 16 ? 5 : 4)  // bits of the state index inside an item
@@ -883,7 +888,19 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
             n_entries = (int)(all & 0xFFFFu);
             if (has_item) {
                 C->coff[tid] = (unsigned short)(((pv - base) & 0xFFFFu) - (u32)my_ent);
-                C->eoff[tid] = (unsigned short)((pv & 0xFFFFu) - (u32)my_ent);
+                const int e_first = (int)((pv & 0xFFFFu) - (u32)my_ent);
+                C->eoff[tid] = (unsigned short)e_first;
+                // this item's entries (draw variant x kept discard, discards ascending), decoded once here: the insert pass found an
+                // entry's item by a binary search over eoff (6 dependent LDS reads) and its discard by a loop over the kept bits, per entry
+                {
+                    int r = 0;
+                    for (u64 rest = kept; rest; rest &= rest - 1, r++) {
+                        const u32 d = (u32)(__ffsll((long long)rest) - 1);
+                        const u32 w = (u32)tid | (d << 6) | ((rest & (rest - 1)) == 0ull ? 1u << 13 : 0u);
+                        if (e_first + r < SP_EINFO_CAP) C->einfo[e_first + r] = w;
+                        if (nvar == 2 && e_first + nkeep + r < SP_EINFO_CAP) C->einfo[e_first + nkeep + r] = w | (1u << 12);
+                    }
+                }
                 if (tid == s_last) {  // one lane per state: the pool space and the node header
                     const u32 tot = upto - base;
                     int total = (int)(tot & 0xFFFFu);
@@ -916,20 +933,32 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
             Ent E;
             E.on = e < n_entries;
             const int ee = E.on ? e : 0;
-            int lo = 0, hi = n_items;  // largest item with eoff[item] <= e
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if ((int)C->eoff[mid] <= ee) lo = mid; else hi = mid;
+            int lo, vidx, d;
+            if (ee < SP_EINFO_CAP) {  // decoded by the layout pass
+                const u32 w = C->einfo[ee];
+                lo = (int)(w & 63u);
+                d = (int)((w >> 6) & 63u);
+                vidx = (int)((w >> 12) & 1u);
+                E.local = ee - (int)C->eoff[lo];
+                E.nk = 2;                                // only `rank == nk - 1` (the last discard of the draw entry) is asked of these two
+                E.rank = (w >> 13) & 1u ? 1 : 0;
+            } else {
+                lo = 0;
+                int hi = n_items;  // largest item with eoff[item] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)C->eoff[mid] <= ee) lo = mid; else hi = mid;
+                }
+                E.local = ee - (int)C->eoff[lo];
+                const u64 bits = C->kept[lo];
+                E.nk = __popcll(bits);
+                vidx = E.local >= E.nk ? 1 : 0;
+                E.rank = E.local - vidx * E.nk;
+                u64 mrest = bits;
+                for (int r = E.rank; r > 0; r--) mrest &= mrest - 1;
+                d = __ffsll((long long)mrest) - 1;
             }
             E.it = lo;
-            E.local = ee - (int)C->eoff[lo];
-            const u64 bits = C->kept[lo];
-            E.nk = __popcll(bits);
-            const int vidx = E.local >= E.nk ? 1 : 0;
-            E.rank = E.local - vidx * E.nk;
-            u64 mrest = bits;
-            for (int r = E.rank; r > 0; r--) mrest &= mrest - 1;
-            const int d = __ffsll((long long)mrest) - 1;
             E.s = C->item[lo] & (SP_NS - 1);
             const int t = C->item[lo] >> SP_SB;
             const SpState Sx = sp_chunk_state(C, E.s);
