@@ -9,6 +9,9 @@
 #pragma once
 #include "mj_algo.h"
 #include "mj_deal.h"
+#include "mj_sptab.h"
+
+__constant__ SpTabDev c_sp_tab;  // table-id shanten (mj_sptab.h; set once by mj_tables_upload): the SP kernel and, since round 5, the seats' discard / wait sets
 
 // Section timers of the step kernel (variant build -DMJ_STEP_PROF only: tools/build_variant.sh stepprof -DMJ_STEP_PROF;
 // MJ_STEP_PROF=1 in the environment makes mj_counters print them).  A section's clocks are read once per wavefront by
@@ -127,25 +130,22 @@ template <class LN> MJD void update_shanten(const LN& L, int s) {
     int v = calc_all(*L.T, load_hand(L, s), F1(len_div3, s));
     F1(shanten, s) = (int8_t)max(v, 0);
 }
-// The hands probed below are one tile away from the seat's hand, so they share the base rows and the six partial merges of
-// the untouched suits (mj_algo.h sh_others): a probe is one table gather + sh_final instead of a from-scratch calc_all
-// (four dependent gathers + two full merges) -- these two scans were 60 % of mj_k_step's wave time.
+// Round 5: both sets come from the table-id formulation of mj_sptab.h (the one mj_k_sp expands its state graphs with): the discards
+// of a 3n+2 hand that keep its shanten number and the draws that complete a tenpai hand are a handful of table walks plus mask
+// arithmetic, whatever the number of tile kinds.  Rounds 1-4 probed every held kind (<= 14) resp. all 34 kinds with one table gather
+// + merge each -- incremental (mj_algo.h sh_others), but still 60 % of mj_k_step's wave time, and a wavefront runs the 34-kind loop
+// whenever ONE of its 64 tables has a tenpai seat to refresh.
 template <class LN> MJDN void update_shanten_discards(const LN& L, int s) {  // 3n+2
     const Hand h = load_hand(L, s);
     const int ld3 = F1(len_div3, s), sh = F1(shanten, s);
-    const ShTab ST = sh_tab(*L.T);
-    const ShBase B = sh_base(ST, h);
-    const ShOthers O = sh_others(B, ld3);
-    u64 next = 0, keep = 0;
-    for (u64 m = h.nonzero_mask(); m; m &= m - 1) {  // each lane walks its own tile kinds: <= 14 rounds per wavefront
-        const int t = __ffsll((long long)m) - 1, st = sh_suit(t), c = h.get(t);
-        const int y = (int)((YAOKYUU_MASK >> t) & 1);
-        const u64 row = sh_load(ST, st, B.key_of(st) - sh_pow(t));
-        const int after = sh_finish(sh_final(O.of(st), row, ld3), ld3, B.pairs - (c == 2), B.kinds - (c == 1),
-                                    B.kpairs - (y && c == 2), B.kkinds - (y && c == 1));
-        if (after < sh) next |= BIT(t);
-        else if (after == sh) keep |= BIT(t);
-    }
+    const SpTabG TG = sp_tab_g(c_sp_tab);
+    // the hand with the drawn tile has the number sh14 (one less than before the draw, or the same); a discard leaves sh14 or sh14 + 1
+    const int sh14 = calc_all(*L.T, h, ld3);
+    const u64 held = h.nonzero_mask();
+    const u64 same = sh14 >= 0 ? sp_keep_of_hand(TG, *L.T, h, ld3, sh14) & held : 0ull;  // discards that leave sh14
+    const u64 up = held & ~same;                                                          // discards that leave sh14 + 1
+    const u64 next = (sh14 < sh ? same : 0ull) | (sh14 + 1 < sh ? up : 0ull);
+    const u64 keep = (sh14 == sh ? same : 0ull) | (sh14 + 1 == sh ? up : 0ull);
     F1(next_shanten, s) = next;
     F1(keep_shanten, s) = keep;
     F1(has_next_shanten, s) = next != 0;
@@ -157,20 +157,15 @@ template <class LN> MJDN void update_waits_and_furiten(const LN& L, int s) {  //
         const Hand h = load_hand(L, s);
         const int ld3 = F1(len_div3, s);
         const u64 disc = F1(discarded, s);
-        const ShTab ST = sh_tab(*L.T);
-        const ShBase B = sh_base(ST, h);
-        const ShOthers O = sh_others(B, ld3);
-        for (int t = 0; t < 34; t++) {
-            const int c = h.get(t);
+        const SpTabG TG = sp_tab_g(c_sp_tab);
+        // the tiles that complete the hand (a fifth copy is not a tile)
+        u64 win = 0;
+        if (calc_all(*L.T, h, ld3) == 0) win = sp_req_of_hand(TG, *L.T, h, ld3, 0);
+        for (u64 m = win; m; m &= m - 1) {
+            const int t = __ffsll((long long)m) - 1, c = h.get(t);
             if (c == 4) continue;
-            const int st = sh_suit(t), y = (int)((YAOKYUU_MASK >> t) & 1);
-            const u64 row = sh_load(ST, st, B.key_of(st) + sh_pow(t));
-            const int v = sh_finish(sh_final(O.of(st), row, ld3), ld3, B.pairs + (c == 1), B.kinds + (c == 0),
-                                    B.kpairs + (y && c == 1), B.kkinds + (y && c == 0));
-            if (v == -1) {
-                if ((disc >> t) & 1) pf |= PF_AT_FURITEN;
-                if (F1(pub_seen, t) + c < 4) waits |= BIT(t);  // tiles_seen = pub_seen + own hand
-            }
+            if ((disc >> t) & 1) pf |= PF_AT_FURITEN;
+            if (F1(pub_seen, t) + c < 4) waits |= BIT(t);  // tiles_seen = pub_seen + own hand
         }
     }
     F1(pflags, s) = pf;

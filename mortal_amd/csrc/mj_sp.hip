@@ -26,7 +26,7 @@
 #include "mj_rules.h"
 #include "mj_sptab.h"
 
-__constant__ SpTabDev c_sp_tab;  // table-id shanten (set once by mj_tables_upload)
+// (c_sp_tab, the table-id shanten block set once by mj_tables_upload, is declared in mj_rules.h: the step kernel uses it too)
 
 #ifndef SP_THREADS
 #define SP_THREADS 256          // threads per workgroup = per decision row in flight.  Measured in round 3 (-DSP_THREADS=64: one row per
