@@ -9,7 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r04_bench_v4.json")) as f:
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_v4.json")))  # the latest round's committed line
+    with open(files[-1]) as f:
         return json.load(f)
 
 
@@ -58,7 +61,7 @@ def test_committed_bench_line_has_the_contract_keys_and_consistent_arithmetic():
     assert abs(sum(k.values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.02  # the per-kernel split covers the cycle
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
-    for w in ("obs_v3_random", "obs_v4_random_no_preroll", "obs_v4_greedy", "brain_v4"):
+    for w in ("obs_v3_random", "obs_v4_random_no_preroll", "obs_v4_greedy", "cfg1_4096_v3", "cfg1_4096_v4", "brain_v4", "brain_v4_compiled"):
         assert d["workloads"][w]["value"] > 0
     assert d["workloads"]["brain_v4"]["env_share_of_cycle"] < 0.05  # BASELINE configs[2]: the net, not the environment, is the cycle
     assert d["steps"] >= 100 and d["config"]["start_stagger"] is True
@@ -74,7 +77,7 @@ def test_design_quotes_the_committed_numbers():
     assert f"`mj_k_sp` {d['kernel_ms_per_step']['mj_k_sp']:.1f} ms" in text
     assert "builder-run" in text  # the committed line is the builder's box; the numbers of record are the driver's
     # ... and the driver's last record is quoted next to it (DESIGN quoted the builder's best box only)
-    drv = [(r, p) for r, p in _driver_lines() if r == "r03"]
+    drv = [(r, p) for r, p in _driver_lines() if r == "r04"]
     if drv:
         p = drv[0][1]
         assert f"{p['value'] / 1e6:.3f} M env steps/s" in text and f"{p['ms_per_step']:.1f} ms/cycle" in text
