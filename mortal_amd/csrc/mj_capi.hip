@@ -153,6 +153,7 @@ struct MjPool {
     unsigned long long* sp_err = nullptr;
     int* enc_flag = nullptr;        // [1] an encoder op list overflowed (reported with the SP overflows)
     int* n_rows_host = nullptr;  // pinned
+    hipEvent_t ev_rows = nullptr;  // recorded right after the row counts' copy: mj_rows_count waits for it, not for the snapshot behind it
     unsigned long long* counters = nullptr;
     int* final_scores = nullptr;
     uint8_t* final_done = nullptr;
@@ -345,6 +346,7 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->rp_script); hipFree(P->rp_off); hipFree(P->rp_cursor); hipFree(P->rp_ev_index);
     hipFree(P->rp_kyoku); hipFree(P->rp_tracked); hipFree(P->rp_label); hipFree(P->rp_kan_label);
     if (P->n_rows_host) hipHostFree(P->n_rows_host);
+    if (P->ev_rows) hipEventDestroy(P->ev_rows);
     hipFree(P->counters);
     hipFree(P->final_scores);
     hipFree(P->final_done);
@@ -499,10 +501,14 @@ static int launch_rows(MjPool* P, hipStream_t s) {
     rp.max_rows[0] = rp.max_rows[1] = P->max_rows;
     hipLaunchKernelGGL(mj_k_scan, dim3(1), dim3(1024), 0, s, rp);
     hipLaunchKernelGGL(mj_k_assign, dim3(P->n_blocks), dim3(64), 0, s, rp);
+    // the row counts go to the host BEFORE the snapshot is queued (round 5): the host's read of them (mj_rows_count, one per cycle) and
+    // its launch of the encoder then run under the snapshot kernel's 0.1 ms instead of after it
+    HIP_OK(hipMemcpyAsync(P->n_rows_host, P->n_rows_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!P->ev_rows) HIP_OK(hipEventCreateWithFlags(&P->ev_rows, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(P->ev_rows, s));
     SnapParams snp = {P->blocks, P->snap, g_tables.gather, {0}};
     for (int c = 0; c <= SNAP_NCH; c++) snp.chunk_first[c] = g_tables.gather_chunk[c];
     hipLaunchKernelGGL(mj_k_snapshot, dim3(P->n_blocks), dim3(256), 0, s, snp);
-    HIP_OK(hipMemcpyAsync(P->n_rows_host, P->n_rows_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(hipGetLastError());
     P->cycles += 1;
     P->rows_valid = false;
@@ -618,7 +624,8 @@ int mj_table_query(MjPool* P, int table, int seat, int what, const int32_t* args
 
 int mj_rows_count(MjPool* P, int32_t out[2], void* stream) {
     if (!P) return fail("null pool");
-    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    if (P->ev_rows) HIP_OK(hipEventSynchronize(P->ev_rows));  // (the counts' copy; the snapshot queued behind it may still be running)
+    else HIP_OK(hipStreamSynchronize((hipStream_t)stream));
     P->last_rows[0] = P->n_rows_host[0];
     P->last_rows[1] = P->n_rows_host[1];
     P->rows_valid = true;

@@ -415,6 +415,8 @@ inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmuEvent{0}; return 0; }
+#define hipEventDisableTiming 2u
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new EmuEvent{0}; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t_ms = emu::now_ms(); return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
