@@ -143,7 +143,7 @@ struct SpParams {
     const uint32_t* rows;
     int n_rows;
     MjTablesDev tables;
-    float* obs;                // [n_rows][1012][34]; rows 889.. are zero on entry (written by mj_k_encode<4>)
+    float* obs;                // [n_rows][1012][34]; rows 0 .. 889 written by mj_k_encode<4>, rows 889 .. 1011 written here (sp_block_write)
     SpWork* work;              // [gridDim.x]
     int* queue;                // dynamic row queue (zeroed before launch); [0] head of the rows with a state graph, [1..8] class counts,
                                // [9..16] class cursors of the row sort, [SP_Q_TAIL] head of the queue's tail (rows without a graph)
@@ -342,6 +342,9 @@ static_assert(SP_CAP == 1 << 14, "sp_dk_pos returns 14 bits");
 // sectors, after re-reading the list).  The epoch counts this workgroup's graph rows (SpWork::epoch, kept across launches); when
 // it wraps, once in 2 M rows, the table is wiped.
 #define SP_EPOCH_MAX 0x1FFFFFu
+#ifndef SP_EPOCH_WRAP
+#define SP_EPOCH_WRAP SP_EPOCH_MAX  // the epoch after which the table is wiped (tests build with a small one: the wrap is 2 M rows away otherwise)
+#endif
 #define SP_TAG(dk, ep) ((dk) | ((u64)(ep) << 42) | (1ull << 63))
 MJD bool sp_tag_free(u64 t, u32 ep) { return (u32)((t >> 42) & SP_EPOCH_MAX) != ep; }  // (0: epoch 0, never a row's epoch)
 
@@ -2045,7 +2048,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             if (tid == 0) X.cc = nullptr;
 #endif
             // a new row = a new epoch of the hash tags
-            if (tag_epoch >= SP_EPOCH_MAX) {  // wrapped (once in 2 M rows): wipe the table, start over
+            if (tag_epoch >= SP_EPOCH_WRAP) {  // wrapped (once in 2 M rows): wipe the table, start over
                 for (int i = tid; i < SP_CAP; i += SP_THREADS) W->tag[i] = 0ull;
                 tag_epoch = 0;
                 __syncthreads();

@@ -214,3 +214,18 @@ def test_emu_staggered_start(oracle, emu):
         if c > S:
             assert k > 0
     assert pool.first_error()[0] == 0
+
+
+def test_emu_tag_epoch_wrap_in_a_variant_build():
+    """The hash tags of mj_k_sp carry the row's epoch instead of being cleared between rows (round 5); when a workgroup's epoch
+    counter wraps -- once in 2 M rows with a state graph, about half an hour of the benchmark's launches -- the table is wiped and the
+    count starts over.  No regular test gets near that, so a variant build of the emulator library with the wrap after THREE rows
+    (-DSP_EPOCH_WRAP=3) runs the lock-step test in which one workgroup takes every row (MJ_SP_GRID=1): dozens of wraps, SP rows f32
+    bit-exact against the oracle, no overflow.  A subprocess: the emulator library of this process is built without the flag."""
+    import subprocess
+
+    env = dict(os.environ, EMU_EXTRA_FLAGS="-DSP_EPOCH_WRAP=3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_emu_device_code.py"), "-x", "-q", "-k",
+                          "one_workgroup_takes_every_row", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
