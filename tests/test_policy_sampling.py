@@ -132,3 +132,38 @@ def test_device_engine_returns_meta_for_logs():
     assert act.dtype == torch.int32 and qv.shape == (32, 46) and greedy.dtype == torch.bool
     assert masks.gather(1, act.long().unsqueeze(1)).all()
     assert (act[greedy].long() == qv.argmax(-1)[greedy]).all() and not greedy.all() and greedy.any()
+
+
+def test_device_engine_compiled_path_pads_the_ragged_tail(monkeypatch):
+    """DeviceEngine(compile_net=True) (bench.py workloads.brain_v4_compiled): every chunk the compiled module sees has ONE shape
+    (max_batch rows; the batch's ragged tail is padded in a staging buffer, pad rows with every action legal) and the actions of
+    the real rows equal the eager engine's.  torch.compile itself is PyTorch's; here it is replaced by a shape-recording wrapper."""
+    import torch
+
+    from mortal_amd.policy import DeviceEngine, PolicyNet
+
+    seen = []
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, obs, mask):
+            seen.append(tuple(obs.shape))
+            return self.m(obs, mask)
+
+    monkeypatch.setattr(torch, "compile", lambda m, **kw: Recorder(m))
+    torch.manual_seed(3)
+    net = PolicyNet(version=4, conv_channels=16, num_blocks=2)
+    eager = DeviceEngine(net, 4, "cpu", enable_amp=False, max_batch=64)
+    comp = DeviceEngine(net, 4, "cpu", enable_amp=False, max_batch=64, compile_net=True)
+    obs = torch.rand(150, 1012, 34)
+    mask = torch.rand(150, 46) < 0.3
+    mask[:, 45] = True
+    a_e = eager.react_batch_device(obs, mask)
+    a_c, q_c, g_c = DeviceEngine(net, 4, "cpu", enable_amp=False, max_batch=64, compile_net=True, return_meta=True).react_batch_device(obs, mask)
+    assert torch.equal(a_e, comp.react_batch_device(obs, mask)) and torch.equal(a_e, a_c)
+    assert q_c.shape == (150, 46) and g_c.all()
+    assert seen and all(s == (64, 1012, 34) for s in seen), seen  # 64 + 64 + (22 padded to 64)
+    assert mask[torch.arange(150), a_e.long()].all()  # legal actions only
