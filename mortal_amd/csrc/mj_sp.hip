@@ -5,16 +5,21 @@
 // obs_repr.rs:564-692.  The reference is a memoised depth-first recursion (draw -> discard -> draw ...) over hand
 // states with order-sensitive f32 sums.  On the GPU the same values are produced LEVEL-SYNCHRONOUSLY, one decision row
 // per (persistent) workgroup at a time:
-//   set-up   : candidates and their required tiles as workgroup-parallel incremental shanten probes;
-//   expand   : for shanten level L = s .. 1, the 3n+1 states of level L in chunks of 8, one chunk per WAVEFRONT
+//   set-up   : candidates (the discards that keep the shanten number) and their required tiles from the table-id sets of
+//              mj_sptab.h, three dependent chains side by side on three wavefronts (sp_row_front);
+//   expand   : for shanten level L = s .. 1, the 3n+1 states of level L in chunks of 16, one chunk per WAVEFRONT
 //              (sp_expand_chunk: thread-per-task passes over the 64 lanes, no workgroup barrier inside a level) find their
 //              required draws t and the shanten-keeping discards d of h+t and insert the children h+t-d into a
-//              per-workgroup hash set keyed by an EXACT 42-bit state id (see "state id" below; claimed by atomicCAS);
+//              per-workgroup hash set keyed by an EXACT 42-bit state id (see "state id" below; look, then atomicCAS on a
+//              free slot; tags carry the row's epoch, nothing is cleared between rows);
 //              the ordered child list of every state (slot, discard order key, draw count) goes to a pool in HBM;
 //   evaluate : for L = 0 .. s: level 0 in three passes (probe / dense thread-per-item scoring / sum), then every level
 //              by teams of T - depth lanes (one lane per remaining draw, sp_eval_wave0 / sp_eval_wave) that reproduce
 //              draw_without_tegawari (calc.rs:447-561) with the reference's exact loop order (draw tiles ascending, aka
-//              after its plain tile; i, j ascending) and fold discards like discard_slow (calc.rs:563-637).
+//              after its plain tile; i, j ascending) and fold discards like discard_slow (calc.rs:563-637);
+//   write    : the whole SP block of the decision (123 rows; the encoder stops at row 890): sp_block_write.
+// Work area per workgroup (SpWork): by hash slot only the tags and the 256-byte value nodes; keys, headers and level lists
+// dense by list index (creation order), child lists / level-0 work items / their scores in append-only pools.
 // Memoisation in the reference is a pure cache, so evaluating every reachable state exactly once gives bit-identical
 // f32 results as long as each state's own accumulation order is kept — it is.  Compiled with -ffp-contract=off
 // (Rust never fuses a*b+c); the only fused operations are the explicit fma steps of sp_div, which reproduce the IEEE
@@ -34,7 +39,7 @@
                                 // at workgroup barriers), but the heaviest rows (~6 k states) then take ~23 ms on their single wavefront
                                 // and the launch lasts as long as they do: 39.5 vs 22.5 ms.  Four wavefronts per row it stays.
 #endif
-#define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~4.3k)
+#define SP_CAP 16384           // hash slots per workgroup (max observed states per decision ~6k)
 #define SP_T 17                // MAX_TSUMOS_LEFT (sp/mod.rs:40)
 #define SP_MAX_CAND 14
 #ifndef SP_NS
@@ -54,7 +59,7 @@
 #ifndef SP_CC_N
 #define SP_CC_N 2048            // entries of the per-workgroup child cache in LDS (0 = off): row epoch << 56 | state id << 14 | slot.
                                 // Measured (round 4, one box, mj_k_sp): none 20.01 ms, 512: 19.78, 1024: 19.73-19.77, 2048: 19.61 (16 KB: with the
-                                // rest 40.5 KB per workgroup, the last size that keeps four workgroups on a CU)
+                                // rest 40.8 KB per workgroup, the last size that keeps four workgroups on a CU)
 #endif
 #ifndef SP_TAIL_BATCH
 #define SP_TAIL_BATCH 4         // rows per pop in the tail of the queue (rows without a state graph, one row per wavefront)
@@ -397,9 +402,9 @@ MJD u64 sp_claim_tag(TagP tagp, u64 h, u64 seen) {  // claim a slot seen empty (
     __hip_atomic_compare_exchange_strong(tagp, &expected, h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return expected == seen ? 0ull : expected;
 }
-// hash-set insert of the state `base` + draw `tile` - discard `dt` (either may be -1) with id `dk`; returns the slot or -1 on
-// overflow.  `fresh`: this call created the slot and wrote the node's key — the state itself is built only then (an edge
-// finds its child already present 11 times in 12).
+// hash-set insert of the state `base` + draw `tile` - discard `dt` (either may be -1) with id `dk`: returns the slot or -1 on
+// overflow.  Only a call that creates the slot builds the state itself and writes its key record (sp_new_state; an edge finds its
+// child already present five times in six).
 MJD SpState sp_apply(SpState s, int tile, int dt) {
     if (tile >= 0) sp_deal(s, tile);
     if (dt >= 0) sp_discard(s, dt);
@@ -549,7 +554,7 @@ __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState
 // ---- Level 0 (tenpai states) is evaluated in three passes so that the expensive, divergent scoring of the winning
 // draws (get_score: agari decomposition + yaku + fu) runs with every lane busy:
 //   probe : sp_l0_probe_chunk — which draws win (34 shanten probes per state) -> draw entries, one work item per entry
-//   score : THREAD per item, dense across the workgroup                  -> 4 scores per entry in the node (sc[])
+//   score : THREAD per item, dense across the workgroup                  -> 4 scores per work item (SpWork::l0sc)
 //   sum   : team per state — sp_eval_wave0 accumulates the scores in the reference's order
 __device__ SP_ATTR_L0S void sp_l0_score(const MjTablesDev& Tb, SpWork* W, const SpCtx* X, u32 item, int item_idx) {
     SP_ASSUME_LDS(X);
@@ -737,7 +742,7 @@ __device__ __forceinline__ void sp_chunk_probe(SP_HBM SpWork* Wg, SpCtx* X, SpCh
 }
 
 // Level 0: which draws win and one scoring work item per draw entry, in the reference's order (plain tile if a non-red
-// copy is left, then the red five); the node gets the entry counts, their number and the not_tsumo row.
+// copy is left, then the red five); the state's header gets the entry counts, their number and the not_tsumo row.
 __device__ SP_ATTR_L0P void sp_l0_probe_chunk(SpWork* W, SpCtx* X, SpChunk* C, int first, int n) {
     SP_ASSUME_LDS(X);
     SP_ASSUME_LDS(C);
@@ -1044,8 +1049,8 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
             u64 oa = 1ull, ob = 1ull;
             const int ka = cc_look(A), kb = cc_look(B);
             // five edges in six find their child already there: LOOK before claiming (a plain load; within a row a tag only ever goes
-            // from 0 to its final value, and the end-of-row reset is a store of this CU, so a stale value can only be a 0 — which
-            // costs the atomic that would have been issued anyway).  mj_k_sp -3.0 % (round 4, same box): 144 M L2 atomics per launch
+            // from free -- zero or another row's epoch -- to its final value, so a stale value can only look free, which costs the
+            // atomic that would have been issued anyway).  mj_k_sp -3.0 % (round 4, same box): 144 M L2 atomics per launch
             // become ~25 M.
             if (A.on && ka < 0) oa = Wg->tag[A.pos];
             if (B.on && kb < 0) ob = Wg->tag[B.pos];
