@@ -56,6 +56,25 @@ struct DealScratch {
 #define MJ_ASSUME_LDS(p) ((void)0)  // host pass of the single-source compile: the builtin only exists on the device
 #endif
 
+// floor(2^32 / n) for the divisors of the rand-0.9.1 shuffle (n = 1 .. 136): chunk / n as one multiply-high plus at most two correction
+// steps instead of the ~40-instruction u32 division -- the shuffle is a serial chain of ONE lane, and that lane is mj_k_step's critical path.
+struct DealMagic {
+    u32 m[137];
+    constexpr DealMagic() : m() {
+        m[0] = 0;
+        for (u32 n = 1; n <= 136; n++) m[n] = (u32)(0x100000000ull / n);
+    }
+};
+__device__ static const DealMagic DEAL_MAGIC = DealMagic();
+MJD void deal_divmod(u32 x, u32 n, u32& q, u32& r) {  // exact: q = x / n, r = x % n for 1 <= n <= 136
+    q = (u32)(((u64)x * DEAL_MAGIC.m[n]) >> 32);
+    r = x - q * n;
+    while (r >= n) {  // the estimate is low by at most 2
+        q += 1;
+        r -= n;
+    }
+}
+
 struct ChaCha12Dev {
     u32 key[8];
     u32* buf;  // -> DealScratch::rng[0][lane], stride DEAL_LANES
@@ -167,8 +186,9 @@ MJDN void deal_wall(u8* wall, int stride, DealScratch* S, int lane, u64 nonce, u
             u32 result;
             if (next_rem == 0) result = chunk;
             else {
-                result = chunk % next_n;
-                chunk /= next_n;
+                u32 q;
+                deal_divmod(chunk, next_n, q, result);
+                chunk = q;
             }
             chunk_remaining = next_rem;
             n = next_n;

@@ -573,7 +573,35 @@ template <class LN> MJD void ev_reach_accepted(const LN& L, int actor) {  // upd
 // ---------------------------------------------------------------- kyoku start (board.rs:99-136,206-239; update.rs:125-217)
 // kyoku_init: everything a StartKyoku event does to the table, given wall[0..52) (haipai) and wall[60] (first dora
 // indicator); shared by the arena (deal from the seed) and the log replay (tiles from the logged event).
-template <class LN> MJDN void kyoku_init(const LN& L) {
+// `lw`: the freshly dealt wall as this lane's column of the wavefront's DealScratch (stride DEAL_LANES), or NULL: the wall is read from the pool.
+// The four hands, their shanten numbers and the dora marker are taken BEFORE the ~150 field stores below: a load issued after them waits for
+// every one (vmcnt counts stores), and start_kyoku runs on ONE lane of a wavefront that is mj_k_step's critical path.
+template <class LN> MJDN void kyoku_init(const LN& L, const u8* lw = nullptr) {
+    auto wall_at = [&](int i) -> int {
+        if (lw) {
+            MJ_ASSUME_LDS(lw);  // (only on this branch: the pointer may be NULL)
+            return (int)lw[i * DEAL_LANES];
+        }
+        return (int)F1(wall, i);
+    };
+    const int marker = wall_at(56 + 4);
+    Hand hh[4];
+    u8 ak[4];
+    int sv[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        Hand h = {0, 0};
+        u8 akas = 0;
+        for (int i = 0; i < 13; i++) {
+            const int t = wall_at(s * 13 + i);
+            if (t >= T_UNK) continue;  // hidden hand of a single-perspective log
+            h.inc(deaka(t));
+            if (is_aka(t)) akas |= 1 << (t - T_5MR);
+        }
+        hh[s] = h;
+        ak[s] = akas;
+        sv[s] = calc_all(*L.T, h, 4);  // (update_shanten of the hand just built: len_div3 = 4)
+    }
     F(yama_n) = 70;
     F(rinshan_n) = 4;
     F(dora_n) = 5;
@@ -625,25 +653,22 @@ template <class LN> MJDN void kyoku_init(const LN& L) {
     F1(inter_cp, 0) = 0;
 
     // StartKyoku: first dora indicator, then 13 tiles per seat
-    int marker = F1(wall, 56 + 4);
     F(dora_n) = 4;
     F1(dora_ind, 0) = (u8)marker;
     F(n_dora_ind) = 1;
-    pub_witness(L, marker);
+    F1(pub_seen, deaka(marker)) = 1;  // pub_witness of the marker on the counters zeroed above
+    if (is_aka(marker)) F(pub_aka_seen) = (u8)(1 << (marker - T_5MR));
+#pragma unroll
     for (int s = 0; s < 4; s++) {
-        Hand h = {0, 0};
-        u8 akas = 0;
-        for (int i = 0; i < 13; i++) {
-            int t = F1(wall, s * 13 + i);
-            if (t >= T_UNK) continue;  // hidden hand of a single-perspective log
-            h.inc(deaka(t));
-            if (is_aka(t)) akas |= 1 << (t - T_5MR);
-        }
-        store_hand(L, s, h);
-        F1(akas_in_hand, s) = akas;
-        update_shanten(L, s);
-        update_waits_and_furiten(L, s);
+        store_hand(L, s, hh[s]);
+        F1(akas_in_hand, s) = ak[s];
+        F1(shanten, s) = (int8_t)max(sv[s], 0);
     }
+    // waits of a hand dealt tenpai (rare); every other seat keeps the zeroed set and its flags (update_waits_and_furiten would only
+    // clear a furiten flag that is not set)
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        if (sv[s] <= 0) update_waits_and_furiten(L, s);
 }
 template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
     static_assert(MJ_LANES == DEAL_LANES, "one DealScratch column per pool lane");
@@ -652,12 +677,19 @@ template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
     deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, L.deal, L.l, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
     SPROF_ADD(19, t_d);
     SPROF_T(t_i);
-    kyoku_init(L);
+    const u8* const lw = L.deal ? &L.deal->wall[0][L.l] : nullptr;  // the wall just dealt, still in the wavefront's LDS scratch
+    kyoku_init(L, lw);
     SPROF_ADD(20, t_i);
-    const int marker = F1(wall, 56 + 4);
-    // first tsumo of the oya
+    int marker, tile;  // dora marker, the oya's first tsumo
+    if (lw) {
+        MJ_ASSUME_LDS(lw);
+        marker = (int)lw[(56 + 4) * DEAL_LANES];
+        tile = (int)lw[(66 + 69) * DEAL_LANES];
+    } else {
+        marker = (int)F1(wall, 56 + 4);
+        tile = (int)F1(wall, 66 + 69);
+    }
     const int oya = kyoku & 3;
-    int tile = F1(wall, 66 + 69);
     F(yama_n) = 69;
     F(tiles_left) = 69;
     F(flags) |= TF_HAIPAI_DONE;
