@@ -113,7 +113,10 @@ int mj_table_apply_event(MjPool* pool, int table, const uint64_t* words_host, in
 int mj_table_mark_row(MjPool* pool, int table, int seat, int at_kan_select, void* stream);
 int mj_table_query(MjPool* pool, int table, int seat, int what, const int32_t* args8_host, int32_t* out8_host, void* stream);
 
-/* Number of policy rows per agent produced by the last mj_step (synchronises `stream`). */
+/* Number of policy rows per agent produced by the last mj_step.  Waits for the row counts of THAT step (recorded on the stream the
+ * step was launched on; `stream` is only used before any step has run) -- it does NOT drain the stream: the snapshot kernel queued
+ * behind the counts may still be running when the call returns.  mj_encode / mj_encode_oracle order themselves behind it: on the
+ * step's stream by stream order, on any other stream by waiting for the snapshot's event. */
 int mj_rows_count(MjPool* pool, int32_t n_rows_out[2], void* stream);
 /* Device array of row descriptors of agent a: table | seat << 28 | is_kan_select << 31. */
 const uint32_t* mj_rows_dev(MjPool* pool, int agent);
@@ -170,6 +173,8 @@ int mj_obs_rows(int version);
  *        followed by Agari::point(arg0 = is_oya)              -> p0 = ron, p1 = tsumo_ko, p2 = tsumo_oya
  *   op 4 check_ankan_after_riichi(tehai incl. the drawn tile, len_div3, arg0 = tile), non-strict -> r0 (algo/agari.rs:854-912)
  *   op 5 Point::calc(arg0 = is_oya, arg1 = fu, arg2 = han)    -> p0..p2                   (algo/point.rs:13-112)
+ *   op 6 the wall shuffle's u32 division (x = tehai[0..3] little endian, n = arg0 in 1..136) -> r0 = x / n, r1 = x % n
+ *        (the `chunk % next_n`, `chunk /= next_n` steps of rand 0.9.1's IncreasingUniform behind arena/board.rs:107-109)
  * Queries and results are host arrays. */
 typedef struct MjAlgoQuery {
     uint8_t tehai[34];                                  /* tile counts, red fives counted as fives (34-tile form) */

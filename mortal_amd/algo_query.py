@@ -16,7 +16,7 @@ QUERY_DTYPE = np.dtype([
 RESULT_DTYPE = np.dtype([(k, np.int32) for k in ("r0", "r1", "r2", "r3", "p0", "p1", "p2", "p3")])
 assert QUERY_DTYPE.itemsize == 72 and RESULT_DTYPE.itemsize == 32
 
-OP_SHANTEN, OP_SEARCH_YAKUS, OP_HAS_YAKU, OP_AGARI, OP_ANKAN_AFTER_RIICHI, OP_POINT = range(6)
+OP_SHANTEN, OP_SEARCH_YAKUS, OP_HAS_YAKU, OP_AGARI, OP_ANKAN_AFTER_RIICHI, OP_POINT, OP_DEAL_DIVMOD = range(7)
 
 
 def queries(n):

@@ -59,6 +59,14 @@ __global__ __launch_bounds__(64) void mj_k_algo_query(const MjAlgoQuery* q, int 
         }
         case 4: R.r0 = check_ankan_after_riichi(c_mj_tables, h, Q.len_div3, Q.arg0); break;
         case 5: put_point(point_calc(Q.arg0 != 0, Q.arg1, Q.arg2)); break;
+        case 6: {  // the shuffle's division by multiply-high (mj_deal.h: deal_divmod), x = tehai[0..3] little endian, n = arg0
+            const u32 x = (u32)Q.tehai[0] | ((u32)Q.tehai[1] << 8) | ((u32)Q.tehai[2] << 16) | ((u32)Q.tehai[3] << 24);
+            u32 qq = 0, rr = 0;
+            if (Q.arg0 >= 1 && Q.arg0 <= 136) deal_divmod(x, (u32)Q.arg0, qq, rr);
+            R.r0 = (int32_t)qq;
+            R.r1 = (int32_t)rr;
+            break;
+        }
         default: R.r3 = -1; break;
     }
     out[i] = R;
@@ -154,6 +162,8 @@ struct MjPool {
     int* enc_flag = nullptr;        // [1] an encoder op list overflowed (reported with the SP overflows)
     int* n_rows_host = nullptr;  // pinned
     hipEvent_t ev_rows = nullptr;  // recorded right after the row counts' copy: mj_rows_count waits for it, not for the snapshot behind it
+    hipEvent_t ev_snap = nullptr;  // recorded after mj_k_snapshot: a reader of P->snap on ANOTHER stream than the step's waits for it
+    hipStream_t step_stream = nullptr;  // the stream the last mj_step / mj_table_* launched on
     unsigned long long* counters = nullptr;
     int* final_scores = nullptr;
     uint8_t* final_done = nullptr;
@@ -347,6 +357,7 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->rp_kyoku); hipFree(P->rp_tracked); hipFree(P->rp_label); hipFree(P->rp_kan_label);
     if (P->n_rows_host) hipHostFree(P->n_rows_host);
     if (P->ev_rows) hipEventDestroy(P->ev_rows);
+    if (P->ev_snap) hipEventDestroy(P->ev_snap);
     hipFree(P->counters);
     hipFree(P->final_scores);
     hipFree(P->final_done);
@@ -446,6 +457,12 @@ int mj_pool_set_start_stagger(MjPool* P, uint32_t cycles, void* stream) {
 }
 
 static int launch_rows(MjPool* P, hipStream_t s);
+// mj_rows_count returns as soon as the row counts are on the host; mj_k_snapshot, queued behind their copy, may still be running.  A
+// reader of the snapshot records on the SAME stream is ordered behind it by the stream; one on another stream waits for ev_snap.
+static int wait_snapshot(MjPool* P, hipStream_t s) {
+    if (P->ev_snap && s != P->step_stream) HIP_OK(hipStreamWaitEvent(s, P->ev_snap, 0));
+    return 0;
+}
 int mj_step(MjPool* P, const int32_t* a0, const int32_t* a1, void* stream) {
     return mj_step_q(P, a0, a1, nullptr, nullptr, stream);
 }
@@ -509,6 +526,9 @@ static int launch_rows(MjPool* P, hipStream_t s) {
     SnapParams snp = {P->blocks, P->snap, g_tables.gather, {0}};
     for (int c = 0; c <= SNAP_NCH; c++) snp.chunk_first[c] = g_tables.gather_chunk[c];
     hipLaunchKernelGGL(mj_k_snapshot, dim3(P->n_blocks), dim3(256), 0, s, snp);
+    if (!P->ev_snap) HIP_OK(hipEventCreateWithFlags(&P->ev_snap, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(P->ev_snap, s));
+    P->step_stream = s;
     HIP_OK(hipGetLastError());
     P->cycles += 1;
     P->rows_valid = false;
@@ -663,6 +683,7 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
     ep.err_flag = P->enc_flag;
     size_t lds = enc_lds_bytes(ep.version);
     hipStream_t s = (hipStream_t)stream;
+    if (wait_snapshot(P, s)) return -1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (P->timing) {
         HIP_OK(hipEventCreate(&e0));
@@ -702,7 +723,10 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
                 if (P->sp_grid > P->max_rows) P->sp_grid = P->max_rows;  // never more rows than that in a launch (small pools: small work area)
                 if (const char* g = getenv("MJ_SP_GRID")) P->sp_grid = std::max(1, std::min(P->sp_grid, atoi(g)));  // tests: few workgroups, many rows each (the row-to-row paths)
                 HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
-                for (int g = 0; g < P->sp_grid; g++) HIP_OK(hipMemsetAsync(P->sp_work[g].tag, 0, sizeof(P->sp_work[g].tag), s));  // empty hash sets
+                for (int g = 0; g < P->sp_grid; g++) {
+                    HIP_OK(hipMemsetAsync(P->sp_work[g].tag, 0, sizeof(P->sp_work[g].tag), s));  // empty hash sets ...
+                    HIP_OK(hipMemsetAsync(&P->sp_work[g].epoch, 0, sizeof(P->sp_work[g].epoch) + sizeof(P->sp_work[g].pad_), s));  // ... at epoch 0
+                }
                 HIP_OK(hipMalloc(&P->sp_queue, SP_Q_WORDS * sizeof(int)));
             }
             HIP_OK(hipMemsetAsync(P->sp_queue, 0, SP_Q_WORDS * sizeof(int), s));
@@ -752,6 +776,7 @@ int mj_encode_oracle(MjPool* P, int agent, float* out, void* stream) {
     ep.all_yama = P->rp_active ? 1 : 0;
     size_t lds = enc_oracle_lds_bytes(ep.version);
     hipStream_t s = (hipStream_t)stream;
+    if (wait_snapshot(P, s)) return -1;
     if (ep.version == 1) hipLaunchKernelGGL(mj_k_encode_oracle<true>, dim3(n), dim3(ENC_THREADS), lds, s, ep);
     else hipLaunchKernelGGL(mj_k_encode_oracle<false>, dim3(n), dim3(ENC_THREADS), lds, s, ep);
     HIP_OK(hipGetLastError());

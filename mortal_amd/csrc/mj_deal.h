@@ -62,17 +62,20 @@ struct DealMagic {
     u32 m[137];
     constexpr DealMagic() : m() {
         m[0] = 0;
-        for (u32 n = 1; n <= 136; n++) m[n] = (u32)(0x100000000ull / n);
+        m[1] = 0xFFFFFFFFu;  // (2^32 / 1 does not fit: with 2^32 - 1 the estimate of x / 1 is x - 1 for x > 0, one correction step)
+        for (u32 n = 2; n <= 136; n++) m[n] = (u32)(0x100000000ull / n);
     }
 };
 __device__ static const DealMagic DEAL_MAGIC = DealMagic();
 MJD void deal_divmod(u32 x, u32 n, u32& q, u32& r) {  // exact: q = x / n, r = x % n for 1 <= n <= 136
     q = (u32)(((u64)x * DEAL_MAGIC.m[n]) >> 32);
     r = x - q * n;
-    while (r >= n) {  // the estimate is low by at most 2
-        q += 1;
-        r -= n;
-    }
+#pragma unroll
+    for (int k = 0; k < 2; k++)  // the estimate is low by at most 2 (floor(2^32 / n) * n > 2^32 - n, x < 2^32): a bounded correction
+        if (r >= n) {
+            q += 1;
+            r -= n;
+        }
 }
 
 struct ChaCha12Dev {

@@ -563,6 +563,12 @@ int mjo_arena_result(void* h, int game, int* scores4, int* done) {
     *done = a->done[game];
     return 0;
 }
+// The done flag of every slot at once (the lock-step harness of a big pool scans for finished slots every cycle).
+int mjo_arena_done_flags(void* h, unsigned char* out) {
+    Arena* a = (Arena*)h;
+    for (size_t g = 0; g < a->done.size(); g++) out[g] = (unsigned char)(a->done[g] != 0);
+    return (int)a->done.size();
+}
 // Live view of one game for lock-step comparison: out int32[16] =
 //  [ended, kyoku, honba, kyotaku, scores[4], kyoku_started, tiles_left, oya, in_renchan, 0...]
 int mjo_arena_game_view(void* h, int game, int* out) {

@@ -420,6 +420,7 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new Em
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t_ms = emu::now_ms(); return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }  // (the emulator runs every launch to completion)
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return 0; }
 template <class F> inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }

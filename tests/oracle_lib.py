@@ -69,6 +69,7 @@ def lib():
     L.mjo_arena_guard_hits.restype = C.c_long
     L.mjo_arena_guard_hits.argtypes = [C.c_void_p]
     L.mjo_arena_result.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.mjo_arena_done_flags.argtypes = [C.c_void_p, C.c_void_p]
     L.mjo_arena_game_view.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.mjo_arena_player_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.mjo_arena_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -493,6 +494,12 @@ class Arena:
     @property
     def steps(self):
         return lib().mjo_arena_steps(self.h)
+
+    def done_flags(self):
+        """done flag of every slot (one call; `result(g)` per slot costs microseconds each on a 16 k-table pool, every cycle)."""
+        out = np.zeros(self.n, dtype=np.uint8)
+        lib().mjo_arena_done_flags(self.h, ptr(out))
+        return out
 
     def result(self, g):
         s = np.zeros(4, dtype=np.int32)

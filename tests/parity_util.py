@@ -289,7 +289,11 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
             # (a slot can only have finished if fewer games are live than have entered play: big pools skip the per-slot scan on the
             # many cycles in which nobody finishes)
             started = n_tables if starts is None else int((starts_np <= cycle).sum())
-            for g in (range(n_tables) if arena.n_live < started else ()):
+            fin = ()
+            if arena.n_live < started:
+                dflags = arena.done_flags() != 0
+                fin = np.flatnonzero(dflags if starts is None else dflags & (starts_np <= cycle)).tolist()
+            for g in fin:
                 sc, dn = arena.result(g)
                 if dn and (starts is None or starts[g] <= cycle):  # a parked slot is "finished" without having played
                     gen_scores[(g, gen[g])] = sc.copy()

@@ -164,6 +164,8 @@ def test_emu_reference_state_scenarios_and_bot(oracle, emu):
     try:
         for name in G.EVENT_DRIVEN:
             G.test_reference_state_scenario_on_device(name)
+        G.test_reference_waits_vectors_on_device()
+        G.test_reference_can_chi_vectors_on_device()
         G.test_device_player_state_obs_matches_oracle(oracle)
         G.test_device_player_state_validate_reaction(oracle)
         G.test_bot_replays_a_game_like_the_oracle_agent(oracle)
@@ -182,6 +184,7 @@ def test_emu_reference_kats_and_generated_hands(oracle, emu):
     st = K.check_reference_kats(oracle, lib)
     assert st["shanten"] == 19 and st["agari"] == 25 and st["open"] >= 5
     assert K.check_point_sweep(lib) > 250
+    assert K.check_deal_divmod(lib, per_n=100) > 20_000
     st = K.check_generated_hands(oracle, 4000, 7, lib)
     assert st["open"] > 1000 and st["kans"] > 500 and st["yakuman"] > 30 and st["none"] > 30, st
 

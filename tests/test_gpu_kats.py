@@ -213,8 +213,32 @@ def check_generated_hands(oracle, n, seed, lib=None):
     return stats
 
 
+def check_deal_divmod(lib=None, per_n=600, seed=5):
+    """mj_deal.h deal_divmod (the rand-0.9.1 shuffle's `chunk % n`, `chunk / n` as multiply-high + bounded correction) == integer
+    division for EVERY divisor 1..136: edge values (0, n - 1, n, multiples of n and their neighbours, 2^32 - 1) and random u32."""
+    rng = np.random.default_rng(seed)
+    xs, ns = [], []
+    for n in range(1, 137):
+        edge = [0, 1, n - 1, n, n + 1, 2 ** 32 - 1, 2 ** 32 - 2, (2 ** 32 - 1) // n * n, (2 ** 32 - 1) // n * n - 1, 2 ** 31, 2 ** 31 - 1]
+        mult = rng.integers(0, 2 ** 32 // n, size=40, dtype=np.uint64) * np.uint64(n)
+        x = np.concatenate([np.array(edge, dtype=np.uint64), mult, mult + np.uint64(n - 1),
+                            rng.integers(0, 2 ** 32, size=per_n, dtype=np.uint64)]) & np.uint64(0xFFFFFFFF)
+        xs.append(x)
+        ns.append(np.full(len(x), n, dtype=np.uint64))
+    x, n = np.concatenate(xs), np.concatenate(ns)
+    q = AQ.queries(len(x))
+    q["op"] = AQ.OP_DEAL_DIVMOD
+    q["arg0"] = n.astype(np.uint8)
+    q["tehai"][:, :4] = x.astype("<u4").view(np.uint8).reshape(-1, 4)
+    r = AQ.run(q, lib)
+    assert np.array_equal(r["r0"].astype(np.uint32).astype(np.uint64), x // n), "deal_divmod quotient"
+    assert np.array_equal(r["r1"].astype(np.uint32).astype(np.uint64), x % n), "deal_divmod remainder"
+    return len(x)
+
+
 @pytest.mark.gpu
 def test_reference_kats_on_device(oracle):
+    assert check_deal_divmod() > 80_000
     st = check_reference_kats(oracle)
     assert st["shanten"] == 19 and st["agari"] == 25 and st["ankan"] >= 3 and st["open"] >= 5
     assert check_point_sweep() > 250

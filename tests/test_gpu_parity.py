@@ -164,6 +164,24 @@ def test_full_size_pool_v4_sp_staggered_against_the_oracle(oracle):
     assert st["counters"]["sp_overflow"] == 0 and st["counters"]["steps"] == st["oracle_steps"]
 
 
+def test_benchmark_protocol_16384_tables_v4_sp_late_game_against_the_oracle(oracle):
+    """The benchmark's REAL protocol at a size where the persistent workgroups of mj_k_sp chain many rows (the 65,536-table
+    comparison staggers over 200 cycles and stops at cycle 240, so it only ever sees tables in the first kyoku of their first hanchan;
+    the late-game mix had been oracle-checked at 48 tables): 16,384 tables, obs v4, uniform-random legal policy, refill, first starts
+    staggered over 3,072 cycles exactly like `bench.py` -- through that pre-roll the oracle follows with masks and row lists only --
+    then 64 more cycles in which the row queue mixes East and South rounds, all-last, riichi-heavy late turns and second-generation
+    (refilled) tables: row lists and 46-wide masks of every decision of all 3,136 cycles, the WHOLE v4 obs including rows 889..1011
+    (f32 bit for bit, NaN-poisoned buffers) on two 4,096-row slices of two cycles after the pre-roll, the step counter, no SP overflow,
+    and tables in their second hanchan present.  Reference: agent/mortal.rs:252-287, state/obs_repr.rs:564-624, arena/game.rs:286-304."""
+    pre = 3072
+    st = parity_util.run_lockstep(oracle, 16384, version=4, max_cycles=pre + 64, obs_cycles={pre + 21, pre + 63}, sp_rows_checked=True,
+                                  refill=16384 // 4, stagger=pre, min_games=99, deal_algo=1, threads=16, obs_slice=4096, obs_slice_max=2,
+                                  verbose=True)
+    assert st["cycles"] == pre + 64 and st["obs_checked"] >= 4 * 4096
+    assert st["generations"][1] >= 2  # (generation 1 = the staggered first start) some slots are in their second played hanchan
+    assert st["counters"]["sp_overflow"] == 0 and st["counters"]["steps"] == st["oracle_steps"]
+
+
 @pytest.mark.parametrize("version,cycles", [(3, 48), (4, 14)])
 def test_full_size_pool_is_size_independent(version, cycles):
     """BASELINE's 65,536-table configuration: tables are independent, so the first 1,024 tables of the big pool must

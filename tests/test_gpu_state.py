@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 TILE_NAMES34 = [f"{n}{s}" for s in "mps" for n in range(1, 10)] + ["E", "S", "W", "N", "P", "F", "C"]
 
-# scenarios that only poke private fields of the Rust struct (no event stream) have no counterpart on the public surface
+# `waits` and `can_chi` (state/test.rs:71-222) poke private fields of the Rust struct (tehai, then one private method); on the public
+# surface the same hands are reached through an event stream: test_reference_waits_vectors_on_device / _can_chi_ below
 EVENT_DRIVEN = sorted(n for n in T.SCEN if n not in ("waits", "can_chi"))
 
 
@@ -82,6 +83,87 @@ def test_reference_state_scenario_on_device(name):
     for s in sc["steps"]:
         r.step(s)
     assert r.n_asserts > 0, f"{name} (test.rs:{sc['line']}) evaluated no assertions"
+
+
+def _hand_tiles(text):
+    h = T.O.hand(text)
+    return [TILE_NAMES34[t] for t in range(34) for _ in range(int(h[t]))]
+
+
+def _start_kyoku(tehai0, oya, dora_marker):
+    return {"type": "start_kyoku", "bakaze": "E", "dora_marker": dora_marker, "kyoku": oya + 1, "honba": 0, "kyotaku": 0, "oya": oya,
+            "scores": [25000] * 4, "tehais": [tehai0] + [["?"] * 13] * 3}
+
+
+def _scenario_vectors(name):
+    """(hand text, [(call argument, assertion text), ...]) groups of the two private-field scenarios of the golden file."""
+    groups = []
+    for s in T.SCEN[name]["steps"]:
+        if "set_tehai" in s:
+            groups.append((s["set_tehai"], []))
+        elif "call" in s:
+            groups[-1][1].append([s.get("arg"), []])
+        elif "assert" in s:
+            groups[-1][1][-1][1].append(s["assert"])
+    return groups
+
+
+def test_reference_waits_vectors_on_device():
+    """state/test.rs:71-102 (`waits`): the reference sets `tehai` and calls update_waits_and_furiten(); here seat 0 is DEALT the
+    hand (start_kyoku runs update_shanten + update_waits_and_furiten, update.rs:212-213; the dora marker is a tile outside both
+    hands' waits) and the device's waits are read back."""
+    groups = _scenario_vectors("waits")
+    assert len(groups) == 2
+    for text, calls in groups:
+        ps = DevicePS(0)
+        ps.update(_start_kyoku(_hand_tiles(text), 1, "1m"))
+        r = DeviceRunner()
+        r.vars["ps"] = ps
+        for _, asserts in calls:
+            for a in asserts:
+                r.eval(a)
+        assert r.n_asserts == 1 and ps.snapshot()["shanten"] == 0
+
+
+def test_reference_can_chi_vectors_on_device():
+    """state/test.rs:104-222 (`can_chi`): the reference sets 7- / 10- / 4-tile hands and calls set_can_chi_from_tile(tile).  On the
+    device seat 0 reaches the same concealed hand by PLAYING: it is dealt the hand plus honour pairs and spare tiles, pons the pairs
+    from seat 1's discards (one pon per missing meld) discarding the spares, and then its kamicha (seat 3) discards the probed tile —
+    the `dahai` handler runs set_can_chi_from_tile (update.rs:404-416).  One vector is physically impossible (a fifth 1m against
+    1111234m) and is the only one left out; every other (hand, tile) pair of the reference's test is checked, 10 of 11."""
+    groups = _scenario_vectors("can_chi")
+    honours = ["E", "S", "W"]
+    spare = ["P", "F", "C"]
+    done = skipped = 0
+    for text, calls in groups:
+        hand = _hand_tiles(text)
+        n_melds = (13 - len(hand)) // 3
+        assert len(hand) + 3 * n_melds == 13
+        tehai0 = hand + [h for h in honours[:n_melds] for _ in range(2)] + spare[:n_melds]
+        for tile, asserts in calls:
+            if hand.count(tile) == 4:
+                skipped += 1
+                continue
+            ps = DevicePS(0)
+            ps.update(_start_kyoku(tehai0, 1, "9s" if tile != "9s" else "1m"))
+            for k in range(n_melds):  # seat 1 draws and discards an honour seat 0 holds a pair of: pon, discard a spare
+                ps.update({"type": "tsumo", "actor": 1, "pai": "?"})
+                c = ps.update({"type": "dahai", "actor": 1, "pai": honours[k], "tsumogiri": True})
+                assert c["can_pon"]
+                ps.update({"type": "pon", "actor": 0, "target": 1, "pai": honours[k], "consumed": [honours[k]] * 2})
+                ps.update({"type": "dahai", "actor": 0, "pai": spare[k], "tsumogiri": False})
+            for actor in (1, 2):
+                ps.update({"type": "tsumo", "actor": actor, "pai": "?"})
+                ps.update({"type": "dahai", "actor": actor, "pai": "N", "tsumogiri": True})
+            ps.update({"type": "tsumo", "actor": 3, "pai": "?"})
+            ps.update({"type": "dahai", "actor": 3, "pai": tile, "tsumogiri": True})
+            r = DeviceRunner()
+            r.vars["ps"] = ps
+            for a in asserts:
+                r.eval(a)
+            assert r.n_asserts == 3, asserts
+            done += 1
+    assert done == 10 and skipped == 1, (done, skipped)
 
 
 def test_device_player_state_obs_matches_oracle(oracle):
