@@ -475,7 +475,7 @@ def main():
         from mortal_amd.policy import DeviceEngine, PolicyNet
 
         torch.manual_seed(0)
-        engine = DeviceEngine(PolicyNet(version=args.version if args.version >= 2 else 2), args.version, dev, enable_amp=True)
+        engine = DeviceEngine(PolicyNet(version=args.version if args.version >= 2 else 2), args.version, dev, enable_amp=True, max_batch=8192)  # compile_net="auto": compiled on a GPU
 
     def barrier():
         if world > 1:
@@ -515,15 +515,19 @@ def main():
             # BASELINE configs[1] (C2): 4,096 tables, random-action policy, env-step kernels (+ encode of every decision)
             "cfg1_4096_v3": _brief(_measure(TablePool, 4096, g0, world, dev, 3, args.preroll, "random", 20 * k, 20, bufs)),
             "cfg1_4096_v4": _brief(_measure(TablePool, 4096, g0, world, dev, 4, args.preroll, "random", 6 * k, 10, bufs)),
+            # the per-GPU share of BASELINE C4's strong-scaling point (65,536 tables over 8 GPUs) and of C5 (131,072 over 8)
+            "cfg_8192_v4": _brief(_measure(TablePool, 8192, g0, world, dev, 4, args.preroll, "random", 6 * k, 10, bufs)),
+            "cfg_16384_v4": _brief(_measure(TablePool, 16384, g0, world, dev, 4, args.preroll, "random", 3 * k, 10, bufs)),
             "brain_v4": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs,
                                         other_ms=(dt * 1e3 - enc_ms - sp_ms) / args.steps),
             "brain_v4_compiled": _brain_workload(TablePool, N, g0, world, dev, args.preroll, bufs,
                                                  other_ms=(dt * 1e3 - enc_ms - sp_ms) / args.steps, compile_net=True),
             "note": "cfg1_4096_v3 / _v4 = BASELINE configs[1]: 4,096 tables, uniform-random legal policy, the same protocol as the headline; "
+                    "cfg_8192_v4 / cfg_16384_v4 = one GPU's share of BASELINE C4's strong-scaling point (65,536 tables over 8 GPUs) and of C5 (131,072 over 8); "
                     "brain_v4 = BASELINE configs[2]: full self-play cycle with a random-init net of the reference's Brain/DQN shape "
                     "(192 channels x 40 blocks, fp16 autocast = torch.autocast's default on this backend like mortal/engine.py:46, greedy argmax) consuming the encoded batch in place on the same GPU; "
                     "2 timed cycles (the net takes seconds per 65 k-row batch); env_share = (step + encode + SP kernels) / cycle; "
-                    "brain_v4_compiled = the same module and autocast under torch.compile (PyTorch's inductor), 8,192-row chunks, 3 timed cycles: "
+                    "brain_v4_compiled = the same module and autocast under torch.compile (PyTorch's inductor) = DeviceEngine's DEFAULT on a GPU since round 6 (compile_net='auto'; brain_v4 passes compile_net=False), 8,192-row chunks, 3 timed cycles: "
                     "the net is PyTorch's by north_star, this only shows what its cheap settings buy (tools/brain_tune.py: 25 k -> 178 k rows/s); "
                     "obs_v3_random = env-step + encode only (no SP block); obs_v4_random_no_preroll = every table in the first "
                     "turns of E1 (17 draws left: the heaviest SP phase); obs_v4_greedy = tenpai-seeking policy on device "

@@ -290,6 +290,8 @@ int mj_tables_upload(const void* payload, size_t size) {
         upload(build_rbf(256, 23, 4), &g_tables.rbf_23))
         return -1;
     HIP_OK(hipGetDevice(&g_tables.device));
+    // ready only after c_mj_tables AND c_sp_tab / c_sp_nt are on the device: since round 5 the step kernel of EVERY obs version walks the
+    // table-id sets (mj_rules.h: update_shanten_discards / update_waits_and_furiten), and no pool can be created before this flag is set
     g_tables.ready = true;
     return 0;
 }

@@ -144,6 +144,17 @@ template <class LN> MJDN void update_shanten_discards(const LN& L, int s) {  // 
     const u64 held = h.nonzero_mask();
     const u64 same = sh14 >= 0 ? sp_keep_of_hand(TG, *L.T, h, ld3, sh14) & held : 0ull;  // discards that leave sh14
     const u64 up = held & ~same;                                                          // discards that leave sh14 + 1
+#ifdef MJ_EMU
+    // host emulation only: `up` is derived (held & ~same), so an error in the table-id set would corrupt the seat's discard
+    // sets silently.  Every held kind probed the old way -- calc_all of the hand without it -- must land in the set the masks say.
+    for (u64 m = held; m; m &= m - 1) {
+        const int t = __ffsll((long long)m) - 1;
+        Hand g = h;
+        g.dec(t);
+        const int v = calc_all(*L.T, g, ld3);
+        if (v != (((same >> t) & 1) ? sh14 : sh14 + 1)) set_err(L, MJ_ERR_INTERNAL);
+    }
+#endif
     const u64 next = (sh14 < sh ? same : 0ull) | (sh14 + 1 < sh ? up : 0ull);
     const u64 keep = (sh14 == sh ? same : 0ull) | (sh14 + 1 == sh ? up : 0ull);
     F1(next_shanten, s) = next;
@@ -161,6 +172,14 @@ template <class LN> MJDN void update_waits_and_furiten(const LN& L, int s) {  //
         // the tiles that complete the hand (a fifth copy is not a tile)
         u64 win = 0;
         if (calc_all(*L.T, h, ld3) == 0) win = sp_req_of_hand(TG, *L.T, h, ld3, 0);
+#ifdef MJ_EMU
+        for (int t = 0; t < 34; t++) {  // host emulation only: the winning tiles by the reference's loop (update.rs:930-951)
+            if (h.get(t) == 4) continue;
+            Hand g = h;
+            g.inc(t);
+            if ((calc_all(*L.T, g, ld3) == -1) != (bool)((win >> t) & 1)) set_err(L, MJ_ERR_INTERNAL);
+        }
+#endif
         for (u64 m = win; m; m &= m - 1) {
             const int t = __ffsll((long long)m) - 1, c = h.get(t);
             if (c == 4) continue;

@@ -106,15 +106,24 @@ class DeviceEngine:
 
     def __init__(self, net, version, device, name="mortal_amd", enable_amp=True, enable_quick_eval=True,
                  max_batch=16384, boltzmann_epsilon=0, boltzmann_temp=1, top_p=1, enable_rule_based_agari_guard=False,
-                 return_meta=False, seed=None, compile_net=False):
-        self.net = net.to(device).eval()
-        # compile_net: torch.compile (inductor) of the same module under the same autocast -- PyTorch's own graph compiler, measured
-        # 7.1 x the eager forward on MI355X for the 192 x 40 net (tools/brain_tune.py).  Chunks then have ONE shape (max_batch rows,
-        # the batch's ragged tail is padded in a staging buffer) so that nothing is compiled twice.
+                 return_meta=False, seed=None, compile_net="auto"):
+        self.net = net.to(device).eval()  # always the EAGER module: state_dict() / load_state_dict() keys stay the reference's
+        # compile_net: the forward runs through torch.compile (PyTorch's inductor) of the same module under the same autocast --
+        # measured 7.1 x the eager forward on MI355X for the 192 x 40 net (tools/brain_tune.py, bench.py workloads.brain_v4_compiled).
+        #   "auto" (default): compiled on a GPU for production-sized batches (max_batch >= 1024), eager otherwise (CPU, small test
+        #                     engines: compiling costs ~1 minute per distinct module); MORTAL_AMD_COMPILE_NET=0 / 1 overrides;
+        #   True / False    : as said.
+        # Chunks are padded to a few bucket sizes (powers of two from 256 rows up to max_batch) in a staging buffer, so a module is
+        # compiled for at most log2(max_batch / 256) + 1 shapes and a 10-row call does not run a max_batch-row forward.  If the
+        # compiler fails on the first call the engine says so once and continues EAGER (the net is PyTorch's either way).
+        import os
+
+        if compile_net == "auto":
+            env = os.environ.get("MORTAL_AMD_COMPILE_NET")
+            compile_net = (env == "1") if env in ("0", "1") else (torch.device(device).type == "cuda" and max_batch >= 1024)
         self.compiled = bool(compile_net)
-        self._stage = None
-        if self.compiled:
-            self.net = torch.compile(self.net)
+        self._fwd = torch.compile(self.net, dynamic=False) if self.compiled else self.net
+        self._stage = {}
         self.version = version
         self.device = torch.device(device)
         self.name = name
@@ -143,15 +152,16 @@ class DeviceEngine:
         for i in range(0, n, self.max_batch):  # bounded activation memory at 65k-row batches
             ob, mk = obs[i:i + self.max_batch], masks[i:i + self.max_batch]
             m = ob.shape[0]
-            if self.compiled and m < self.max_batch:  # the ragged tail, padded to the one compiled shape (a legal action in every pad row)
-                if self._stage is None or self._stage[0].shape[0] != self.max_batch or self._stage[0].shape[1:] != ob.shape[1:]:
-                    self._stage = (torch.zeros((self.max_batch,) + tuple(ob.shape[1:]), dtype=ob.dtype, device=ob.device),
-                                   torch.ones((self.max_batch, masks.shape[1]), dtype=torch.bool, device=ob.device))
-                self._stage[0][:m] = ob
-                self._stage[1][:m] = mk
-                ob, mk = self._stage
-            with torch.autocast(obs.device.type, enabled=self.enable_amp):
-                q = self.net(ob, mk)
+            b = self._bucket(m)
+            if self.compiled and m < b:  # a ragged chunk, padded to its bucket's shape (a legal action in every pad row)
+                st = self._stage.get(b)
+                if st is None or st[0].shape[1:] != ob.shape[1:] or st[0].device != ob.device:
+                    st = self._stage[b] = (torch.zeros((b,) + tuple(ob.shape[1:]), dtype=ob.dtype, device=ob.device),
+                                           torch.ones((b, masks.shape[1]), dtype=torch.bool, device=ob.device))
+                st[0][:m] = ob
+                st[1][:m] = mk
+                ob, mk = st
+            q = self._forward(ob, mk)
             q, mk = q[:m], mk[:m]
             act, is_greedy = boltzmann_actions(q, mk, self.boltzmann_epsilon, self.boltzmann_temp, self.top_p, self.generator)
             out[i:i + m] = act.to(torch.int32)
@@ -159,6 +169,28 @@ class DeviceEngine:
                 q_all[i:i + m] = q.float()
                 greedy_all[i:i + m] = is_greedy
         return (out, q_all, greedy_all) if want_meta else out
+
+    def _bucket(self, m):
+        """The padded row count of an m-row chunk on the compiled path: the next power of two >= max(m, 256), at most max_batch."""
+        b = 256
+        while b < m:
+            b *= 2
+        return min(b, self.max_batch)
+
+    def _forward(self, ob, mk):
+        try:
+            with torch.autocast(ob.device.type, enabled=self.enable_amp):
+                return self._fwd(ob, mk)
+        except Exception as e:  # noqa: BLE001 - inductor / toolchain failures surface on the first call of a shape
+            if not self.compiled:
+                raise
+            import warnings
+
+            warnings.warn(f"DeviceEngine: torch.compile failed ({e!r:.300}); continuing with the eager module", RuntimeWarning)
+            self.compiled = False
+            self._fwd = self.net
+            with torch.autocast(ob.device.type, enabled=self.enable_amp):
+                return self.net(ob[:], mk[:])
 
     def react_batch(self, obs, masks, invisible_obs):
         import numpy as np

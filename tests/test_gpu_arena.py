@@ -15,7 +15,7 @@ def _engine(version, seed, name, device_path):
 
     torch.manual_seed(seed)
     net = PolicyNet(version=version, conv_channels=32, num_blocks=2)
-    eng = DeviceEngine(net, version, "cuda:0", name=name, enable_amp=False)
+    eng = DeviceEngine(net, version, "cuda:0", name=name, enable_amp=False, compile_net=False)  # (bit-equal q-values against the oracle loop)
     if not device_path:
         eng.react_batch_device = None
         del eng.react_batch_device
@@ -237,7 +237,7 @@ def test_device_engine_exploration_meta_on_device(oracle, tmp_path):
     def engine(seed, name, eps):
         torch.manual_seed(seed)
         return DeviceEngine(PolicyNet(version=4, conv_channels=32, num_blocks=2), 4, "cuda:0", name=name, enable_amp=False,
-                            boltzmann_epsilon=eps, top_p=0.9, return_meta=True, seed=seed)
+                            boltzmann_epsilon=eps, top_p=0.9, return_meta=True, seed=seed, compile_net=False)
 
     d = str(tmp_path / "logs")
     got = OneVsThree(disable_progress_bar=True, log_dir=d).py_vs_py(challenger=engine(1, "challenger", 0.25), champion=engine(2, "champion", 0.0),
@@ -252,3 +252,35 @@ def test_device_engine_exploration_meta_on_device(oracle, tmp_path):
                 n_explored += not meta["is_greedy"]
                 assert len(meta["q_values"]) == bin(meta["mask_bits"]).count("1")
     assert n_meta > 1000 and 0 < n_explored < n_meta / 2
+
+
+def test_device_engine_real_torch_compile_matches_eager():
+    """DeviceEngine's DEFAULT on a GPU (compile_net="auto": torch.compile of the module, dynamic=False, autocast inside the call,
+    bucketed padding of ragged chunks) against the eager module on real encoded-shape batches: q-values within fp32 reassociation
+    noise, the same greedy action wherever the best two q-values are not a near-tie, a legal action everywhere; the engine's module
+    keeps the reference's parameter names (the only test of the compiled path had replaced torch.compile)."""
+    import torch
+
+    from mortal_amd.policy import DeviceEngine, PolicyNet
+
+    torch.manual_seed(11)
+    net = PolicyNet(version=4, conv_channels=16, num_blocks=1)
+    comp = DeviceEngine(net, 4, "cuda:0", enable_amp=False, max_batch=1024, return_meta=True)
+    assert comp.compiled, "auto = compiled on a GPU for max_batch >= 1024"
+    eager = DeviceEngine(net, 4, "cuda:0", enable_amp=False, max_batch=1024, return_meta=True, compile_net=False)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for rows in (1500, 37):  # 1024 + 476 (padded to 512); 37 (padded to 256)
+        obs = torch.rand((rows, 1012, 34), device="cuda", generator=g)
+        mask = torch.rand((rows, 46), device="cuda", generator=g) < 0.3
+        mask[:, 45] = True
+        a_c, q_c, _ = comp.react_batch_device(obs, mask)
+        a_e, q_e, _ = eager.react_batch_device(obs, mask)
+        assert comp.compiled, "torch.compile fell back to eager on this box"
+        fin = torch.isfinite(q_e)
+        assert torch.equal(fin, torch.isfinite(q_c)) and torch.equal(fin, mask)
+        assert torch.allclose(q_c[fin], q_e[fin], rtol=1e-4, atol=1e-4)
+        top2 = q_e.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert clear.float().mean() > 0.5 and torch.equal(a_c[clear], a_e[clear])
+        assert mask.gather(1, a_c.long().unsqueeze(1)).all()
+    assert not any(k.startswith("_orig_mod.") for k in comp.net.state_dict())

@@ -167,3 +167,42 @@ def test_device_engine_compiled_path_pads_the_ragged_tail(monkeypatch):
     assert q_c.shape == (150, 46) and g_c.all()
     assert seen and all(s == (64, 1012, 34) for s in seen), seen  # 64 + 64 + (22 padded to 64)
     assert mask[torch.arange(150), a_e.long()].all()  # legal actions only
+    # padding goes to a few bucket sizes, not to max_batch: a 10-row call of a 16,384-row engine runs a 256-row forward
+    seen.clear()
+    big = DeviceEngine(net, 4, "cpu", enable_amp=False, max_batch=1024, compile_net=True)
+    for rows in (10, 150, 256, 700, 1024):
+        assert torch.equal(big.react_batch_device(obs[:1].expand(rows, -1, -1).contiguous(), mask[:1].expand(rows, -1).contiguous()),
+                           a_e[:1].expand(rows))
+    assert [s[0] for s in seen] == [256, 256, 256, 1024, 1024], seen
+    assert set(big._stage) == {256, 1024}
+    # the engine's module stays the eager one: checkpoints saved / loaded through engine.net keep the reference's parameter names
+    assert not any(k.startswith("_orig_mod.") for k in big.net.state_dict()) and big.net is net
+    # "auto" never compiles on the CPU; the environment switch forces either way
+    assert DeviceEngine(net, 4, "cpu", enable_amp=False).compiled is False
+    monkeypatch.setenv("MORTAL_AMD_COMPILE_NET", "1")
+    assert DeviceEngine(net, 4, "cpu", enable_amp=False).compiled is True
+    monkeypatch.setenv("MORTAL_AMD_COMPILE_NET", "0")
+    assert DeviceEngine(net, 4, "cpu", enable_amp=False, max_batch=4096).compiled is False
+
+
+def test_device_engine_compile_failure_falls_back_to_eager_loudly(monkeypatch):
+    """A compiler that throws on the first call (no inductor toolchain, an unsupported op) costs a RuntimeWarning, not the run."""
+    import torch
+
+    from mortal_amd.policy import DeviceEngine, PolicyNet
+
+    class Broken(torch.nn.Module):
+        def forward(self, obs, mask):
+            raise RuntimeError("inductor: no C++ compiler")
+
+    monkeypatch.setattr(torch, "compile", lambda m, **kw: Broken())
+    torch.manual_seed(4)
+    net = PolicyNet(version=4, conv_channels=16, num_blocks=1)
+    obs = torch.rand(20, 1012, 34)
+    mask = torch.rand(20, 46) < 0.3
+    mask[:, 45] = True
+    want = DeviceEngine(net, 4, "cpu", enable_amp=False, compile_net=False).react_batch_device(obs, mask)
+    eng = DeviceEngine(net, 4, "cpu", enable_amp=False, compile_net=True)
+    with pytest.warns(RuntimeWarning, match="torch.compile failed"):
+        got = eng.react_batch_device(obs, mask)
+    assert torch.equal(got, want) and eng.compiled is False
