@@ -315,6 +315,9 @@ def _measure(pool_cls, N, g0, world, dev, version, preroll, policy, steps, warmu
         tot_t = max(1, sum(d[k] for k in ("setup", "expand", "level0", "eval", "write")))
         res["sp_phases"] = {"share": {k: round(d[k] / tot_t, 4) for k in ("setup", "expand", "level0", "eval", "write")},
                             "states_per_step": d["states"] / steps, "rows_per_step": d["rows"] / steps, "overflows": d["overflow"]}
+    if C == 1012:  # obs v4: the small-pool schedule of the SP kernel (rows parked by mj_k_sp and finished by mj_k_sp_wide), whole run incl. warm-up
+        sc = [pool.sp_schedule_stats() for pool in pools]
+        res["sp_schedule"] = {k: sum(x[k] for x in sc) for k in sc[0]}
     if world > 1:  # episode returns of EVERY pool of this rank (--pools K > 1 used to gather the first pool's only)
         parts = [pool.results() for pool in pools]
         res["results"] = (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
@@ -617,6 +620,8 @@ def main():
         if "sp_phases" in r:  # where mj_k_sp spends its workgroup time (shares of the summed phase timers) + states per cycle
             line["sp_phases"] = r["sp_phases"]
             line["roofline_sp"] = _roofline_sp(r, sp_ms, sp_launches)
+        if "sp_schedule" in r:
+            line["sp_schedule"] = r["sp_schedule"]
         if matrix:
             line["workloads"] = matrix
         if not args.no_cpu_baseline and world == 1 and args.policy == "random":  # reported at N=1 only (rank 0)

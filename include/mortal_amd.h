@@ -136,6 +136,18 @@ int mj_sp_timing(MjPool* pool, double* total_ms_out, int64_t* launches_out);
  * workgroups): out[0] hash/pool overflows, [1] rows, [2] set-up, [3] expansion, [4] level 0 (probe + scoring + sum),
  * [5] evaluation of levels > 0, [6] writing the rows, [7] states visited.  Measurement only (bench.py `sp_phases`). */
 int mj_sp_phase_ticks(MjPool* pool, uint64_t* out8, void* stream);
+/* Small-pool schedule of the SP kernel (round 6).  The reference spreads the decisions of a batch over every core and pins nothing
+ * (agent/mortal.rs:252-287: rayon par_iter over the batch's states); here a decision row is pinned to one 256-thread workgroup of
+ * mj_k_sp, and with few rows per launch the launch lasts as long as its heaviest row.  With the schedule on, a workgroup that finds a
+ * row's state graph large (the level it is about to expand has >= min_level1 / min_level2 states) parks the row and a 1,024-thread
+ * workgroup of the kernel mj_k_sp_wide [wide_grid of them, one per CU, running beside mj_k_sp] finishes it; results are bit-identical either way.
+ * mode: -1 auto (launches of at most max_rows rows; the default, also settable through MJ_SP_WIDE / MJ_SP_WIDE_MAX_ROWS /
+ * MJ_SP_WIDE_GRID / MJ_SP_PROMO_MIN1 / _MIN2), 0 never, 1 every launch.  Arguments <= 0 keep the current value (mode: < -1).
+ * Call it before the pool's first obs-v4 mj_encode (the spare work areas are sized then); afterwards only mode 0 / the thresholds change. */
+int mj_pool_set_sp_schedule(MjPool* pool, int mode, int max_rows, int wide_grid, int min_level1, int min_level2);
+/* out[0] launches that ran both kernels, [1] rows parked and finished by mj_k_sp_wide, [2] rows the sweep launch had to take (the two
+ * kernels did not overlap), [3] wide workgroups that gave up waiting (same), since the pool was created.  Measurement only. */
+int mj_sp_schedule_stats(MjPool* pool, uint64_t* out4, void* stream);
 
 /* Uniform-random legal action per row, counter-based (seed, game id, seat, kan flag, cycle). */
 int mj_random_policy(MjPool* pool, int agent, const uint8_t* masks_dev, uint64_t seed, uint64_t cycle,

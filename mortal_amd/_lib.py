@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MORTAL_AMD_LIB") or os.path.join(_DIR, "libmortal_amd
 SYMBOLS = [
     "mj_last_error", "mj_abi_version", "mj_tables_upload", "mj_pool_create", "mj_pool_destroy", "mj_pool_reset",
     "mj_pool_configure", "mj_pool_set_refill", "mj_pool_set_start_stagger", "mj_table_apply_event", "mj_table_mark_row", "mj_table_query", "mj_replay_load", "mj_replay_step", "mj_replay_meta", "mj_pool_enable_log", "mj_log_lengths", "mj_log_read", "mj_step", "mj_step_q", "mj_step_ev", "mj_rows_count", "mj_rows_dev", "mj_encode",
-    "mj_encode_oracle", "mj_oracle_obs_rows", "mj_encode_timing", "mj_sp_timing", "mj_sp_phase_ticks", "mj_random_policy", "mj_greedy_policy", "mj_counters", "mj_results", "mj_pool_first_error", "mj_debug_table",
+    "mj_encode_oracle", "mj_oracle_obs_rows", "mj_encode_timing", "mj_sp_timing", "mj_sp_phase_ticks", "mj_pool_set_sp_schedule", "mj_sp_schedule_stats", "mj_random_policy", "mj_greedy_policy", "mj_counters", "mj_results", "mj_pool_first_error", "mj_debug_table",
     "mj_debug_table_size", "mj_debug_layout", "mj_obs_rows", "mj_algo_query",
 ]
 
@@ -56,6 +56,8 @@ def _load(path=None):
     L.mj_encode_timing.argtypes = [vp, i32, vp, vp]
     L.mj_sp_timing.argtypes = [vp, vp, vp]
     L.mj_sp_phase_ticks.argtypes = [vp, vp, vp]
+    L.mj_pool_set_sp_schedule.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.mj_sp_schedule_stats.argtypes = [vp, vp, vp]
     L.mj_table_apply_event.argtypes = [vp, i32, vp, i32, vp]
     L.mj_table_mark_row.argtypes = [vp, i32, i32, i32, vp]
     L.mj_table_query.argtypes = [vp, i32, i32, i32, vp, vp, vp]

@@ -153,8 +153,16 @@ struct MjPool {
     int* n_rows_dev = nullptr;
     int* block_rows = nullptr;
     TableOne* snap = nullptr;
-    SpWork* sp_work = nullptr;      // lazily allocated on the first v4 encode
+    SpWork* sp_work = nullptr;      // lazily allocated on the first v4 encode: sp_grid areas (one per workgroup of mj_k_sp) + sp_spare spare ones
     int sp_grid = 0;
+    int sp_wide_areas = 0;          // work areas of mj_k_sp_wide's own workgroups (= its largest grid)
+    int sp_spare = 0;               // spare work areas = promotions per launch (small pools: mj_sp.hip "promotion"; 0 = this pool never promotes)
+    int sp_wide_mode = -1;          // -1 auto (launches of at most sp_wide_max_rows rows), 0 never, 1 always
+    int sp_wide_max_rows = 20000, sp_wide_grid = 0, sp_promo_min[4] = {0, 0, 0, 0};  // grid / thresholds 0 = by the launch's row count (mj_encode)
+    hipStream_t sp_stream2 = nullptr;   // mj_k_sp's stream while mj_k_sp_wide runs on the caller's
+    hipEvent_t sp_ev_fork = nullptr, sp_ev_join = nullptr;
+    uint64_t sp_hybrid_launches = 0;
+    bool sp_sched_set = false;      // mj_pool_set_sp_schedule was called: the environment does not override it
     int* sp_queue = nullptr;        // [0] row queue head, [1..8] / [9..16] class counts / cursors of the row sort, [SP_Q_TAIL] head of the tail
     uint32_t* sp_order = nullptr;   // [max_rows] queue position -> row
     uint8_t* sp_cls = nullptr;      // [max_rows] cost class of a row
@@ -348,6 +356,9 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->block_rows);
     hipFree(P->snap);
     hipFree(P->sp_work);
+    if (P->sp_stream2) hipStreamDestroy(P->sp_stream2);
+    if (P->sp_ev_fork) hipEventDestroy(P->sp_ev_fork);
+    if (P->sp_ev_join) hipEventDestroy(P->sp_ev_join);
     hipFree(P->sp_queue);
     hipFree(P->sp_order);
     hipFree(P->sp_cls);
@@ -724,12 +735,30 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
                 P->sp_grid = 256 * SP_WGS;  // persistent workgroups: SP_WGS per CU, one decision row each at a time
                 if (P->sp_grid > P->max_rows) P->sp_grid = P->max_rows;  // never more rows than that in a launch (small pools: small work area)
                 if (const char* g = getenv("MJ_SP_GRID")) P->sp_grid = std::max(1, std::min(P->sp_grid, atoi(g)));  // tests: few workgroups, many rows each (the row-to-row paths)
-                HIP_OK(hipMalloc(&P->sp_work, (size_t)P->sp_grid * sizeof(SpWork)));
-                for (int g = 0; g < P->sp_grid; g++) {
+                // promotion of large rows to mj_k_sp_wide (mj_sp.hip): MJ_SP_WIDE = 0 never / 1 every launch / unset: launches of at most
+                // MJ_SP_WIDE_MAX_ROWS rows; MJ_SP_WIDE_GRID wide workgroups; MJ_SP_PROMO_MIN1 / _MIN2: the level sizes that park a row
+                if (!P->sp_sched_set) {
+                    if (const char* g = getenv("MJ_SP_WIDE")) P->sp_wide_mode = atoi(g);
+                    if (const char* g = getenv("MJ_SP_WIDE_MAX_ROWS")) P->sp_wide_max_rows = atoi(g);
+                    if (const char* g = getenv("MJ_SP_WIDE_GRID")) P->sp_wide_grid = std::max(1, atoi(g));
+                    if (const char* g = getenv("MJ_SP_PROMO_MIN1")) P->sp_promo_min[1] = std::max(1, atoi(g));
+                    if (const char* g = getenv("MJ_SP_PROMO_MIN2")) P->sp_promo_min[2] = std::max(1, atoi(g));
+                }
+                P->sp_spare = P->sp_wide_mode == 0 ? 0 : std::min(SP_PROMO_CAP, std::max(8, P->n_tables / 4) & ~1);
+                P->sp_wide_areas = P->sp_spare ? std::min(256, std::max(2, P->n_tables / 16)) : 0;  // (a 64-table test pool does not need 2 GB of work areas)
+                if (P->sp_wide_mode < 0 && P->n_tables > P->sp_wide_max_rows) P->sp_spare = 0;  // (a launch has about as many rows as the pool has tables)
+                const int areas = P->sp_grid + P->sp_spare + P->sp_wide_areas;  // + one per workgroup of mj_k_sp_wide (its own rows)
+                HIP_OK(hipMalloc(&P->sp_work, (size_t)areas * sizeof(SpWork)));
+                for (int g = 0; g < areas; g++) {
                     HIP_OK(hipMemsetAsync(P->sp_work[g].tag, 0, sizeof(P->sp_work[g].tag), s));  // empty hash sets ...
                     HIP_OK(hipMemsetAsync(&P->sp_work[g].epoch, 0, sizeof(P->sp_work[g].epoch) + sizeof(P->sp_work[g].pad_), s));  // ... at epoch 0
                 }
                 HIP_OK(hipMalloc(&P->sp_queue, SP_Q_WORDS * sizeof(int)));
+                if (P->sp_spare) {
+                    HIP_OK(hipStreamCreateWithFlags(&P->sp_stream2, hipStreamNonBlocking));
+                    HIP_OK(hipEventCreateWithFlags(&P->sp_ev_fork, hipEventDisableTiming));
+                    HIP_OK(hipEventCreateWithFlags(&P->sp_ev_join, hipEventDisableTiming));
+                }
             }
             HIP_OK(hipMemsetAsync(P->sp_queue, 0, SP_Q_WORDS * sizeof(int), s));
             SpParams sp;
@@ -743,11 +772,83 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
             sp.order = P->sp_order;
             sp.err = P->sp_err;
             sp.prof = getenv("MJ_SP_PROF") ? P->sp_err : nullptr;
+            sp.rowdump = nullptr;
+            static const char* rowdump_path = getenv("MJ_SP_ROWDUMP");  // (debug) per-row cost records appended to this file, one synchronous copy per launch
+            if (rowdump_path) {
+                HIP_OK(hipMalloc(&sp.rowdump, (size_t)n * 48));
+                HIP_OK(hipMemsetAsync(sp.rowdump, 0, (size_t)n * 48, s));
+                HIP_OK(hipMemsetAsync(P->sp_err + 28, 0xFF, 8, s));
+                HIP_OK(hipMemsetAsync(P->sp_err + 29, 0, 24, s));
+            }
             int grid = n < P->sp_grid ? n : P->sp_grid;
+            const bool hybrid = P->sp_spare > 0 && (P->sp_wide_mode > 0 || (P->sp_wide_mode < 0 && n <= P->sp_wide_max_rows));
+            sp.promo_cap = hybrid ? P->sp_spare : 0;
+            // Defaults measured on MI355X (tools/r06_sweep.sh): up to ~12 k rows 64 wide workgroups (a quarter of the CUs),
+            // rows parked at >= 1,200 level-1 states (or >= 400 level-2 states, before that level is expanded); up to ~20 k rows 32 wide
+            // workgroups and 1,600 level-1 states; beyond that a launch keeps all CUs for mj_k_sp (sp_wide_max_rows).  The root level is never
+            // parked (nothing is known yet), level 0 is not expanded.
+            sp.promo_min[0] = sp.promo_min[3] = 1 << 30;
+            sp.promo_min[1] = P->sp_promo_min[1] > 0 ? P->sp_promo_min[1] : n <= 12000 ? 1200 : 1600;
+            sp.promo_min[2] = P->sp_promo_min[2] > 0 ? P->sp_promo_min[2] : n <= 12000 ? 400 : 1 << 30;
+            sp.n_narrow = grid;
+            sp.sweep = 0;
             // queue order: rows counting-sorted by cost class, heaviest first (inside the timed mj_k_sp region)
             hipLaunchKernelGGL(mj_k_order_classify, dim3((n + 255) / 256), dim3(256), 0, s, P->snap, sp.rows, n, P->sp_cls, P->sp_queue + 1);
             hipLaunchKernelGGL(mj_k_order_scatter, dim3((n + 255) / 256), dim3(256), 0, s, P->sp_cls, n, P->sp_queue + 1, P->sp_queue + 9, P->sp_order);
-            hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
+            if (!hybrid) {
+                hipLaunchKernelGGL(mj_k_sp, dim3(grid), dim3(SP_THREADS), 0, s, sp);
+            } else {
+                // mj_k_sp_wide FIRST and on the caller's stream (its few workgroups take a whole CU each and must be resident before the 1,024
+                // workgroups of mj_k_sp fill the chip), mj_k_sp on the second stream behind the row order, then the sweep behind both.
+                // The emulator runs a launch to completion: there (and with MJ_SP_WIDE_SERIAL=1) the sweep alone takes the parked rows.
+                P->sp_hybrid_launches++;
+                const int wgrid = std::min(P->sp_wide_areas, P->sp_wide_grid > 0 ? P->sp_wide_grid : n <= 12000 ? 64 : 32);
+#ifdef MJ_EMU
+                const bool serial = true;
+#else
+                static const bool serial = getenv("MJ_SP_WIDE_SERIAL") != nullptr;
+#endif
+                if (serial) {
+                    if (getenv("MJ_SP_WIDE_ALL_ROWS")) {  // (tests) the wide kernel alone first: with no producer to wait for it takes EVERY row of the queue itself
+                        SpParams spw = sp;
+                        spw.n_narrow = 0;
+                        spw.work = sp.work + grid;  // (its own areas: work + n_narrow + promo_cap + block, as in the concurrent launch)
+                        hipLaunchKernelGGL(mj_k_sp_wide, dim3(wgrid), dim3(SP_WIDE_THREADS), 0, s, spw);
+                    }
+                    hipLaunchKernelGGL(mj_k_sp_promo, dim3(grid), dim3(SP_THREADS), 0, s, sp);
+                } else {
+                    HIP_OK(hipEventRecord(P->sp_ev_fork, s));
+                    hipLaunchKernelGGL(mj_k_sp_wide, dim3(wgrid), dim3(SP_WIDE_THREADS), 0, s, sp);
+                    HIP_OK(hipStreamWaitEvent(P->sp_stream2, P->sp_ev_fork, 0));
+                    hipLaunchKernelGGL(mj_k_sp_promo, dim3(grid), dim3(SP_THREADS), 0, P->sp_stream2, sp);
+                    HIP_OK(hipEventRecord(P->sp_ev_join, P->sp_stream2));
+                    HIP_OK(hipStreamWaitEvent(s, P->sp_ev_join, 0));
+                }
+                sp.sweep = 1;
+                hipLaunchKernelGGL(mj_k_sp_wide, dim3(wgrid), dim3(SP_WIDE_THREADS), 0, s, sp);
+            }
+            if (sp.rowdump) {
+                std::vector<uint32_t> h((size_t)n * 12);
+                int q[SP_Q_WORDS];
+                HIP_OK(hipMemcpyAsync(h.data(), sp.rowdump, (size_t)n * 48, hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(q, P->sp_queue, sizeof(q), hipMemcpyDeviceToHost, s));
+                HIP_OK(hipStreamSynchronize(s));
+                hipFree(sp.rowdump);
+                if (FILE* f = fopen(rowdump_path, "ab")) {
+                    uint32_t hdr[12] = {0xFFFFFFFFu, (uint32_t)n};
+                    for (int k = 0; k < 10; k++) hdr[2 + k] = 0;
+                    unsigned long long tt[4];
+                    HIP_OK(hipMemcpy(tt, P->sp_err + 28, sizeof tt, hipMemcpyDeviceToHost));
+                    for (int k = 0; k < 4; k++) hdr[2 + k] = (uint32_t)tt[k];  // first workgroup in, last narrow / wide out of the row loop, end of the tail
+                    fwrite(hdr, 4, 12, f);
+                    uint32_t cc[12];
+                    for (int k = 0; k < 12; k++) cc[k] = k < 8 ? (uint32_t)q[1 + k] : 0u;
+                    fwrite(cc, 4, 12, f);
+                    for (int i = 0; i < n; i++)
+                        if (h[(size_t)i * 12 + 7]) fwrite(&h[(size_t)i * 12], 4, 12, f);
+                    fclose(f);
+                }
+            }
         }
         if (P->timing) {
             HIP_OK(hipEventRecord(s1, s));
@@ -896,6 +997,32 @@ int mj_sp_phase_ticks(MjPool* P, uint64_t out[8], void* stream) {
     unsigned long long e2[8];
     HIP_OK(hipMemcpy(e2, P->sp_err, sizeof e2, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = e2[i];
+    return 0;
+}
+
+int mj_pool_set_sp_schedule(MjPool* P, int mode, int max_rows, int wide_grid, int min_level1, int min_level2) {
+    if (!P) return fail("null pool");
+    if (P->sp_work && mode != 0 && mode >= -1 && P->sp_spare == 0) return fail("mj_pool_set_sp_schedule: the work areas are allocated (call it before the first obs-v4 mj_encode)");
+    if (mode >= -1) P->sp_wide_mode = mode > 0 ? 1 : mode;
+    if (max_rows > 0) P->sp_wide_max_rows = max_rows;
+    if (wide_grid > 0) P->sp_wide_grid = std::min(wide_grid, 256);
+    if (min_level1 > 0) P->sp_promo_min[1] = min_level1;
+    if (min_level2 > 0) P->sp_promo_min[2] = min_level2;
+    P->sp_sched_set = true;
+    return 0;
+}
+
+int mj_sp_schedule_stats(MjPool* P, uint64_t out[4], void* stream) {
+    if (!P) return fail("null pool");
+    for (int i = 0; i < 4; i++) out[i] = 0;
+    if (!P->sp_err) return 0;
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long e2[32];
+    HIP_OK(hipMemcpy(e2, P->sp_err, sizeof e2, hipMemcpyDeviceToHost));
+    out[0] = P->sp_hybrid_launches;
+    out[1] = e2[26];
+    out[2] = e2[27];
+    out[3] = e2[25];
     return 0;
 }
 

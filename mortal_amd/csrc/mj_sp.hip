@@ -65,7 +65,20 @@
 #define SP_TAIL_BATCH 4         // rows per pop in the tail of the queue (rows without a state graph, one row per wavefront)
 #endif
 #define SP_Q_TAIL 32            // index of the tail's head word in SpParams::queue
-#define SP_Q_WORDS 64
+// Small pools (round 6): a row whose state graph turns out large is PROMOTED by its 256-thread workgroup to a wide (SP_WIDE_THREADS)
+// workgroup of mj_k_sp_wide, which runs beside mj_k_sp on another stream (see "promotion" at mj_k_sp).  Queue words, one 128-byte line each:
+#define SP_Q_PROMO_DONE 96      // workgroups of mj_k_sp that have left their row loop (no promotion can follow)
+#define SP_PROMO_LEVELS 2       // promotion queues: [0] the largest rows (taken first), [1] the rest
+#define SP_Q_PROMO_ALLOC(p) (128 + 64 * (p))  // promotions so far = the next free entry / spare work area of queue p
+#define SP_Q_PROMO_HEAD(p) (160 + 64 * (p))   // next entry of queue p a wide workgroup takes; + 1: the same for the sweep launch
+#define SP_Q_PROMO_ENT 256      // entries [queue][SP_PROMO_CAP / 2]: work area + 1 (published after an agent-scope release), -1 = taken
+#ifndef SP_PROMO_CAP
+#define SP_PROMO_CAP 512        // promotions per launch (= spare work areas), half of them per queue
+#endif
+#define SP_Q_WORDS (SP_Q_PROMO_ENT + SP_PROMO_CAP)
+#ifndef SP_WIDE_THREADS
+#define SP_WIDE_THREADS 1024
+#endif
 #define SP_POOL (SP_CAP * 32)   // child-list pool entries per workgroup
 #define SP_ITEMS (SP_CAP * 4)   // level-0 scoring items per workgroup
 #define SP_L0_MAX 17            // winning draw entries per tenpai state (13 waits + 3 aka variants)
@@ -101,6 +114,7 @@ struct SpKeys {                 // a state's key and exact id, DENSE by list ind
 #define SP_ENT_COUNT(e) (((e) >> 24) & 7u)
 #define SP_ENT_INVALID (1u << 27)
 struct alignas(16) SpF4 { float x, y, z, w; };
+#define SP_HANDOFF_WORDS 1024   // >= sizeof(SpHandoff) / 4 (static_assert below)
 struct alignas(128) SpWork {   // per-workgroup scratch in HBM (persistent workgroups), 8.1 MB
     u64 tag[SP_CAP];           // state id | row epoch << 42 | 1 << 63; a tag of another epoch (or 0) is an EMPTY slot
     SpNode node[SP_CAP];       // by hash slot
@@ -113,6 +127,7 @@ struct alignas(128) SpWork {   // per-workgroup scratch in HBM (persistent workg
     SpF4 l0sc[SP_ITEMS];       // level 0: get_score() of every work item (sp_l0_score), all zero = no yaku
     u32 epoch;                 // the tag epoch of the last row with a state graph this workgroup processed (persists across launches)
     u32 pad_[31];
+    alignas(16) u32 handoff[SP_HANDOFF_WORDS];  // a promoted row's context (SpHandoff: SpCtx + SpRowInfo + row + next level), written by its first workgroup
 #ifdef MJ_EMU
     u32 idx_of[SP_CAP];        // emulator only: slot -> list index, for the id <-> key bijection check on every hit
 #endif
@@ -155,6 +170,12 @@ struct SpParams {
     const uint32_t* order;     // [n_rows] queue position -> row index, heaviest cost class first (mj_k_order_classify / _scatter)
     unsigned long long* prof;  // NULL or [24] phase timers / counters (MJ_SP_PROF; mj_counters prints them)
     unsigned long long* err;   // [0] hash-capacity overflows, [1] rows; cycle sums: [2] setup [3] expand [4] eval L0 [5] eval L>0 [6] encode; [7] states
+    uint32_t* rowdump;         // (builds with -DSP_ROWDUMP only: tools/build_variant.sh dump -DSP_ROWDUMP) NULL, or [n_rows][12] per-row records of the rows with a state graph (MJ_SP_ROWDUMP: cost-model data for the row order)
+    // promotion of large rows to mj_k_sp_wide (small pools; see "promotion" at mj_k_sp)
+    int promo_cap;             // spare work areas = promotions allowed in this launch (0: off); work[] holds grid + promo_cap areas
+    int promo_min[4];          // [level]: park the row when the level about to be expanded has at least this many states
+    int n_narrow;              // mj_k_sp_wide: workgroups of mj_k_sp in this launch (the DONE word's final value)
+    int sweep;                 // mj_k_sp_wide: 1 = the sweep launch behind both kernels (never waits)
 };
 
 // algo/data/uradora_prob_table.txt (values restated; calc.rs:17)
@@ -474,7 +495,12 @@ MJD SpState sp_state_of(const NodeT& n) {
 __device__ bool sp_get_score(const MjTablesDev& T, const SpCtx* X, const SpState& s, int win_tile, float scores[4]) {
     AgariIn in;
     in.tehai = s.h;
-    in.m = X->melds;
+    {   // member-wise (a struct copy is a memcpy, which keeps the generic address space of X: flat loads, both wait counters; with one
+        // kernel the compiler knew X's LDS address, with three kernels sharing this function it does not)
+        const Melds& xm = X->melds;
+        in.m.chis = xm.chis; in.m.pons = xm.pons; in.m.minkans = xm.minkans; in.m.ankans = xm.ankans;
+        in.m.n_chis = xm.n_chis; in.m.n_pons = xm.n_pons; in.m.n_minkans = xm.n_minkans; in.m.n_ankans = xm.n_ankans;
+    }
     in.is_menzen = X->is_menzen != 0;
     in.bakaze = X->bakaze;
     in.jikaze = X->jikaze;
@@ -1091,7 +1117,7 @@ __device__ SP_ATTR_EXPAND void sp_expand_chunk(SpWork* W, SpCtx* X, SpChunk* C, 
 // LDS of the evaluation: SP_EVW_WAVE_FLOATS per wavefront, split between its teams (a team is exactly T - off lanes wide, T = draws
 // left, a constant of the row: floor(64 / (T - off)) teams per wavefront, so rows with 9 draws left run 7 states per wavefront
 // instead of 4): levels > 0 park SP_EV_ENT rows-of-(T + 4) x 4 floats per team, level 0 SP_EV_ENT numerator rows of SP_EV0_STRIDE floats.
-#define SP_EVAL_LDS_FLOATS ((SP_THREADS / 64) * 1408)
+#define SP_EVAL_LDS_FLOATS(NT) (((NT) / 64) * 1408)
 
 // Evaluation (bottom-up), by TEAMS of T - off lanes, lane = turn: tenpai / win / EV of calc.rs:447-561 into node.val[turn].
 // A state `off` levels below the row's roots is reached after at least `off` draws, so nobody ever reads its values of the turns
@@ -1450,11 +1476,12 @@ __device__ SP_ATTR_EVAL void sp_eval_wave(SpWork* W, SpCtx* X, float* WL, int fi
 // The teams of a wavefront evaluate consecutive states of a level, and the wavefront runs as long as its slowest team: order
 // the level by child-list length (counting sort over 64 buckets, workgroup-wide) so that neighbours cost about the same (key: children + 4 x draw entries).  The
 // order of states inside a level does not touch the results (each state is evaluated on its own).
+template <int NT>
 __device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] */, int b, int e) {
     SP_HBM SpWork* const Wg = (SP_HBM SpWork*)W;
     const int tid = threadIdx.x;
     if (e - b <= SP_SORT_MIN) {  // a handful of states (the root level): one round of teams whatever the order
-        for (int i = b + tid; i < e; i += SP_THREADS) Wg->elist[i] = Wg->list[i] | ((u32)i << 14);
+        for (int i = b + tid; i < e; i += NT) Wg->elist[i] = Wg->list[i] | ((u32)i << 14);
         __syncthreads();
         return;
     }
@@ -1469,12 +1496,12 @@ __device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] *
     int my_key[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int i = b + tid + q * SP_THREADS;
+        const int i = b + tid + q * NT;
         my_slot[q] = i < e ? (Wg->list[i] | ((u32)i << 14)) : 0u;
         my_key[q] = i < e ? cost_key(i) : 0;
         if (i < e) atomicAdd(&hist[my_key[q]], 1);
     }
-    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) atomicAdd(&hist[cost_key(i)], 1);
+    for (int i = b + tid + 4 * NT; i < e; i += NT) atomicAdd(&hist[cost_key(i)], 1);
     __syncthreads();
     if (tid < 64) {  // exclusive prefix over the 64 buckets: one wavefront scan
         const int c = hist[tid];
@@ -1483,10 +1510,10 @@ __device__ __forceinline__ void sp_sort_level(SpWork* W, int* hist /* LDS [64] *
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int i = b + tid + q * SP_THREADS;
+        const int i = b + tid + q * NT;
         if (i < e) Wg->elist[b + atomicAdd(&hist[my_key[q]], 1)] = my_slot[q];
     }
-    for (int i = b + tid + 4 * SP_THREADS; i < e; i += SP_THREADS) Wg->elist[b + atomicAdd(&hist[cost_key(i)], 1)] = Wg->list[i] | ((u32)i << 14);
+    for (int i = b + tid + 4 * NT; i < e; i += NT) Wg->elist[b + atomicAdd(&hist[cost_key(i)], 1)] = Wg->list[i] | ((u32)i << 14);
     __syncthreads();
 }
 
@@ -1936,7 +1963,7 @@ __device__ __forceinline__ void sp_row_write(const SpNode* nodes, SpCtx& X, cons
             if (table_ok) {  // uniform over the workgroup
                 // one load per (candidate, turn): the clamped values go to the LDS (the evaluation scratch is free now), and
                 // take_while(p > 0) on the tenpai probs becomes a count of the leading positive turns
-                static_assert(SP_EVAL_LDS_FLOATS >= SP_MAX_CAND * SP_T * 4, "table staging fits the evaluation scratch");
+                static_assert(SP_EVAL_LDS_FLOATS(64) >= SP_MAX_CAND * SP_T * 4, "table staging fits the evaluation scratch");
                 const int n_src = can_discard0 ? n_cand : 1;
                 for (int q = tid; q < n_src * SP_T; q += NT) {
                     const int c = q / SP_T, turn = q % SP_T;
@@ -1988,28 +2015,82 @@ __device__ __noinline__ unsigned long long sp_light_row(const uint32_t* rows, co
     return ret;
 }
 
-__global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
+// ---- promotion (round 6): small pools.  A decision row is pinned to ONE workgroup, and the heaviest rows (~6 k states) need ~3 ms on four
+// wavefronts: with 65,536 tables a workgroup chains ~20 rows and nobody notices, with 4,096 tables the launch lasts as long as its heaviest
+// row while 1,000 of the 1,024 workgroups idle.  What a row will cost is only known once its graph is growing (the best predictor from
+// the table record alone, the candidates' required tiles, leaves 2 ms rows undetected), so the decision is taken THERE: when a workgroup of
+// mj_k_sp finds the level it is about to expand at least SpParams::promo_min[level] states large, it parks the row -- its context goes to the
+// work area's `handoff` block, the area itself (hash set, nodes, lists: everything is in HBM already) is handed over through an entry of
+// the promotion queue after an agent-scope release, and the workgroup continues with a spare area and the next row.  mj_k_sp_wide
+// (SP_WIDE_THREADS threads, one workgroup per CU, launched BEFORE mj_k_sp on the pool's stream while mj_k_sp runs on a second stream)
+// takes the entries in order, acquires, and finishes the row -- remaining expansion levels, evaluation, row output -- with four times the
+// wavefronts.  Nothing flows back.  The results do not depend on who expands which level (a state's values depend on its child list's
+// order, which is the reference's, not on creation order).  Every spin is bounded: a wide workgroup that waits longer than SP_WIDE_TIMEOUT
+// gives up, and a third launch on the pool's stream after both (sweep = the wide kernel again, now with every producer finished) takes
+// whatever entry is left, so the result never depends on the two kernels having run side by side.
+struct SpHandoff {
+    SpCtx X;
+    SpRowInfo R;
+    int row, next_lv;
+};
+static_assert(sizeof(SpHandoff) <= SP_HANDOFF_WORDS * 4 && sizeof(SpHandoff) % 4 == 0, "SpWork::handoff holds an SpHandoff");
+#ifndef SP_WIDE_TIMEOUT
+#define SP_WIDE_TIMEOUT 20000000ll  // wall_clock64 ticks (100 MHz): 200 ms
+#endif
+// The hand-off's two fences (MI355X_MICROARCH.md, inter-workgroup visibility: per-XCD L2s are not coherent with each other, a CU's L1 is never
+// refreshed by another CU's stores).  Producer: every wavefront drains its stores, workgroup barrier, ONE lane releases at agent scope
+// (buffer_wbl2 sc1) and drains again (the compiler may drop the wait behind the write-back), then the relaxed agent-scope flag store.
+// Consumer: one relaxed poll, ONE agent-scope acquire (buffer_inv sc1), workgroup barrier, plain loads.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MJ_EMU)
+#define SP_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SP_RELEASE_AGENT() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define SP_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define SP_SPIN_PAUSE() __builtin_amdgcn_s_sleep(32)
+#else
+#define SP_DRAIN_STORES() ((void)0)
+#define SP_RELEASE_AGENT() ((void)0)
+#define SP_ACQUIRE_AGENT() ((void)0)
+#define SP_SPIN_PAUSE() ((void)0)
+#endif
+
+#ifdef SP_ROWDUMP
+#define SP_DUMP(P) ((P).rowdump != nullptr)
+#else
+#define SP_DUMP(P) false  // (the debug records cost the kernel five VGPR spills)
+#endif
+template <int NT>
+struct SpLds {
+    union Teams {
+        TableOne st;                                 // the decision's table record: read during the row set-up only
+        SpChunk wchunk[NT / SP_NT];                  // expansion / level-0 probe: one chunk per wavefront
+        float ev[SP_EVAL_LDS_FLOATS(NT)];            // evaluation teams (T lanes each)
+        SpWaveArea wave[NT / 64];                    // queue tail: one row without a state graph per wavefront
+    };
+};
+
+template <int NT, bool WIDE, bool PROMO>
+__device__ __forceinline__ void sp_kernel_body(SpParams P) {
     __shared__ SpCtx X;
-    __shared__ int s_row;
+    __shared__ int s_row, s_k;
     __shared__ unsigned long long s_stat[25];  // this workgroup's share of SpParams::err, flushed once (see sp_light_row)
     if (threadIdx.x < 25) s_stat[threadIdx.x] = 0ull;
-    __shared__ union SpTeams {
-        TableOne st;                                 // the decision's table record: read during the row set-up only
-        SpChunk wchunk[SP_THREADS / SP_NT];          // expansion / level-0 probe: one chunk per wavefront
-        float ev[SP_EVAL_LDS_FLOATS];                // evaluation teams (T lanes each)
-        SpWaveArea wave[SP_THREADS / 64];            // queue tail: one row without a state graph per wavefront
-    } s_tm;
+    __shared__ typename SpLds<NT>::Teams s_tm;
 #if SP_CC_N > 0
     __shared__ unsigned long long s_cc[SP_CC_N];  // the child cache of the expansion (sp_expand_chunk)
-    for (int i = threadIdx.x; i < SP_CC_N; i += SP_THREADS) s_cc[i] = 0ull;
+    for (int i = threadIdx.x; i < SP_CC_N; i += NT) s_cc[i] = 0ull;
     unsigned n_graph_rows = 0;
 #endif
-    SpWork* W = P.work + blockIdx.x;
+    // mj_k_sp: workgroup b owns work area b (and moves to spare area grid + k after its k-th promotion); mj_k_sp_wide: the promoted row's area
+    SpWork* W = WIDE ? P.work + P.n_narrow + P.promo_cap + blockIdx.x : P.work + blockIdx.x;
+    SpWork* const W_own = W;
     const int tid_wg = threadIdx.x, tid = tid_wg;
 
     // the hash tags start empty (zeroed once when the work area is allocated); a row's tags carry its epoch, no row clears anything
-    unsigned tag_epoch = W->epoch;  // (uniform; written back when the workgroup leaves the row loop)
+    unsigned tag_epoch = W->epoch;  // (uniform; written back when the workgroup leaves the row loop / parks a row)
+    unsigned own_epoch = tag_epoch;  // (mj_k_sp_wide: the epoch of its own area while it works in a promoted row's)
+    bool main_done = false, drained = false;  // (mj_k_sp_wide, lane 0: the row queue is empty; the last look at the promotion queues)
 
+    const long long t_wg_in = SP_DUMP(P) ? wall_clock64() : 0;
     const long long t_wg0 = P.prof ? wall_clock64() : 0;  // MJ_SP_PROF: workgroup lifetime / queue + reset time (err[19..22])
 #ifndef MJ_EMU
     const long long c_wg0 = P.prof ? clock64() : 0;       // the same lifetime in shader-clock cycles (s_memtime): err[24] / err[19] x 100 MHz = the clock the kernel ran at
@@ -2021,29 +2102,120 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
     for (;;) {
         const int tid = SP_OPQ(2, tid_wg);
         const long long t_a = P.prof ? wall_clock64() : 0;
-        if (tid == 0) s_row = atomicAdd(P.queue, 1);
-        __syncthreads();
-        if (s_row >= n_heavy) { wave_mode = n_heavy < P.n_rows; break; }  // no graph rows left: on to the tail (its own head word)
-        const int row = (int)P.order[s_row];
-        if (P.prof) t_pop += wall_clock64() - t_a;
-        long long t_0 = wall_clock64(), t_1 = t_0, t_2 = t_0, t_3 = t_0, t_4 = t_0;
+        int row, lv_first = 0;
+        SpRowInfo R;
+        long long t_0, t_1, t_2, t_3, t_4;
+        bool promoted = false;  // (mj_k_sp_wide only) this row was parked by a workgroup of mj_k_sp: continue it from its hand-off block
+        if constexpr (WIDE) {
+            // ---- the next row: a promoted one if there is any (the largest first), else one from the row queue like mj_k_sp -- a wide
+            // workgroup never idles while rows are left; when the queue is empty it waits for promotions until every producer has gone
+            if (tid == 0) {
+                int got = 0;  // > 0: promoted (work area + 1); < 0: -(queue position + 1); 0: nothing left
+                const int cap = P.promo_cap / SP_PROMO_LEVELS;
+                long long t_idle = 0;
+                for (;;) {
+                    for (int q = 0; q < SP_PROMO_LEVELS && !got; q++) {
+                        int* const ents = P.queue + SP_Q_PROMO_ENT + q * (SP_PROMO_CAP / SP_PROMO_LEVELS);
+                        int* const head = P.queue + SP_Q_PROMO_HEAD(q) + (P.sweep ? 1 : 0);
+                        for (;;) {
+                            const int h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const int a = min(__hip_atomic_load(P.queue + SP_Q_PROMO_ALLOC(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cap);
+                            if (h >= a) break;
+                            if (atomicCAS(head, h, h + 1) != h) continue;
+                            // entry h is ours; its producer publishes it right behind the allocation (a copy + one release)
+                            const long long t_w = wall_clock64();
+                            int e;
+                            while ((e = __hip_atomic_load(ents + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && !P.sweep &&
+                                   wall_clock64() - t_w < SP_WIDE_TIMEOUT)
+                                SP_SPIN_PAUSE();
+                            if (e == 0 && !P.sweep) atomicAdd(&P.err[25], 1ull);  // (left to the sweep)
+                            if (e > 0 && atomicCAS(ents + h, e, -1) == e) {       // (the sweep skips what the first launch took)
+                                got = e;
+                                break;
+                            }
+                        }
+                    }
+                    if (got || P.sweep) break;
+                    if (!main_done) {
+                        const int r = atomicAdd(P.queue, 1);
+                        if (r < n_heavy) {
+                            got = -(r + 1);
+                            break;
+                        }
+                        main_done = true;
+                    }
+                    // nothing to do right now.  Every producer gone (their entries were released before they arrived at the DONE word) and
+                    // still nothing => finished
+                    if (__hip_atomic_load(P.queue + SP_Q_PROMO_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.n_narrow) {
+                        if (drained) break;
+                        drained = true;  // (one more look at the queues)
+                        continue;
+                    }
+                    const long long now = wall_clock64();
+                    if (t_idle == 0) t_idle = now;
+                    else if (now - t_idle > SP_WIDE_TIMEOUT) {  // the two kernels do not overlap (or mj_k_sp has not started): give up, the sweep follows
+                        atomicAdd(&P.err[25], 1ull);
+                        break;
+                    }
+                    SP_SPIN_PAUSE();
+                }
+                s_row = got;
+                if (got > 0) SP_ACQUIRE_AGENT();  // the producer's release: this CU reads the area for the first time
+            }
+            __syncthreads();
+            if (s_row == 0) break;
+            if (P.prof) t_pop += wall_clock64() - t_a;
+            t_0 = wall_clock64();
+            if (s_row > 0) {
+                promoted = true;
+                if (tid == 0) atomicAdd(&P.err[P.sweep ? 27 : 26], 1ull);  // rows finished here (by the sweep launch: the two kernels did not overlap)
+                W = P.work + (s_row - 1);
+                SP_HBM const u32* src = (SP_HBM const u32*)W->handoff;
+                u32* dx = reinterpret_cast<u32*>(&X);
+                for (int i = tid; i < (int)(sizeof(SpCtx) / 4); i += NT) dx[i] = src[i];
+                const SpHandoff* H = reinterpret_cast<const SpHandoff*>(W->handoff);
+                R = H->R;
+                row = H->row;
+                lv_first = H->next_lv;
+                __syncthreads();
+                tag_epoch = X.tag_epoch;
+            } else {
+                W = W_own;
+                tag_epoch = own_epoch;
+                row = (int)P.order[-s_row - 1];
+            }
+            t_1 = t_2 = t_3 = t_4 = t_0;
+        } else {
+            if (tid == 0) s_row = atomicAdd(P.queue, 1);
+            __syncthreads();
+            if (s_row >= n_heavy) { wave_mode = n_heavy < P.n_rows; break; }  // no graph rows left: on to the tail (its own head word)
+            row = (int)P.order[s_row];
+            if (P.prof) t_pop += wall_clock64() - t_a;
+            t_0 = wall_clock64();
+            t_1 = t_2 = t_3 = t_4 = t_0;
+        }
         float* out = P.obs + (size_t)row * (1012 * 34);
-        const SpRowInfo R = sp_row_front<false, SP_THREADS>(P.rows, P.snap, W, X, &s_tm.st, tid, row, out, P.prof);
-        if (!R.ok) continue;
+        if (!promoted) {
+            R = sp_row_front<false, NT>(P.rows, P.snap, W, X, &s_tm.st, tid, row, out, P.prof);
+            if (!R.ok) continue;
+        }
         const int cur_shanten = R.cur_shanten, n_cand = R.n_cand, T = R.T;
         const bool with_probs = R.with_probs, can_discard = R.can_discard;
         const SpState root = R.root;
         // fewer draws left than the shanten number: tenpai / win / EV are exactly zero for every candidate (reaching tenpai
         // takes cur_shanten draws), so the state graph need not be built at all
-        t_1 = wall_clock64();
-        t_2 = t_3 = t_4 = t_1;
+        if (!promoted) {
+            t_1 = wall_clock64();
+            t_2 = t_3 = t_4 = t_1;
+        }
+        bool parked = false;
         if (with_probs) {
 #if SP_CC_N > 0
             // a new row = a new epoch of the child cache (8 bits, 1..255; when they have gone round the cache is wiped)
             n_graph_rows++;
             if ((n_graph_rows & 255u) == 0u) {
                 n_graph_rows++;
-                for (int i = tid; i < SP_CC_N; i += SP_THREADS) s_cc[i] = 0ull;
+                for (int i = tid; i < SP_CC_N; i += NT) s_cc[i] = 0ull;
             }
             if (tid == 0) {
                 X.cc = s_cc;
@@ -2052,35 +2224,79 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
 #else
             if (tid == 0) X.cc = nullptr;
 #endif
-            // a new row = a new epoch of the hash tags
-            if (tag_epoch >= SP_EPOCH_WRAP) {  // wrapped (once in 2 M rows): wipe the table, start over
-                for (int i = tid; i < SP_CAP; i += SP_THREADS) W->tag[i] = 0ull;
-                tag_epoch = 0;
+            if (promoted) {
+                if (tid == 0) {
+                    X.prof = P.prof;
+                    for (int k = 0; k < 8; k++) X.pt[k] = 0ull;  // (the first workgroup flushed its share of the pass timers)
+                }
+                __syncthreads();
+            } else {
+                // a new row = a new epoch of the hash tags
+                if (tag_epoch >= SP_EPOCH_WRAP) {  // wrapped (once in 2 M rows): wipe the table, start over
+                    for (int i = tid; i < SP_CAP; i += NT) W->tag[i] = 0ull;
+                    tag_epoch = 0;
+                    __syncthreads();
+                }
+                tag_epoch++;
+                if (tid == 0) X.tag_epoch = tag_epoch;
+                __syncthreads();
+                // root states = level cur_shanten
+                if (tid < n_cand) {  // one lane per candidate: the claims (one L2 atomic round trip each) run side by side
+                    const int c = tid;
+                    SpState s = root;
+                    if (can_discard) sp_discard(s, X.cand_tile[c]);
+                    X.cand_slot[c] = sp_insert(W, &X, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), s, -1, -1);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    X.lvl_begin[cur_shanten] = 0;
+                    X.lvl_end[cur_shanten] = X.n_list;
+                }
                 __syncthreads();
             }
-            tag_epoch++;
-            if (tid == 0) X.tag_epoch = tag_epoch;
-            __syncthreads();
-            // root states = level cur_shanten
-            if (tid < n_cand) {  // one lane per candidate: the claims (one L2 atomic round trip each) run side by side
-                const int c = tid;
-                SpState s = root;
-                if (can_discard) sp_discard(s, X.cand_tile[c]);
-                X.cand_slot[c] = sp_insert(W, &X, sp_dk_add(0ull, -1, can_discard ? X.cand_tile[c] : -1), s, -1, -1);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                X.lvl_begin[cur_shanten] = 0;
-                X.lvl_end[cur_shanten] = X.n_list;
-            }
-            __syncthreads();
             // expand top-down
-            for (int lv = cur_shanten; lv >= 1; lv--) {
+            for (int lv = promoted ? lv_first : cur_shanten; lv >= 1; lv--) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
+                if constexpr (PROMO) {  // (mj_k_sp_promo only: compiled into mj_k_sp the parking code costs the full-size pool 2.7 % -- register allocation)
+                    // ---- promotion: this level is large (the ones below it will be larger) and a wide workgroup may take the row from here
+                    if (P.promo_cap > 0 && lv < cur_shanten && e - b >= P.promo_min[lv] && !X.overflow) {
+                        const int pq = e - b >= 2 * P.promo_min[lv] ? 0 : 1;  // the largest rows have their own queue: wide workgroups take them first
+                        if (tid == 0) s_k = atomicAdd(P.queue + SP_Q_PROMO_ALLOC(pq), 1);
+                        __syncthreads();
+                        const int k = s_k;
+                        if (k < P.promo_cap / SP_PROMO_LEVELS) {
+                            {
+                                const u32* sx = reinterpret_cast<const u32*>(&X);
+                                SP_HBM u32* dst = (SP_HBM u32*)W->handoff;
+                                for (int i = tid; i < (int)(sizeof(SpCtx) / 4); i += NT) dst[i] = sx[i];
+                                if (tid == 0) {
+                                    SpHandoff* H = reinterpret_cast<SpHandoff*>(W->handoff);
+                                    H->R = R;
+                                    H->row = row;
+                                    H->next_lv = lv;
+                                    W->epoch = tag_epoch;
+                                    if (SP_DUMP(P)) P.rowdump[(size_t)row * 12 + 8] = (uint32_t)t_0, P.rowdump[(size_t)row * 12 + 9] = (uint32_t)wall_clock64();
+                                }
+                            }
+                            // every wavefront's stores of this row (nodes, keys, lists, pools ...) are in L2 before lane 0 releases them
+                            SP_DRAIN_STORES();
+                            __syncthreads();
+                            if (tid == 0) {
+                                SP_RELEASE_AGENT();
+                                __hip_atomic_store(P.queue + SP_Q_PROMO_ENT + pq * (SP_PROMO_CAP / SP_PROMO_LEVELS) + k, (int)(W - P.work) + 1, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            W = P.work + gridDim.x + pq * (P.promo_cap / SP_PROMO_LEVELS) + k;  // the spare area of this promotion
+                            tag_epoch = W->epoch;
+                            parked = true;
+                            break;
+                        }
+                    }
+                }
                 // every wavefront its own chunks; a level too small for four full chunks is split four ways (a chunk pass costs
                 // the same for 4 states as for 16, so idle wavefronts are the only thing to lose)
-                const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
-                for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
+                const int ns = min(SP_NS, max(1, (e - b + NT / SP_NT - 1) / (NT / SP_NT)));
+                for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (NT / SP_NT))
                     sp_expand_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(ns, e - c0), lv);
                 __syncthreads();
                 if (tid == 0) {
@@ -2091,25 +2307,26 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             }
             t_2 = wall_clock64();
             // evaluate bottom-up
+            if (!parked)
             for (int lv = 0; lv <= cur_shanten; lv++) {
                 const int b = X.lvl_begin[lv], e = X.lvl_end[lv];
                 if (lv == 0) {
                     if (tid == 0) X.n_items = 0;
                     __syncthreads();
-                    const int ns = min(SP_NS, max(1, (e - b + SP_THREADS / SP_NT - 1) / (SP_THREADS / SP_NT)));
-                    for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (SP_THREADS / SP_NT))
+                    const int ns = min(SP_NS, max(1, (e - b + NT / SP_NT - 1) / (NT / SP_NT)));
+                    for (int c0 = b + ns * (tid / SP_NT); c0 < e; c0 += ns * (NT / SP_NT))
                         sp_l0_probe_chunk(W, &X, &s_tm.wchunk[tid / SP_NT], c0, min(ns, e - c0));
                     __syncthreads();
                     const long long t_2a = wall_clock64();
                     const int n_items = min(X.n_items, SP_ITEMS);
-                    for (int i = tid; i < n_items; i += SP_THREADS) sp_l0_score(c_mj_tables, W, &X, W->items[i], i);
+                    for (int i = tid; i < n_items; i += NT) sp_l0_score(c_mj_tables, W, &X, W->items[i], i);
                     __syncthreads();
                     if (P.prof && tid == 0) {  // level-0 sub-phases: probe, scoring (the sum is the rest of the level-0 timer)
                         X.pt[7] += (unsigned long long)(t_2a - t_2);
                         s_stat[18] += (unsigned long long)(wall_clock64() - t_2a);
                     }
                 }
-                sp_sort_level(W, reinterpret_cast<int*>(s_tm.ev), b, e);
+                sp_sort_level<NT>(W, reinterpret_cast<int*>(s_tm.ev), b, e);
                 {
                     // teams of exactly T lanes, floor(64 / T) per wavefront (the leftover lanes of a wavefront idle)
                     // ... of the turns that can be reached at this level: the first `off` turns are dead
@@ -2119,7 +2336,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                     const long long t_ev0 = P.prof ? wall_clock64() : 0;
                     if (lv == 0) {
                         const int tpw0 = min(64 / TW, SP_EVW_WAVE_FLOATS / (SP_EV_ENT * SP_EV0_STRIDE));
-                        const int team0 = (tid >> 6) * tpw0 + tw, n_teams0 = (SP_THREADS / 64) * tpw0;
+                        const int team0 = (tid >> 6) * tpw0 + tw, n_teams0 = (NT / 64) * tpw0;
                         const bool on0 = tw < tpw0;
                         if (T <= 8) sp_eval_wave0<8>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
                         else if (T <= 16) sp_eval_wave0<16>(W, &X, wl_lds, b + team0, e, n_teams0, ln, off, tw, on0);
@@ -2127,7 +2344,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
                     } else {
                         // levels > 0: the whole wavefront in lock-step (sp_eval_wave), its own team geometry (LDS per team differs)
                         const int tpw2 = min(64 / TW, SP_EVW_WAVE_FLOATS / sp_evw_team_floats(T));
-                        const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (SP_THREADS / 64) * tpw2;
+                        const int team2 = (tid >> 6) * tpw2 + tw, n_teams2 = (NT / 64) * tpw2;
                         const bool on = tw < tpw2;
                         if (T <= 8) {
                             if (lv == 1) sp_eval_wave<8, 1>(W, &X, wl_lds, b + team2, e, n_teams2, ln, off, tw, on);
@@ -2148,32 +2365,59 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             t_4 = wall_clock64();
         }
 
-        sp_row_write<false, SP_THREADS>(W->node, X, R, tid, out, s_tm.ev);
+        if (!parked) sp_row_write<false, NT>(W->node, X, R, tid, out, s_tm.ev);
         __syncthreads();
         if (tid == 0) {
             long long t_5 = wall_clock64();
-            s_stat[1] += 1ull;
+            if (!parked) s_stat[1] += 1ull;
             s_stat[2] += (unsigned long long)(t_1 - t_0);
             if (with_probs) {
                 s_stat[3] += (unsigned long long)(t_2 - t_1);
-                s_stat[4] += (unsigned long long)(t_3 - t_2);
-                s_stat[5] += (unsigned long long)(t_4 - t_3);
-                s_stat[6] += (unsigned long long)(t_5 - t_4);
-                s_stat[7] += (unsigned long long)X.n_list;
+                if (!parked) {
+                    s_stat[4] += (unsigned long long)(t_3 - t_2);
+                    s_stat[5] += (unsigned long long)(t_4 - t_3);
+                    s_stat[6] += (unsigned long long)(t_5 - t_4);
+                    s_stat[7] += (unsigned long long)X.n_list;
+                    s_stat[15] += (unsigned long long)X.n_pool;   // child-list entries (edges of the state graph)
+                    s_stat[16] += (unsigned long long)X.n_items;  // level-0 draw entries scored
+                }
                 if (P.prof)
                     for (int k = 0; k < 7; k++) s_stat[8 + k] += X.pt[k];  // expansion pass timers (MJ_SP_PROF)
                 if (P.prof) s_stat[17] += X.pt[7];                          // level-0 probe
-                s_stat[15] += (unsigned long long)X.n_pool;   // child-list entries (edges of the state graph)
-                s_stat[16] += (unsigned long long)X.n_items;  // level-0 draw entries scored
             }
+            if (SP_DUMP(P) && !parked) {  // (debug) queue position | wide << 31, shanten | T << 8 | n_cand << 16 | can_discard << 24, sum of the candidates' required kinds, states, edges, l0 items, ticks, level sizes
+                uint32_t* d = P.rowdump + (size_t)row * 12;
+                int nreq = 0;
+                for (int c = 0; c < n_cand; c++) nreq += X.cand_nreq[c];
+                d[0] = (uint32_t)(WIDE ? 0x40000000 | (promoted ? 0x20000000 : 0) : s_row); d[1] = (uint32_t)(cur_shanten | T << 8 | n_cand << 16 | (int)can_discard << 24); d[2] = (uint32_t)nreq;
+                d[3] = with_probs ? (uint32_t)X.n_list : 0u; d[4] = with_probs ? (uint32_t)X.n_pool : 0u; d[5] = with_probs ? (uint32_t)X.n_items : 0u;
+                d[6] = (uint32_t)(t_5 - t_0);
+                if (!promoted) d[8] = (uint32_t)t_0, d[9] = 0u;
+                d[10] = (uint32_t)t_0; d[11] = (uint32_t)t_5;
+                d[7] = 0x80000000u | (with_probs ? (uint32_t)min(X.lvl_end[1] - X.lvl_begin[1], 32767) | (uint32_t)min(X.lvl_end[2] - X.lvl_begin[2], 32767) << 15 : 0u);
+            }
+        }
+        if constexpr (WIDE) {
+            if (!promoted) own_epoch = tag_epoch;
         }
         // ---- the hash set needs no reset (tag epochs); a row that overflowed it is counted
         const long long t_r = P.prof ? wall_clock64() : 0;
-        if (X.overflow && tid == 0) s_stat[0] += 1ull;
+        if (X.overflow && tid == 0 && !parked) s_stat[0] += 1ull;
         __syncthreads();
         if (P.prof) t_reset += wall_clock64() - t_r;
     }
-    if (tid == 0) W->epoch = tag_epoch;
+    if constexpr (WIDE) {
+        if (tid == 0) W_own->epoch = own_epoch;
+    } else {
+        if (tid == 0) {
+            W->epoch = tag_epoch;
+            if (PROMO && P.promo_cap > 0) {  // arrival at the DONE word, behind this workgroup's entry stores (agent-scope stores, complete once vmcnt says so:
+                                    // the areas they point to were released when they were parked -- no second write-back of the XCD's L2 here)
+                SP_DRAIN_STORES();
+                __hip_atomic_fetch_add(P.queue + SP_Q_PROMO_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if (P.prof && tid == 0) {
         const unsigned long long life = (unsigned long long)(wall_clock64() - t_wg0);
         s_stat[19] += life;
@@ -2185,11 +2429,16 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
         s_stat[22] += (unsigned long long)t_reset;
     }
     __syncthreads();  // (every thread leaves the row loop at the same pop)
+    if (SP_DUMP(P) && tid == 0) {  // (debug) first workgroup start / last end of the graph-row loops, both kernels
+        atomicMin(&P.err[28], (unsigned long long)t_wg_in);
+        atomicMax(&P.err[WIDE ? 30 : 29], (unsigned long long)wall_clock64());
+    }
     if (tid < 25 && tid != 20 && s_stat[tid]) atomicAdd(&P.err[tid], s_stat[tid]);  // the workgroup's statistics, once
     // ---- the tail of the queue: every wavefront takes its own rows (set-up + encoder only, no workgroup barrier any more)
     // The tail has its own head word (another 128-byte line than the heavy rows' head) and is popped SP_TAIL_BATCH rows at a time:
     // ~46 k light rows per launch against 4,096 wavefronts that need ~10 us per row ask for ~400 pops per microsecond, and one word
     // serves ~88 (MI355X_MICROARCH.md, dequeue row) -- one row per atomic made the tail dequeue-bound.
+    if constexpr (!WIDE) {
     if (wave_mode) {
         const int wv = tid >> 6, lane = tid & 63;
         unsigned long long w_rows = 0, w_ticks = 0, w_over = 0;
@@ -2211,5 +2460,12 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) {
             atomicAdd(&P.err[2], w_ticks);
             if (w_over) atomicAdd(&P.err[0], w_over);
         }
+        if (SP_DUMP(P) && lane == 0) atomicMax(&P.err[31], (unsigned long long)wall_clock64());  // (debug) end of the tail
+    }
     }
 }
+
+__global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp(SpParams P) { sp_kernel_body<SP_THREADS, false, false>(P); }
+// the small-pool pair: mj_k_sp with the parking code, and the wide kernel that finishes parked rows / takes rows of the queue itself
+__global__ __launch_bounds__(SP_THREADS, SP_WPS) void mj_k_sp_promo(SpParams P) { sp_kernel_body<SP_THREADS, false, true>(P); }
+__global__ __launch_bounds__(SP_WIDE_THREADS, SP_WPS) void mj_k_sp_wide(SpParams P) { sp_kernel_body<SP_WIDE_THREADS, true, false>(P); }

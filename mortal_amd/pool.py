@@ -279,6 +279,15 @@ class TablePool:
         check(self._L.mj_sp_phase_ticks(self.h, out, self._stream()))
         return dict(zip(("overflow", "rows", "setup", "expand", "level0", "eval", "write", "states"), (int(x) for x in out)))
 
+    def set_sp_schedule(self, mode=-2, max_rows=0, wide_grid=0, min_level1=0, min_level2=0):
+        """Small-pool schedule of the SP kernel (include/mortal_amd.h mj_pool_set_sp_schedule): mode -1 auto / 0 never / 1 always."""
+        check(self._L.mj_pool_set_sp_schedule(self.h, mode, max_rows, wide_grid, min_level1, min_level2))
+
+    def sp_schedule_stats(self):
+        out = (C.c_uint64 * 4)()
+        check(self._L.mj_sp_schedule_stats(self.h, out, self._stream()))
+        return dict(zip(("hybrid_launches", "rows_promoted", "rows_swept", "wide_gave_up"), (int(x) for x in out)))
+
     def debug_table(self, table):
         size = self._L.mj_debug_table_size()
         buf = (C.c_uint8 * size)()

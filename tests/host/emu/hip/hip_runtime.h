@@ -411,6 +411,9 @@ inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); 
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return 0; }
 template <class T> inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n) { memcpy((void*)&sym, src, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipStreamNonBlocking 1u
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }

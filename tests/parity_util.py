@@ -306,6 +306,7 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     assert code == 0, f"gpu table {t} in error {code}"
     scores_g, done_g = pool.results()
     cnt = pool.counters()
+    stats["sp_schedule"] = pool.sp_schedule_stats()  # (small-pool schedule of mj_k_sp: rows parked / finished by mj_k_sp_wide)
     if refill:
         # every hanchan the oracle finished (slot g, generation k) is game id g + k * n_tables on the device
         assert cnt["steps"] == arena.steps, (cnt["steps"], arena.steps)

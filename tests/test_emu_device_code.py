@@ -232,3 +232,29 @@ def test_emu_tag_epoch_wrap_in_a_variant_build():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_emu_device_code.py"), "-x", "-q", "-k",
                           "one_workgroup_takes_every_row", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_emu_lockstep_v4_every_large_row_promoted_to_the_wide_kernel(oracle, emu, monkeypatch):
+    """Small-pool schedule of round 6 (mj_sp.hip "promotion"): with MJ_SP_WIDE=1 and level thresholds of 1 every row with two or more
+    levels is parked by its 256-thread workgroup after the first expansion and finished by mj_k_sp_wide (1,024 threads) from the hand-off
+    block of its work area — remaining expansion levels, evaluation and row output.  Same f32 bits as the oracle; the emulator runs the
+    launches one after the other, so the wide kernel takes the rows as the sweep launch does on the GPU."""
+    monkeypatch.setenv("MJ_SP_WIDE", "1")
+    monkeypatch.setenv("MJ_SP_PROMO_MIN1", "1")
+    monkeypatch.setenv("MJ_SP_PROMO_MIN2", "1")
+    st = parity_util.run_lockstep(oracle, 4, version=4, max_cycles=70, obs_every=1, pool_cls=emu, sp_rows_checked=True,
+                                  policy="greedy", verbose=False)
+    assert st["obs_checked"] > 250 and st["counters"]["sp_overflow"] == 0
+    assert st["sp_schedule"]["hybrid_launches"] > 50 and st["sp_schedule"]["rows_swept"] > 100, st["sp_schedule"]
+    # one workgroup chaining rows: after a promotion it continues in a spare work area (its tag epoch, its cache)
+    monkeypatch.setenv("MJ_SP_GRID", "1")
+    st = parity_util.run_lockstep(oracle, 4, version=4, max_cycles=50, obs_every=1, pool_cls=emu, sp_rows_checked=True,
+                                  policy="random", verbose=False)
+    assert st["obs_checked"] > 150 and st["counters"]["sp_overflow"] == 0 and st["sp_schedule"]["rows_swept"] > 30, st["sp_schedule"]
+    # the wide kernel as a worker of the row queue (on the GPU it takes rows from the queue whenever no promoted row waits): every row
+    # with a state graph from set-up to output by 1,024 threads
+    monkeypatch.delenv("MJ_SP_GRID")
+    monkeypatch.setenv("MJ_SP_WIDE_ALL_ROWS", "1")
+    st = parity_util.run_lockstep(oracle, 4, version=4, max_cycles=50, obs_every=1, pool_cls=emu, sp_rows_checked=True,
+                                  policy="greedy", verbose=False)
+    assert st["obs_checked"] > 150 and st["counters"]["sp_overflow"] == 0 and st["sp_schedule"]["rows_swept"] == 0, st["sp_schedule"]

@@ -33,6 +33,27 @@ def test_lockstep_4096_tables_v4_obs_with_sp(oracle):
     st = parity_util.run_lockstep(oracle, 4096, version=4, max_cycles=420, obs_cycles={2, 37, 111, 222, 333, 419},
                                   sp_rows_checked=True, threads=16)
     assert st["obs_checked"] > 15000 and st["counters"]["sp_overflow"] == 0
+    # a pool of this size runs under the small-pool schedule (round 6): rows with a large state graph were parked by mj_k_sp_promo and
+    # finished by mj_k_sp_wide -- with the default thresholds, in every launch of the SP-heavy first turns
+    sc = st["sp_schedule"]
+    assert sc["hybrid_launches"] >= 420 and sc["rows_promoted"] + sc["rows_swept"] > 1000, sc
+
+
+def test_lockstep_small_pool_schedule_parks_every_row_it_can(oracle, monkeypatch):
+    """The small-pool schedule with thresholds of a few states (mj_sp.hip "promotion"; MJ_SP_WIDE=1, level sizes 24 / 6): nearly every row
+    with two or more levels is parked after its first or second expansion and finished by mj_k_sp_wide from the hand-off block, while the
+    wide workgroups take whole rows of the queue in between -- REAL concurrency of the two kernels on two streams (the emulator runs them
+    one after the other), agent-scope release / acquire across CUs and XCDs, spare work areas with their own tag epochs, two promotion
+    queues.  Rows, masks and the whole v4 obs against the oracle under refill + stagger (every phase of a hanchan in the queue)."""
+    monkeypatch.setenv("MJ_SP_WIDE", "1")
+    monkeypatch.setenv("MJ_SP_PROMO_MIN1", "24")
+    monkeypatch.setenv("MJ_SP_PROMO_MIN2", "6")
+    monkeypatch.setenv("MJ_SP_WIDE_GRID", "48")
+    st = parity_util.run_lockstep(oracle, 512, version=4, max_cycles=600, obs_every=7, sp_rows_checked=True, refill=128, stagger=300,
+                                  min_games=99, deal_algo=1, threads=16)
+    sc = st["sp_schedule"]
+    assert st["obs_checked"] > 20000 and st["counters"]["sp_overflow"] == 0
+    assert sc["rows_promoted"] > 20000 and sc["wide_gave_up"] == 0, sc
 
 
 def test_lockstep_rand09_deal(oracle):
