@@ -758,6 +758,27 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
                     HIP_OK(hipStreamCreateWithFlags(&P->sp_stream2, hipStreamNonBlocking));
                     HIP_OK(hipEventCreateWithFlags(&P->sp_ev_fork, hipEventDisableTiming));
                     HIP_OK(hipEventCreateWithFlags(&P->sp_ev_join, hipEventDisableTiming));
+                    // One empty launch of the pair now: the HIP runtime sizes a queue's scratch at the first launch that needs it, and a caller
+                    // whose allocator has taken the whole HBM by then (torch's caching allocator under a growing batch) turns that into
+                    // HSA_STATUS_ERROR_OUT_OF_RESOURCES in the middle of a run -- at pool set-up it is an ordinary, early failure.
+                    HIP_OK(hipMemsetAsync(P->sp_queue, 0, SP_Q_WORDS * sizeof(int), s));
+                    HIP_OK(hipStreamSynchronize(s));
+                    SpParams w{};
+                    w.snap = P->snap;
+                    w.rows = P->rows[agent & 1];
+                    w.n_rows = 0;
+                    w.tables = g_tables.dev;
+                    w.obs = obs;
+                    w.work = P->sp_work;
+                    w.queue = P->sp_queue;
+                    w.order = P->sp_order;
+                    w.err = P->sp_err;
+                    w.sweep = 1;
+                    hipLaunchKernelGGL(mj_k_sp_wide, dim3(1), dim3(SP_WIDE_THREADS), 0, s, w);
+                    hipLaunchKernelGGL(mj_k_sp_promo, dim3(1), dim3(SP_THREADS), 0, P->sp_stream2, w);
+                    HIP_OK(hipStreamSynchronize(P->sp_stream2));
+                    HIP_OK(hipStreamSynchronize(s));
+                    HIP_OK(hipGetLastError());
                 }
             }
             HIP_OK(hipMemsetAsync(P->sp_queue, 0, SP_Q_WORDS * sizeof(int), s));

@@ -146,6 +146,7 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
     n_cmp = C if (version != 4 or sp_rows_checked) else 889
     actions = q_dev = None
     stats = dict(cycles=0, rows=0, obs_checked=0)
+    obs_buf = [None, None]  # the device's obs / mask buffers, reused across cycles
     for cycle in range(max_cycles):
         if starts is not None:
             for g in np.flatnonzero(starts_np == cycle).tolist():
@@ -180,8 +181,17 @@ def run_lockstep(oracle, n_tables, version, max_cycles=4000, seeds=None, compare
         # buffers poisoned before the encode: every cell of the observation has to be WRITTEN by a kernel (the encoder owns rows
         # 0..888 of obs v4 and mj_k_sp the rest), nothing may rely on what the allocator handed out
         n_g = pool.n_rows[0]
-        obs_g = torch.full((n_g, OBS_ROWS[pool.versions[0]], 34), float("nan"), dtype=torch.float32, device=pool.device)
-        masks_g = torch.ones((n_g, 46), dtype=torch.bool, device=pool.device)
+        # (ONE buffer that grows geometrically: a fresh torch.full of a slightly larger size every cycle of a staggered start makes torch's
+        # caching allocator keep ~3,000 blocks of distinct sizes -- it fills the 288 GB, and the HIP runtime's own next allocation,
+        # e.g. the scratch of a kernel's first launch, aborts the process with HSA_STATUS_ERROR_OUT_OF_RESOURCES)
+        C_g = OBS_ROWS[pool.versions[0]]
+        if obs_buf[0] is None or obs_buf[0].shape[0] < n_g:
+            obs_buf[0] = obs_buf[1] = None
+            cap_g = max(n_g + n_g // 4, 64)
+            obs_buf[0] = torch.empty((cap_g, C_g, 34), dtype=torch.float32, device=pool.device)
+            obs_buf[1] = torch.empty((cap_g, 46), dtype=torch.bool, device=pool.device)
+        obs_g = obs_buf[0][:n_g].fill_(float("nan"))
+        masks_g = obs_buf[1][:n_g].fill_(True)
         obs_g, masks_g = pool.encode(0, obs_g, masks_g)
         want_obs = compare_obs and ((cycle in obs_cycles) if obs_cycles is not None else (cycle % obs_every == 0))
         sliced = bool(want_obs and obs_slice and n > obs_slice)
