@@ -11,7 +11,9 @@ import sys
 import numpy as np
 import pytest
 
-REF = "/root/reference/mortal"
+REF = os.environ.get("MORTAL_REF_DIR", "/root/reference/mortal")
+REAL = os.environ.get("MORTAL_AMD_CFG0_REAL") == "1"  # tools/r06_cfg0_gpu.sh: the real libmortal_amd.so and the networks on cuda:0
+DEVICE = "cuda:0" if REAL else "cpu"
 KEY = 0xD5DFAA4CEF265CD7
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "tests", "host")
@@ -37,9 +39,9 @@ def _engine(ref_engine, ref_model, version, seed, name, **kw):
     import torch
 
     torch.manual_seed(seed)
-    brain = ref_model.Brain(version=version, conv_channels=16, num_blocks=1)  # "random-init tiny model"
-    dqn = ref_model.DQN(version=version)
-    return ref_engine.MortalEngine(brain, dqn, is_oracle=False, version=version, device=torch.device("cpu"), name=name,
+    brain = ref_model.Brain(version=version, conv_channels=16, num_blocks=1).to(DEVICE)  # "random-init tiny model"
+    dqn = ref_model.DQN(version=version).to(DEVICE)
+    return ref_engine.MortalEngine(brain, dqn, is_oracle=False, version=version, device=torch.device(DEVICE), name=name,
                                    enable_amp=False, enable_quick_eval=True, enable_rule_based_agari_guard=False, **kw)
 
 
@@ -71,7 +73,6 @@ def _oracle_rankings(oracle, chal, cham, seed_start, seed_count, version, deal_a
 
 @pytest.mark.parametrize("version", [4, 2])
 def test_reference_engine_plays_one_vs_three(oracle, ref_modules, version):
-    import emu_pool
     from libriichi.arena import OneVsThree
 
     from mortal_amd import arena as A
@@ -80,7 +81,10 @@ def test_reference_engine_plays_one_vs_three(oracle, ref_modules, version):
     chal = _engine(ref_engine, ref_model, version, 1, "challenger")
     cham = _engine(ref_engine, ref_model, version, 2, "champion")
     old = A.BatchRunner.pool_cls
-    A.BatchRunner.pool_cls = emu_pool.make_pool_class()
+    if not REAL:  # (REAL: the product's own TablePool over libmortal_amd.so)
+        import emu_pool
+
+        A.BatchRunner.pool_cls = emu_pool.make_pool_class()
     try:
         env = OneVsThree(disable_progress_bar=True)
         got = env.py_vs_py(challenger=chal, champion=cham, seed_start=(10000, KEY), seed_count=1)
@@ -90,3 +94,4 @@ def test_reference_engine_plays_one_vs_three(oracle, ref_modules, version):
 
     want = _oracle_rankings(oracle, chal, cham, (10000, KEY), 1, version, default_deal_algo())
     assert sum(got) == 4 and got == want
+    print(f"reference engine.py + model.py, py_vs_py v{version} on {'libmortal_amd.so, ' + DEVICE if REAL else 'the host emulator'}: rankings {got} == oracle loop")
