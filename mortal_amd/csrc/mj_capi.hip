@@ -119,7 +119,10 @@ std::vector<float> build_rbf(int n_max, int cap, int intervals) {
 size_t enc_lds_bytes(int version) {
     int C = enc_rows_written(version);
     int tile_rows = ((C + ENC_PASSES - 1) / ENC_PASSES + 1) & ~1;
-    return (size_t)tile_rows * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + sizeof(EncDerived);
+    // MJ_ENC_LDS_PAD (measurement only): extra dynamic LDS per workgroup = fewer resident workgroups per CU (round 6: the encoder is FASTER
+    // with four than with five or six -- concurrent write streams, not occupancy, limit it)
+    static const size_t pad = getenv("MJ_ENC_LDS_PAD") ? (size_t)atoi(getenv("MJ_ENC_LDS_PAD")) : 0;
+    return (size_t)tile_rows * 34 * 4 + ((sizeof(TableOne) + 15) & ~(size_t)15) + sizeof(EncDerived) + pad;
 }
 
 std::vector<MjGatherEnt> build_gather() {
@@ -703,11 +706,17 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
         HIP_OK(hipEventCreate(&e1));
         HIP_OK(hipEventRecord(e0, s));
     }
+#if ENC_PERSIST
+    static const int enc_grid_max = getenv("MJ_ENC_GRID") ? std::max(1, atoi(getenv("MJ_ENC_GRID"))) : 256 * ENC_WPS;  // persistent: ENC_WPS workgroups per CU
+    const int egrid = std::min(n, enc_grid_max);
+#else
+    const int egrid = n;
+#endif
     switch (ep.version) {
-        case 1: hipLaunchKernelGGL(mj_k_encode<1>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
-        case 2: hipLaunchKernelGGL(mj_k_encode<2>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
-        case 3: hipLaunchKernelGGL(mj_k_encode<3>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
-        default: hipLaunchKernelGGL(mj_k_encode<4>, dim3(n), dim3(ENC_THREADS), lds, s, ep); break;
+        case 1: hipLaunchKernelGGL(mj_k_encode<1>, dim3(egrid), dim3(ENC_THREADS), lds, s, ep); break;
+        case 2: hipLaunchKernelGGL(mj_k_encode<2>, dim3(egrid), dim3(ENC_THREADS), lds, s, ep); break;
+        case 3: hipLaunchKernelGGL(mj_k_encode<3>, dim3(egrid), dim3(ENC_THREADS), lds, s, ep); break;
+        default: hipLaunchKernelGGL(mj_k_encode<4>, dim3(egrid), dim3(ENC_THREADS), lds, s, ep); break;
     }
     if (P->timing) {
         HIP_OK(hipEventRecord(e1, s));
