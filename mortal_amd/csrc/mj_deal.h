@@ -46,9 +46,21 @@ MJDN void keccak_f(u64 a[25]) {
 // every link of that chain costs a memory round trip (the deal was the critical path of mj_k_step: a wavefront with one
 // dealing lane ran 3x as long as one without), in LDS it costs ~100 cycles.
 #define DEAL_LANES 64
+struct DealPre {  // a dealt kyoku's four hands with their shanten numbers, computed by four lanes of the deal service (deal_wall_coop)
+    u32 hand[4][4];   // hand.mp / hand.sz as two dwords each
+    u8 akas[4];
+    signed char shanten[4];
+};
 struct DealScratch {
     u8 wall[136][DEAL_LANES];
     u32 rng[16][DEAL_LANES];
+    // the wave-cooperative deal (round 6): one table at a time, all 64 lanes
+    alignas(16) u8 cw[144];   // the wall being shuffled
+    u8 cres[144];             // the 136 swap partners
+    u32 crng[64];             // four ChaCha12 blocks
+    u32 cchunk[32];           // the 28 chunk values of the IncreasingUniform sampler
+    u64 cseed[4];             // SHA3-256 of (nonce, key, kyoku, honba)
+    DealPre pre[DEAL_LANES];  // per pool lane: what the service hands to the lane's kyoku_init
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MJ_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
@@ -201,4 +213,173 @@ MJDN void deal_wall(u8* wall, int stride, DealScratch* S, int lane, u64 nonce, u
         }
     }
     for (int i = 0; i < 136; i++) wall[i * stride] = w[i * WS];
+}
+
+// ---- The deal as a service of the whole wavefront (round 6).  mj_k_step's duration was ONE lane: a wavefront with a dealing lane spent
+// 141 us in start_kyoku -- SHA3-256, ChaCha12 and the shuffle as ~32 k instructions of a single lane, then four hands initialised one
+// after the other (dependent table gathers) -- on top of the 127 us every wavefront needs.  Here the poll loop hands the deal out: the 64
+// lanes build ONE table's wall together -- the four ChaCha12 blocks side by side on 16 lanes (a block = four lanes, one per column; the
+// diagonal rounds rotate the rows across them), the 28 chunk values of rand 0.9.1's IncreasingUniform by one short serial scan (a chunk
+// consumes one or two words depending on its own first word: Canon's method), the 136 swap partners chunk by chunk on 28 lanes, the swaps
+// themselves by one lane in LDS (a data-dependent chain: 136 x two reads + two writes), the copy to the pool and to the owner's LDS column
+// by all lanes, and the four hands with their shanten numbers on four lanes.  SHA3-256 stays on one lane (24 rounds over 25 words: a
+// cross-lane version trades its 300 instructions per round for ~18 dependent permutes).  Same bytes as deal_wall: the lock-step tests deal
+// every kyoku through this path, tests/test_oracle_deal.py pins the algorithm.  rand 0.8's rejection sampler is serial by nature: lane 0
+// runs the reference-shaped loop of deal_wall for it.
+struct DealPlan {
+    u8 start[28], rem[28];
+    u32 bound[28];
+    constexpr DealPlan() : start(), rem(), bound() {
+        int k = 0;
+        u32 n = 0;
+        int i = 1;  // (position 0 takes the initial chunk: no draw)
+        n = 1;
+        while (i < 136) {
+            const u32 next_n = n + 1;
+            unsigned long long product = next_n;
+            u32 current = next_n + 1;
+            while (product * current <= 0xffffffffull) {
+                product *= current;
+                current += 1;
+            }
+            start[k] = (u8)i;
+            rem[k] = (u8)(current - next_n);
+            bound[k] = (u32)product;
+            k++;
+            n += current - next_n;
+            i += (int)(current - next_n);
+        }
+    }
+};
+__device__ static const DealPlan DEAL_PLAN = DealPlan();
+constexpr bool deal_plan_ok() {
+    constexpr DealPlan p = DealPlan();
+    return p.start[0] == 1 && p.bound[0] == 479001600u && p.rem[0] == 11 && p.start[1] == 12 && p.bound[2] == 3315312000u && p.start[27] == 135 &&
+           p.bound[27] == 357399024u && p.rem[27] == 4;
+}
+static_assert(deal_plan_ok(), "the chunk plan of IncreasingUniform for 136 elements (28 chunks)");
+
+// All 64 lanes call it with the SAME arguments (the dealing table's); `owner` = that table's lane: its pool column `wall` (stride MJ_LANES)
+// and its column of S->wall / S->pre receive the result.
+template <class TablesT>
+MJDN void deal_wall_coop(u8* wall, int stride, DealScratch* S, int owner, u64 nonce, u64 key, int kyoku, int honba, int algo, const TablesT& T) {
+    MJ_ASSUME_LDS(S);
+    const int lane = threadIdx.x & 63;
+    if (algo != 1) {  // rand 0.8: the serial path, on lane 0, into the owner's column
+        if (lane == 0) deal_wall(wall, stride, S, owner, nonce, key, kyoku, honba, algo);
+        mj_team_sync<64>();
+    } else {
+        if (lane == 0) {  // SHA3-256 of the 18-byte message
+            u64 st[25];
+#pragma unroll
+            for (int i = 0; i < 25; i++) st[i] = 0;
+            st[0] = nonce;
+            st[1] = key;
+            st[2] = (u64)(kyoku & 0xFF) | ((u64)(honba & 0xFF) << 8) | (0x06ull << 16);
+            st[16] = 0x80ull << 56;
+            keccak_f(st);
+#pragma unroll
+            for (int i = 0; i < 4; i++) S->cseed[i] = st[i];
+        }
+        // the unshuffled wall, three tiles per lane
+        for (int j = lane; j < 136; j += 64) {
+            const int t = j >> 2;
+            S->cw[j] = (u8)((j & 3) == 0 && (t == T_5M || t == T_5P || t == T_5S) ? (t == T_5M ? T_5MR : t == T_5P ? T_5PR : T_5SR) : t);
+        }
+        mj_team_sync<64>();
+        {   // four ChaCha12 blocks (counters 0 .. 3), a block = four lanes = the four columns of its 4 x 4 state (lanes 16 .. 63 repeat
+            // them: the cross-lane rotations stay outside divergent control flow)
+            const int c = lane & 3, blk = (lane >> 2) & 3;
+            const u32 k0 = (u32)(S->cseed[c >> 1] >> (32 * (c & 1))), k1 = (u32)(S->cseed[2 + (c >> 1)] >> (32 * (c & 1)));
+            const u32 cst = c == 0 ? 0x61707865u : c == 1 ? 0x3320646eu : c == 2 ? 0x79622d32u : 0x6b206574u;
+            const u32 i0 = cst, i1 = k0, i2 = k1, i3 = c == 0 ? (u32)blk : 0u;
+            u32 a = i0, b = i1, cc = i2, d = i3;
+#define DEAL_QR()                                   \
+    a += b; d = rotl32(d ^ a, 16);                  \
+    cc += d; b = rotl32(b ^ cc, 12);                \
+    a += b; d = rotl32(d ^ a, 8);                   \
+    cc += d; b = rotl32(b ^ cc, 7);
+            for (int r = 0; r < 6; r++) {
+                DEAL_QR()  // columns
+                b = __shfl(b, (lane & ~3) | ((c + 1) & 3));
+                cc = __shfl(cc, (lane & ~3) | ((c + 2) & 3));
+                d = __shfl(d, (lane & ~3) | ((c + 3) & 3));
+                DEAL_QR()  // diagonals
+                b = __shfl(b, (lane & ~3) | ((c + 3) & 3));
+                cc = __shfl(cc, (lane & ~3) | ((c + 2) & 3));
+                d = __shfl(d, (lane & ~3) | ((c + 1) & 3));
+            }
+#undef DEAL_QR
+            if (lane < 16) {
+                S->crng[blk * 16 + c] = a + i0;
+                S->crng[blk * 16 + 4 + c] = b + i1;
+                S->crng[blk * 16 + 8 + c] = cc + i2;
+                S->crng[blk * 16 + 12 + c] = d + i3;
+            }
+        }
+        mj_team_sync<64>();
+        if (lane == 0) {  // the chunk values: Canon's method, one or two words per chunk (28 chunks, at most 56 of the 64 words)
+            int idx = 0;
+            for (int k = 0; k < 28; k++) {
+                const u32 bound = DEAL_PLAN.bound[k];
+                const u64 m = (u64)S->crng[idx++] * bound;
+                u32 res = (u32)(m >> 32);
+                const u32 lo = (u32)m;
+                if (lo > (u32)(0u - bound)) {
+                    const u32 new_hi = (u32)(((u64)S->crng[idx++] * bound) >> 32);
+                    res += (lo + new_hi) < lo;
+                }
+                S->cchunk[k] = res;
+            }
+            S->cres[0] = 0;
+        }
+        mj_team_sync<64>();
+        if (lane < 28) {  // the swap partners of a chunk's positions: successive divisions, the last position takes what is left
+            u32 chunk = S->cchunk[lane];
+            const int i0 = DEAL_PLAN.start[lane], rem = DEAL_PLAN.rem[lane];
+            for (int q = 0; q < rem; q++) {
+                const int i = i0 + q;
+                if (i >= 136) break;
+                u32 result;
+                if (q == rem - 1) result = chunk;
+                else {
+                    u32 qq;
+                    deal_divmod(chunk, (u32)(i + 1), qq, result);
+                    chunk = qq;
+                }
+                S->cres[i] = (u8)result;
+            }
+        }
+        mj_team_sync<64>();
+        if (lane == 0) {  // the shuffle itself: a chain of data-dependent swaps
+            for (int i = 1; i < 136; i++) {
+                const int r = S->cres[i];
+                const u8 a = S->cw[i], b = S->cw[r];
+                S->cw[i] = b;
+                S->cw[r] = a;
+            }
+        }
+        mj_team_sync<64>();
+        for (int j = lane; j < 136; j += 64) {  // to the pool and to the owner's column of the lane-interleaved scratch
+            const u8 t = S->cw[j];
+            wall[j * stride] = t;
+            S->wall[j][owner] = t;
+        }
+        mj_team_sync<64>();
+    }
+    if (lane < 4) {  // the four hands and their shanten numbers (kyoku_init takes them from S->pre[owner])
+        Hand h = {0, 0};
+        u8 akas = 0;
+        for (int i = 0; i < 13; i++) {
+            const int t = S->wall[lane * 13 + i][owner];
+            h.inc(deaka(t));
+            if (is_aka(t)) akas |= 1 << (t - T_5MR);
+        }
+        const int sv = calc_all(T, h, 4);
+        DealPre& P = S->pre[owner];
+        P.hand[lane][0] = (u32)h.mp; P.hand[lane][1] = (u32)(h.mp >> 32); P.hand[lane][2] = (u32)h.sz; P.hand[lane][3] = (u32)(h.sz >> 32);
+        P.akas[lane] = akas;
+        P.shanten[lane] = (signed char)sv;
+    }
+    mj_team_sync<64>();
 }

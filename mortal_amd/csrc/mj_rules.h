@@ -595,7 +595,8 @@ template <class LN> MJD void ev_reach_accepted(const LN& L, int actor) {  // upd
 // `lw`: the freshly dealt wall as this lane's column of the wavefront's DealScratch (stride DEAL_LANES), or NULL: the wall is read from the pool.
 // The four hands, their shanten numbers and the dora marker are taken BEFORE the ~150 field stores below: a load issued after them waits for
 // every one (vmcnt counts stores), and start_kyoku runs on ONE lane of a wavefront that is mj_k_step's critical path.
-template <class LN> MJDN void kyoku_init(const LN& L, const u8* lw = nullptr) {
+// `pre`: the four hands with their shanten numbers as the wavefront's deal service left them (deal_wall_coop), or NULL: computed here.
+template <class LN> MJDN void kyoku_init(const LN& L, const u8* lw = nullptr, const DealPre* pre = nullptr) {
     auto wall_at = [&](int i) -> int {
         if (lw) {
             MJ_ASSUME_LDS(lw);  // (only on this branch: the pointer may be NULL)
@@ -607,19 +608,30 @@ template <class LN> MJDN void kyoku_init(const LN& L, const u8* lw = nullptr) {
     Hand hh[4];
     u8 ak[4];
     int sv[4];
+    if (pre) {
+        MJ_ASSUME_LDS(pre);
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        Hand h = {0, 0};
-        u8 akas = 0;
-        for (int i = 0; i < 13; i++) {
-            const int t = wall_at(s * 13 + i);
-            if (t >= T_UNK) continue;  // hidden hand of a single-perspective log
-            h.inc(deaka(t));
-            if (is_aka(t)) akas |= 1 << (t - T_5MR);
+        for (int s = 0; s < 4; s++) {
+            hh[s].mp = (u64)pre->hand[s][0] | ((u64)pre->hand[s][1] << 32);
+            hh[s].sz = (u64)pre->hand[s][2] | ((u64)pre->hand[s][3] << 32);
+            ak[s] = pre->akas[s];
+            sv[s] = pre->shanten[s];
         }
-        hh[s] = h;
-        ak[s] = akas;
-        sv[s] = calc_all(*L.T, h, 4);  // (update_shanten of the hand just built: len_div3 = 4)
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            Hand h = {0, 0};
+            u8 akas = 0;
+            for (int i = 0; i < 13; i++) {
+                const int t = wall_at(s * 13 + i);
+                if (t >= T_UNK) continue;  // hidden hand of a single-perspective log
+                h.inc(deaka(t));
+                if (is_aka(t)) akas |= 1 << (t - T_5MR);
+            }
+            hh[s] = h;
+            ak[s] = akas;
+            sv[s] = calc_all(*L.T, h, 4);  // (update_shanten of the hand just built: len_div3 = 4)
+        }
     }
     F(yama_n) = 70;
     F(rinshan_n) = 4;
@@ -689,15 +701,17 @@ template <class LN> MJDN void kyoku_init(const LN& L, const u8* lw = nullptr) {
     for (int s = 0; s < 4; s++)
         if (sv[s] <= 0) update_waits_and_furiten(L, s);
 }
-template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo) {
+// `dealt`: the wavefront's deal service (deal_wall_coop, mj_k_step) has put the wall into the pool, into this lane's column of the LDS
+// scratch and the four hands into its DealPre; otherwise the lane deals by itself.
+template <class LN> MJDN void start_kyoku(const LN& L, int deal_algo, bool dealt = false) {
     static_assert(MJ_LANES == DEAL_LANES, "one DealScratch column per pool lane");
     const int kyoku = F(kyoku), honba = F(honba);
     SPROF_T(t_d);
-    deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, L.deal, L.l, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
+    if (!dealt) deal_wall((uint8_t*)&L.B->wall[0][L.l], MJ_LANES, L.deal, L.l, F(seed_nonce), F(seed_key), kyoku, honba, deal_algo);
     SPROF_ADD(19, t_d);
     SPROF_T(t_i);
     const u8* const lw = L.deal ? &L.deal->wall[0][L.l] : nullptr;  // the wall just dealt, still in the wavefront's LDS scratch
-    kyoku_init(L, lw);
+    kyoku_init(L, lw, dealt && L.deal ? &L.deal->pre[L.l] : nullptr);
     SPROF_ADD(20, t_i);
     int marker, tile;  // dora marker, the oya's first tsumo
     if (lw) {

@@ -595,11 +595,13 @@ template <class LN> MJD bool any_can_act(const LN& L) {
 }
 
 // Game::poll (game.rs:59-178) with BoardState::poll (board.rs:141-161) inlined.
-template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepParams& P) {
+// Returns true when the table needs a kyoku dealt and `deal_service` is set (mj_k_step: the wavefront deals it together, deal_wall_coop,
+// and calls again with `dealt`); false when the poll is over (a seat can act, or the game has ended).
+template <class LN> MJDN bool game_poll(const LN& L, Reaction rx[4], const StepParams& P, bool deal_service = false, bool dealt = false) {
     for (;;) {
         u32 fl = F(flags);
-        if (fl & TF_ENDED) return;
-        if (F(err) != MJ_OK) { F(flags) = fl | TF_ENDED; return; }
+        if (fl & TF_ENDED) return false;
+        if (F(err) != MJ_OK) { F(flags) = fl | TF_ENDED; return false; }
         bool kyoku_end;
         if (!(fl & TF_KYOKU_STARTED)) {
             const int kyoku = F(kyoku), len = P.game_length;
@@ -607,10 +609,12 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
             for (int i = 0; i < 4; i++) any30k |= F1(scores, i) >= 30000;
             if (kyoku >= len + 4 || (kyoku >= len && !(fl & TF_IN_RENCHAN) && any30k)) {
                 F(flags) = fl | TF_ENDED;
-                return;
+                return false;
             }
+            if (deal_service && !dealt) return true;  // (the caller deals, then calls again)
             SPROF_T(t_sk);
-            start_kyoku(L, P.deal_algo);  // haipai + first tsumo == the first board step (board.rs:512-515)
+            start_kyoku(L, P.deal_algo, dealt);  // haipai + first tsumo == the first board step (board.rs:512-515)
+            dealt = false;
             SPROF_ADD(3, t_sk);
             kyoku_end = false;
         } else {
@@ -624,7 +628,7 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
             SPROF_T(t_ca);
             const bool act = any_can_act(L);
             SPROF_ADD(5, t_ca);
-            if (act) return;
+            if (act) return false;
             continue;
         }
         SPROF_CNT(10);
@@ -639,7 +643,7 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
         for (int i = 0; i < 4; i++) tobi |= F1(scores, i) < 0;
         if (tobi) {
             F(flags) = fl | TF_ENDED;
-            return;
+            return false;
         }
         const int kyoku = F(kyoku);
         if (fl & TF_HAS_ABORTIVE) {
@@ -656,7 +660,7 @@ template <class LN> MJDN void game_poll(const LN& L, Reaction rx[4], const StepP
                     if (F1(scores, i) > F1(scores, top)) top = i;
                 if (top == oya) {
                     F(flags) = fl | TF_ENDED;
-                    return;
+                    return false;
                 }
             }
             fl |= TF_IN_RENCHAN;
@@ -686,9 +690,10 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
     const bool active = table < P.n_tables && !(fl & TF_INACTIVE);
     bool live_after = false;
     int n_dec = 0, n_quick = 0;
-    if (active && !(fl & TF_DONE)) {
+    Reaction rx[4];
+    const bool playing = active && !(fl & TF_DONE);
+    if (playing) {
         // ---- commit (game.rs:180-218)
-        Reaction rx[4];
         const int pend = F(pending);
         for (int s = 0; s < 4; s++) {
             rx[s].type = RX_NONE;
@@ -734,10 +739,32 @@ __global__ __launch_bounds__(64) void mj_k_step(StepParams P) {
         }
         F(pending) = 0;
         SPROF_ADD(1, t_k0);
-        // ---- poll
+    }
+    // ---- poll, with the deal as a service of the whole wavefront (mj_deal.h: deal_wall_coop): a lane whose table needs a kyoku leaves its
+    // poll loop, the 64 lanes deal the tables that asked one after the other, the lanes go back in.  Wave-uniform control flow.
+    {
         SPROF_T(t_gp);
-        game_poll(L, rx, P);
+        bool want = playing, dealt = false;
+        for (;;) {
+            bool need = false;
+            if (want) need = game_poll(L, rx, P, true, dealt);
+            unsigned long long m = __ballot(need);
+            if (m == 0ull) break;
+            const u64 my_nonce = need ? F(seed_nonce) : 0ull, my_key = need ? F(seed_key) : 0ull;
+            const int my_kh = need ? ((int)F(kyoku) | ((int)F(honba) << 8)) : 0;
+            for (; m; m &= m - 1) {
+                const int d = __ffsll((long long)m) - 1;
+                const u64 nonce = (u64)(u32)__shfl((int)(u32)my_nonce, d) | ((u64)(u32)__shfl((int)(u32)(my_nonce >> 32), d) << 32);
+                const u64 key = (u64)(u32)__shfl((int)(u32)my_key, d) | ((u64)(u32)__shfl((int)(u32)(my_key >> 32), d) << 32);
+                const int kh = __shfl(my_kh, d);
+                deal_wall_coop((uint8_t*)&L.B->wall[0][d], MJ_LANES, &s_deal, d, nonce, key, kh & 0xFF, (kh >> 8) & 0xFF, P.deal_algo, c_mj_tables);
+            }
+            want = need;
+            dealt = need;
+        }
         SPROF_ADD(2, t_gp);
+    }
+    if (playing) {
         SPROF_T(t_cl);
         fl = F(flags);
         if (fl & TF_ENDED) {

@@ -170,6 +170,19 @@ class DeviceEngine:
                 greedy_all[i:i + m] = is_greedy
         return (out, q_all, greedy_all) if want_meta else out
 
+    def warm(self, obs_rows=1012):
+        """Compile every bucket shape now (compiled path only): with dynamic=False a chunk size seen for the first time costs ~10 s of
+        inductor, and a batch's ragged tail changes bucket from one call to the next.  Call it once before a timed / latency-sensitive loop."""
+        if not self.compiled:
+            return
+        b = 256
+        while b <= self.max_batch:
+            self.react_batch_device(torch.zeros((b, obs_rows, 34), dtype=torch.float32, device=self.device),
+                                    torch.ones((b, 46), dtype=torch.bool, device=self.device))
+            b *= 2
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def _bucket(self, m):
         """The padded row count of an m-row chunk on the compiled path: the next power of two >= max(m, 256), at most max_batch."""
         b = 256

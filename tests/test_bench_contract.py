@@ -77,7 +77,7 @@ def test_design_quotes_the_committed_numbers():
     assert f"`mj_k_sp` {d['kernel_ms_per_step']['mj_k_sp']:.1f} ms" in text
     assert "builder-run" in text  # the committed line is the builder's box; the numbers of record are the driver's
     # ... and the driver's last record is quoted next to it (DESIGN quoted the builder's best box only)
-    drv = [(r, p) for r, p in _driver_lines() if r == "r04"]
+    drv = [(r, p) for r, p in _driver_lines() if r == "r05"]  # the last driver record when this text was written
     if drv:
         p = drv[0][1]
         assert f"{p['value'] / 1e6:.3f} M env steps/s" in text and f"{p['ms_per_step']:.1f} ms/cycle" in text
