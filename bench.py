@@ -338,11 +338,12 @@ def _brain_workload(pool_cls, N, g0, world, dev, preroll, bufs, other_ms=None, c
 
     try:
         torch.manual_seed(0)
-        engine = DeviceEngine(PolicyNet(version=4), 4, dev, enable_amp=True, compile_net=compile_net, max_batch=8192 if compile_net else 16384)
+        engine = DeviceEngine(PolicyNet(version=4), 4, dev, enable_amp=True, compile_net=compile_net, max_batch=8192 if compile_net else 16384, min_bucket=512)
         if compile_net:
-            # every bucket shape a ragged tail can take is compiled BEFORE the timed cycles (round 6: the tail of a 65.8 k-row batch is 200-400
-            # rows, i.e. the 256- or the 512-row bucket depending on the cycle -- a first-time shape inside the 3 timed cycles cost ~10 s of inductor)
-            engine.warm()
+            # the two chunk shapes of this workload are compiled BEFORE the timed cycles: 8,192 rows, and the 512-row bucket of the batch's
+            # ragged tail (65.8 k rows = 8 x 8,192 + 200..400).  Round 6's first line had a tail bucket seen for the first time INSIDE the 3 timed
+            # cycles: ~10 s of inductor counted as 3 cycles of play (15 k instead of 145 k env steps/s)
+            engine.warm(buckets=[512, 8192])
         r = _measure(pool_cls, N, g0, world, dev, 4, preroll, "brain", 3 if compile_net else 2, 1, bufs, engine)
     except Exception as e:  # noqa: BLE001 - an extra workload must never cost the headline line
         return {"error": repr(e)[:300]}

@@ -106,7 +106,7 @@ class DeviceEngine:
 
     def __init__(self, net, version, device, name="mortal_amd", enable_amp=True, enable_quick_eval=True,
                  max_batch=16384, boltzmann_epsilon=0, boltzmann_temp=1, top_p=1, enable_rule_based_agari_guard=False,
-                 return_meta=False, seed=None, compile_net="auto"):
+                 return_meta=False, seed=None, compile_net="auto", min_bucket=256):
         self.net = net.to(device).eval()  # always the EAGER module: state_dict() / load_state_dict() keys stay the reference's
         # compile_net: the forward runs through torch.compile (PyTorch's inductor) of the same module under the same autocast --
         # measured 7.1 x the eager forward on MI355X for the 192 x 40 net (tools/brain_tune.py, bench.py workloads.brain_v4_compiled).
@@ -124,6 +124,7 @@ class DeviceEngine:
         self.compiled = bool(compile_net)
         self._fwd = torch.compile(self.net, dynamic=False) if self.compiled else self.net
         self._stage = {}
+        self.min_bucket = int(min_bucket)  # the smallest padded chunk of the compiled path (a power of two)
         self.version = version
         self.device = torch.device(device)
         self.name = name
@@ -170,22 +171,25 @@ class DeviceEngine:
                 greedy_all[i:i + m] = is_greedy
         return (out, q_all, greedy_all) if want_meta else out
 
-    def warm(self, obs_rows=1012):
+    def warm(self, obs_rows=1012, buckets=None):
         """Compile every bucket shape now (compiled path only): with dynamic=False a chunk size seen for the first time costs ~10 s of
         inductor, and a batch's ragged tail changes bucket from one call to the next.  Call it once before a timed / latency-sensitive loop."""
         if not self.compiled:
             return
-        b = 256
-        while b <= self.max_batch:
+        if buckets is None:  # every bucket; or only the chunk sizes the caller knows its batches produce
+            buckets, b = [], self.min_bucket
+            while b <= self.max_batch:
+                buckets.append(b)
+                b *= 2
+        for b in buckets:
             self.react_batch_device(torch.zeros((b, obs_rows, 34), dtype=torch.float32, device=self.device),
                                     torch.ones((b, 46), dtype=torch.bool, device=self.device))
-            b *= 2
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
     def _bucket(self, m):
         """The padded row count of an m-row chunk on the compiled path: the next power of two >= max(m, 256), at most max_batch."""
-        b = 256
+        b = self.min_bucket
         while b < m:
             b *= 2
         return min(b, self.max_batch)
