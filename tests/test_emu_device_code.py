@@ -258,3 +258,26 @@ def test_emu_lockstep_v4_every_large_row_promoted_to_the_wide_kernel(oracle, emu
     st = parity_util.run_lockstep(oracle, 4, version=4, max_cycles=50, obs_every=1, pool_cls=emu, sp_rows_checked=True,
                                   policy="greedy", verbose=False)
     assert st["obs_checked"] > 150 and st["counters"]["sp_overflow"] == 0 and st["sp_schedule"]["rows_swept"] == 0, st["sp_schedule"]
+
+
+def test_emu_sp_schedule_api(emu):
+    """include/mortal_amd.h mj_pool_set_sp_schedule / mj_sp_schedule_stats: mode 0 before the first obs-v4 encode = no spare work areas, every
+    launch runs mj_k_sp alone; asking for the schedule afterwards is refused (the areas are sized at the first encode); thresholds may change."""
+    import numpy as np
+    import torch
+
+    from mortal_amd._lib import MortalAmdError
+
+    pool = emu(4, version=4)
+    pool.reset(parity_util.default_seeds(4), game_ids=np.arange(4), n_games_total=4)
+    pool.set_sp_schedule(mode=0)
+    act = None
+    for i in range(12):
+        n, _ = pool.step(act, None)
+        obs, masks = pool.encode(0)
+        act = pool.random_policy(0, masks, 1, i)
+    assert pool.sp_schedule_stats() == {"hybrid_launches": 0, "rows_promoted": 0, "rows_swept": 0, "wide_gave_up": 0}
+    with pytest.raises(MortalAmdError):
+        pool.set_sp_schedule(mode=1)
+    pool.set_sp_schedule(min_level1=900, min_level2=300)  # (allowed: only mode needs the areas)
+    pool.close()
