@@ -141,6 +141,8 @@ int mj_sp_phase_ticks(MjPool* pool, uint64_t* out8, void* stream);
  * mj_k_sp, and with few rows per launch the launch lasts as long as its heaviest row.  With the schedule on, a workgroup that finds a
  * row's state graph large (the level it is about to expand has >= min_level1 / min_level2 states) parks the row and a 1,024-thread
  * workgroup of the kernel mj_k_sp_wide [wide_grid of them, one per CU, running beside mj_k_sp] finishes it; results are bit-identical either way.
+ * In auto mode the schedule switches itself off for a pool whose two kernels turn out not to overlap (more concurrent streams than hardware
+ * queues: the wide workgroups give up after 50 ms, the sweep launch still finishes every parked row, one line on stderr).
  * mode: -1 auto (launches of at most max_rows rows; the default, also settable through MJ_SP_WIDE / MJ_SP_WIDE_MAX_ROWS /
  * MJ_SP_WIDE_GRID / MJ_SP_PROMO_MIN1 / _MIN2), 0 never, 1 every launch.  Arguments <= 0 keep the current value (mode: < -1).
  * Call it before the pool's first obs-v4 mj_encode (the spare work areas are sized then); afterwards only mode 0 / the thresholds change. */

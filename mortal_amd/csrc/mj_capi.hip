@@ -165,6 +165,8 @@ struct MjPool {
     hipStream_t sp_stream2 = nullptr;   // mj_k_sp's stream while mj_k_sp_wide runs on the caller's
     hipEvent_t sp_ev_fork = nullptr, sp_ev_join = nullptr;
     uint64_t sp_hybrid_launches = 0;
+    unsigned long long* sp_gaveup_host = nullptr;  // pinned: the device's count of wide workgroups that gave up waiting, copied behind every sweep
+    bool sp_wide_off = false;       // the two kernels did not overlap on this system: the schedule switched itself off (see mj_encode)
     bool sp_sched_set = false;      // mj_pool_set_sp_schedule was called: the environment does not override it
     int* sp_queue = nullptr;        // [0] row queue head, [1..8] / [9..16] class counts / cursors of the row sort, [SP_Q_TAIL] head of the tail
     uint32_t* sp_order = nullptr;   // [max_rows] queue position -> row
@@ -372,6 +374,7 @@ void mj_pool_destroy(MjPool* P) {
     hipFree(P->rp_script); hipFree(P->rp_off); hipFree(P->rp_cursor); hipFree(P->rp_ev_index);
     hipFree(P->rp_kyoku); hipFree(P->rp_tracked); hipFree(P->rp_label); hipFree(P->rp_kan_label);
     if (P->n_rows_host) hipHostFree(P->n_rows_host);
+    if (P->sp_gaveup_host) hipHostFree(P->sp_gaveup_host);
     if (P->ev_rows) hipEventDestroy(P->ev_rows);
     if (P->ev_snap) hipEventDestroy(P->ev_snap);
     hipFree(P->counters);
@@ -811,7 +814,16 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
                 HIP_OK(hipMemsetAsync(P->sp_err + 29, 0, 24, s));
             }
             int grid = n < P->sp_grid ? n : P->sp_grid;
-            const bool hybrid = P->sp_spare > 0 && (P->sp_wide_mode > 0 || (P->sp_wide_mode < 0 && n <= P->sp_wide_max_rows));
+            // The schedule needs mj_k_sp_wide and mj_k_sp_promo side by side.  Where they do not overlap -- more streams in the process than the
+            // runtime has hardware queues, so that the promo kernel queues up BEHIND the spinning wide kernel -- the wide workgroups give up
+            // after SP_WIDE_TIMEOUT, the sweep launch still produces the same obs, and the give-ups (copied to pinned memory behind every
+            // sweep) switch the schedule off for this pool: one slow launch, then mj_k_sp alone as in round 5.
+            if (P->sp_wide_mode < 0 && P->sp_gaveup_host && *P->sp_gaveup_host && !P->sp_wide_off) {  // (auto mode only: mode 1 = every launch, as asked)
+                P->sp_wide_off = true;
+                fprintf(stderr, "[mortal_amd] small-pool SP schedule switched off for this pool: mj_k_sp_wide and mj_k_sp_promo did not run side by side "
+                                "(%llu wide workgroups gave up waiting; more concurrent streams than hardware queues?)\n", *P->sp_gaveup_host);
+            }
+            const bool hybrid = P->sp_spare > 0 && !P->sp_wide_off && (P->sp_wide_mode > 0 || (P->sp_wide_mode < 0 && n <= P->sp_wide_max_rows));
             sp.promo_cap = hybrid ? P->sp_spare : 0;
             // Defaults measured on MI355X (tools/r06_sweep.sh): up to ~12 k rows 64 wide workgroups (a quarter of the CUs),
             // rows parked at >= 1,200 level-1 states (or >= 400 level-2 states, before that level is expanded); up to ~20 k rows 32 wide
@@ -856,6 +868,8 @@ int mj_encode(MjPool* P, int agent, float* obs, uint8_t* masks, void* stream) {
                 }
                 sp.sweep = 1;
                 hipLaunchKernelGGL(mj_k_sp_wide, dim3(wgrid), dim3(SP_WIDE_THREADS), 0, s, sp);
+                if (!P->sp_gaveup_host && hipHostMalloc(&P->sp_gaveup_host, sizeof(unsigned long long)) == hipSuccess) *P->sp_gaveup_host = 0ull;
+                if (P->sp_gaveup_host) HIP_OK(hipMemcpyAsync(P->sp_gaveup_host, P->sp_err + 25, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             }
             if (sp.rowdump) {
                 std::vector<uint32_t> h((size_t)n * 12);

@@ -2055,7 +2055,7 @@ struct SpHandoff {
 };
 static_assert(sizeof(SpHandoff) <= SP_HANDOFF_WORDS * 4 && sizeof(SpHandoff) % 4 == 0, "SpWork::handoff holds an SpHandoff");
 #ifndef SP_WIDE_TIMEOUT
-#define SP_WIDE_TIMEOUT 20000000ll  // wall_clock64 ticks (100 MHz): 200 ms
+#define SP_WIDE_TIMEOUT 5000000ll  // wall_clock64 ticks (100 MHz): 50 ms (a legitimate wait ends with mj_k_sp_promo's last row: milliseconds)
 #endif
 // The hand-off's two fences (MI355X_MICROARCH.md, inter-workgroup visibility: per-XCD L2s are not coherent with each other, a CU's L1 is never
 // refreshed by another CU's stores).  Producer: every wavefront drains its stores, workgroup barrier, ONE lane releases at agent scope
