@@ -222,10 +222,42 @@ MJDN void deal_wall(u8* wall, int stride, DealScratch* S, int lane, u64 nonce, u
 // diagonal rounds rotate the rows across them), the 28 chunk values of rand 0.9.1's IncreasingUniform by one short serial scan (a chunk
 // consumes one or two words depending on its own first word: Canon's method), the 136 swap partners chunk by chunk on 28 lanes, the swaps
 // themselves by one lane in LDS (a data-dependent chain: 136 x two reads + two writes), the copy to the pool and to the owner's LDS column
-// by all lanes, and the four hands with their shanten numbers on four lanes.  SHA3-256 stays on one lane (24 rounds over 25 words: a
-// cross-lane version trades its 300 instructions per round for ~18 dependent permutes).  Same bytes as deal_wall: the lock-step tests deal
+// by all lanes, and the four hands with their shanten numbers on four lanes; SHA3-256's permutation runs on 25 lanes (keccak_f_lanes).  Same bytes as deal_wall: the lock-step tests deal
 // every kyoku through this path, tests/test_oracle_deal.py pins the algorithm.  rand 0.8's rejection sampler is serial by nature: lane 0
 // runs the reference-shaped loop of deal_wall for it.
+// Keccak-f[1600] across 25 lanes of the wavefront (lane i holds word i = x + 5 y); every lane of the wavefront executes it (the cross-lane
+// moves stay outside divergent control flow), lanes 25 .. 63 carry don't-care values.  Per round: column parities (four moves), theta's two
+// neighbours, rho + pi as ONE move of the rotated word (lane (x', y') pulls from x = 3 (y' + 2 x') mod 5, y = x'), chi's two neighbours --
+// nine 64-bit moves and ~40 instructions instead of the ~300 instructions of keccak_f's single-lane round.
+__device__ static const u8 KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+MJD u64 deal_shfl64(u64 v, int src) {
+    const u32 lo = (u32)__shfl((int)(u32)v, src), hi = (u32)__shfl((int)(u32)(v >> 32), src);
+    return (u64)lo | ((u64)hi << 32);
+}
+MJD u64 keccak_f_lanes(u64 a, int lane) {
+    const bool in = lane < 25;
+    const int i = in ? lane : 0, x = i % 5, y = i / 5;
+    int col[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) col[k] = in ? (i + 5 * (k + 1)) % 25 : lane;
+    const int xm1 = in ? y * 5 + (x + 4) % 5 : lane, xp1 = in ? y * 5 + (x + 1) % 5 : lane, xp2 = in ? y * 5 + (x + 2) % 5 : lane;
+    // pi: b[x', y'] = rot(a[x, y]) with x' = y, y' = (2 x + 3 y) mod 5  =>  this lane (x', y') = (x, y) pulls from (3 (y + 2 x) mod 5, x)
+    const int pi_src = in ? (3 * ((y + 2 * x) % 5)) % 5 + 5 * x : lane;
+    const unsigned rot = KECCAK_RHO[i];
+    for (int round = 0; round < 24; round++) {
+        u64 c = a;
+#pragma unroll
+        for (int k = 0; k < 4; k++) c ^= deal_shfl64(a, col[k]);
+        const u64 d = deal_shfl64(c, xm1) ^ rotl64(deal_shfl64(c, xp1), 1);
+        a ^= d;
+        const u64 t = (a << rot) | (a >> ((64u - rot) & 63u));
+        const u64 b = deal_shfl64(t, pi_src);
+        a = b ^ (~deal_shfl64(b, xp1) & deal_shfl64(b, xp2));
+        if (lane == 0) a ^= KECCAK_RC[round];
+    }
+    return a;
+}
+
 struct DealPlan {
     u8 start[28], rem[28];
     u32 bound[28];
@@ -269,17 +301,11 @@ MJDN void deal_wall_coop(u8* wall, int stride, DealScratch* S, int owner, u64 no
         if (lane == 0) deal_wall(wall, stride, S, owner, nonce, key, kyoku, honba, algo);
         mj_team_sync<64>();
     } else {
-        if (lane == 0) {  // SHA3-256 of the 18-byte message
-            u64 st[25];
-#pragma unroll
-            for (int i = 0; i < 25; i++) st[i] = 0;
-            st[0] = nonce;
-            st[1] = key;
-            st[2] = (u64)(kyoku & 0xFF) | ((u64)(honba & 0xFF) << 8) | (0x06ull << 16);
-            st[16] = 0x80ull << 56;
-            keccak_f(st);
-#pragma unroll
-            for (int i = 0; i < 4; i++) S->cseed[i] = st[i];
+        {   // SHA3-256 of the 18-byte message: one rate block (136 B), pad 0x06 .. 0x80; the permutation on 25 lanes
+            u64 a = lane == 0 ? nonce : lane == 1 ? key : lane == 2 ? ((u64)(kyoku & 0xFF) | ((u64)(honba & 0xFF) << 8) | (0x06ull << 16))
+                  : lane == 16 ? (0x80ull << 56) : 0ull;
+            a = keccak_f_lanes(a, lane);
+            if (lane < 4) S->cseed[lane] = a;
         }
         // the unshuffled wall, three tiles per lane
         for (int j = lane; j < 136; j += 64) {
